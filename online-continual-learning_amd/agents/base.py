@@ -1,0 +1,170 @@
+"""agents/base.py:14-227 — ContinualLearner: label bookkeeping, criterion (CE / SupCon), review trick, and
+evaluate() with the nearest-class-mean classifier (NCM) or argmax, on the MI355X.
+
+Only the branches BASELINE.json's configs use are implemented; the labels / separated-softmax / KD tricks raise
+NotImplementedError instead of silently doing something else."""
+from abc import abstractmethod
+import abc
+import copy
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..loss import SupConLoss, cross_entropy_mean
+from ..utils import maybe_cuda, AverageMeter
+
+
+class ContinualLearner(torch.nn.Module, metaclass=abc.ABCMeta):
+    '''
+    Abstract module which is inherited by each and every continual learning algorithm.
+    '''
+
+    def __init__(self, model, opt, params):
+        super(ContinualLearner, self).__init__()
+        self.params = params
+        self.model = model
+        self.opt = opt
+        self.data = params.data
+        self.cuda = params.cuda
+        self.epoch = params.epoch
+        self.batch = params.batch
+        self.verbose = params.verbose
+        self.old_labels = []
+        self.new_labels = []
+        self.task_seen = 0
+        self.lbl_inv_map = {}
+        self.class_task_map = {}
+        for t in ('labels_trick', 'separated_softmax', 'kd_trick', 'kd_trick_star'):
+            if params.trick.get(t, False):
+                raise NotImplementedError("trick %r is outside the HIP hot path (BASELINE configs keep it off)" % t)
+        if getattr(params, 'error_analysis', False):
+            raise NotImplementedError("error_analysis is outside the HIP hot path")
+
+    def before_train(self, x_train, y_train):
+        """agents/base.py:43-50."""
+        new_labels = list(set(y_train.tolist()))
+        self.new_labels += new_labels
+        for i, lbl in enumerate(new_labels):
+            self.lbl_inv_map[lbl] = len(self.old_labels) + i
+
+        for i in new_labels:
+            self.class_task_map[i] = self.task_seen
+
+    @abstractmethod
+    def train_learner(self, x_train, y_train):
+        pass
+
+    def after_train(self):
+        """agents/base.py:56-91 (review trick branch :62-88)."""
+        self.old_labels += self.new_labels
+        self.new_labels_zombie = copy.deepcopy(self.new_labels)
+        self.new_labels.clear()
+        self.task_seen += 1
+        if self.params.trick['review_trick'] and hasattr(self, 'buffer'):
+            self.model.train()
+            filled = self.buffer.current_index
+            if filled > 0:
+                from torch.utils.data import DataLoader
+                from ..data import _IndexDataset
+                bs = self.params.eps_mem_batch
+                rv_loader = DataLoader(_IndexDataset(filled), batch_size=bs, shuffle=True, num_workers=0, drop_last=True)
+                dev = self.buffer.buffer_img.device
+                for ep in range(1):
+                    for i, idx in enumerate(rv_loader):
+                        idx = idx.to(dev)
+                        batch_x = ops.gather_rows(self.buffer.buffer_img, idx)
+                        batch_y = ops.gather_rows(self.buffer.buffer_label, idx)
+                        if self.params.agent == 'SCR':
+                            # the reference also runs one extra plain forward whose only effect is a BatchNorm
+                            # running-stat update (base.py:77) before the two-view forwards (:78-80)
+                            with torch.no_grad():
+                                self.model.forward(batch_x)
+                            feats = self.model.forward_views([batch_x, self.transform(batch_x)])
+                            loss = self.criterion_views(feats, batch_y, 2)
+                        else:
+                            logits = self.model.forward(batch_x)
+                            loss = self.criterion(logits, batch_y)
+                        self.opt.zero_grad()
+                        loss.backward()
+                        self._step_scaled(0.1)   # grads / 10 (base.py:84-87)
+
+    def _step_scaled(self, scale):
+        if hasattr(self.opt, "model"):
+            self.opt.step(grad_scale=scale)
+        else:
+            for p in self.model.parameters():
+                if p.requires_grad and p.grad is not None:
+                    p.grad.data.mul_(scale)
+            self.opt.step()
+
+    def criterion(self, logits, labels):
+        """agents/base.py:93-113."""
+        labels = labels.clone()
+        if self.params.agent in ['SCR', 'SCP']:
+            SC = SupConLoss(temperature=self.params.temp)
+            return SC(logits, labels)
+        else:
+            return cross_entropy_mean(logits, labels)
+
+    def criterion_views(self, feat_view_major, labels, n_views):
+        """SupConLoss on the engine's native view-major [n_views*bsz, dim] layout (no permute / cat)."""
+        SC = SupConLoss(temperature=self.params.temp)
+        return SC.forward_view_major(feat_view_major, labels, n_views)
+
+    def forward(self, x):
+        return self.model.forward(x)
+
+    def evaluate(self, test_loaders):
+        """agents/base.py:118-227.  The reference extracts exemplar features one image at a time (:130-134);
+        eval-mode BatchNorm makes the batched extraction below numerically equivalent per sample."""
+        self.model.eval()
+        acc_array = np.zeros(len(test_loaders))
+        use_ncm = self.params.trick['ncm_trick'] or self.params.agent in ['ICARL', 'SCR', 'SCP']
+        if use_ncm:
+            buffer_filled = self.buffer.current_index
+            dev = self.buffer.buffer_img.device
+            labels = self.buffer.buffer_label[:buffer_filled].contiguous()
+            # every buffered label must be a seen class (the reference would raise KeyError, base.py:126)
+            host_labels = set(self.buffer.label_host[:buffer_filled].tolist())
+            missing = host_labels - set(self.old_labels)
+            if missing:
+                raise KeyError(sorted(missing)[0])
+            class_ids = torch.tensor(self.old_labels, dtype=torch.long, device=dev)
+            with torch.no_grad():
+                if buffer_filled > 0:
+                    feats = self.model.features_batched(self.buffer.buffer_img[:buffer_filled])
+                else:
+                    feats = torch.zeros((0, self.model.feature_dim), device=dev)
+                means, counts = ops.ncm_class_means(feats, labels, class_ids)
+                counts_h = counts.cpu().numpy()
+                for ci in range(len(self.old_labels)):   # dict order of cls_exemplar = old_labels order
+                    if counts_h[ci] == 0:
+                        # no exemplar: random mean (base.py:135-137), drawn on the CPU generator
+                        mu_y = torch.normal(0, 1, size=(1, feats.shape[1])).squeeze()
+                        mu_y = mu_y / mu_y.norm()
+                        means[ci] = mu_y.to(dev)
+        with torch.no_grad():
+            for task, test_loader in enumerate(test_loaders):
+                acc = AverageMeter()
+                correct = []
+                sizes = []
+                for i, (batch_x, batch_y) in enumerate(test_loader):
+                    batch_x = maybe_cuda(batch_x, self.cuda)
+                    batch_y = maybe_cuda(batch_y, self.cuda)
+                    if use_ncm:
+                        feature = self.model.features_batched(batch_x)  # (batch_size, feature_size)
+                        pred = ops.ncm_predict(feature, means)
+                        pred_label = ops.gather_rows(class_ids, pred)
+                    else:
+                        logits = self.model.forward(batch_x)
+                        _, pred_label = torch.max(logits, 1)
+                    correct.append((pred_label == batch_y).sum())
+                    sizes.append(batch_y.size(0))
+                if correct:
+                    correct_h = torch.stack(correct).cpu().tolist()   # one sync per task loader
+                    for c, n in zip(correct_h, sizes):
+                        acc.update(c / n, n)
+                acc_array[task] = acc.avg()
+        print(acc_array)
+        return acc_array

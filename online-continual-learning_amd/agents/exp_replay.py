@@ -1,0 +1,89 @@
+"""agents/exp_replay.py:10-104 — Experience Replay inner loop (also hosts MIR / ASER through the plugins)."""
+import torch
+
+from ..buffer import Buffer
+from ..data import DeviceLoader
+from ..utils import maybe_cuda, AverageMeter
+from .base import ContinualLearner
+
+
+class ExperienceReplay(ContinualLearner):
+    def __init__(self, model, opt, params):
+        super(ExperienceReplay, self).__init__(model, opt, params)
+        self.buffer = Buffer(model, params)
+        self.mem_size = params.mem_size
+        self.eps_mem_batch = params.eps_mem_batch
+        self.mem_iters = params.mem_iters
+
+    def train_learner(self, x_train, y_train):
+        self.before_train(x_train, y_train)
+        # set up loader: device-resident task, same sampler / RNG draws as the reference's DataLoader
+        train_loader = DeviceLoader(x_train, y_train, self.batch, shuffle=True, drop_last=True)
+        # set up model
+        self.model = self.model.train()
+
+        # setup tracker
+        losses_batch = AverageMeter()
+        losses_mem = AverageMeter()
+        acc_batch = AverageMeter()
+        acc_mem = AverageMeter()
+        aser = self.params.update == 'ASER' or self.params.retrieve == 'ASER'
+
+        for ep in range(self.epoch):
+            for i, batch_data in enumerate(train_loader):
+                # batch update
+                batch_x, batch_y = batch_data
+                batch_y_host = train_loader.last_y_host
+                for j in range(self.mem_iters):
+                    logits = self.model.forward(batch_x)
+                    loss = self.criterion(logits, batch_y)
+                    if self.verbose:
+                        # trackers only (the reference syncs with .item() every iteration; here only when printing)
+                        _, pred_label = torch.max(logits, 1)
+                        acc_batch.update((pred_label == batch_y).sum() / batch_y.size(0), batch_y.size(0))
+                        losses_batch.update(loss, batch_y.size(0))
+                    # backward
+                    self.opt.zero_grad()
+                    loss.backward()
+
+                    # mem update
+                    mem_x, mem_y = self.buffer.retrieve(x=batch_x, y=batch_y)
+                    if mem_x.size(0) > 0:
+                        mem_x = maybe_cuda(mem_x, self.cuda)
+                        mem_y = maybe_cuda(mem_y, self.cuda)
+                        mem_logits = self.model.forward(mem_x)
+                        loss_mem = self.criterion(mem_logits, mem_y)
+                        if self.verbose:
+                            losses_mem.update(loss_mem, mem_y.size(0))
+                            _, pred_label = torch.max(mem_logits, 1)
+                            acc_mem.update((pred_label == mem_y).sum() / mem_y.size(0), mem_y.size(0))
+
+                        loss_mem.backward()
+
+                    if aser:
+                        # opt update: passes #1/#2 only leave their BatchNorm running-stat updates behind
+                        self.opt.zero_grad()
+                        combined_batch = torch.cat((mem_x, batch_x))
+                        combined_labels = torch.cat((mem_y, batch_y))
+                        combined_logits = self.model.forward(combined_batch)
+                        loss_combined = self.criterion(combined_logits, combined_labels)
+                        loss_combined.backward()
+                        self.opt.step()
+                    else:
+                        self.opt.step()
+
+                # update mem
+                self.buffer.update(batch_x, batch_y, y_host=batch_y_host)
+
+                if i % 100 == 1 and self.verbose:
+                    print(
+                        '==>>> it: {}, avg. loss: {:.6f}, '
+                        'running train acc: {:.3f}'
+                            .format(i, losses_batch.avg(), acc_batch.avg())
+                    )
+                    print(
+                        '==>>> it: {}, mem avg. loss: {:.6f}, '
+                        'running mem acc: {:.3f}'
+                            .format(i, losses_mem.avg(), acc_mem.avg())
+                    )
+        self.after_train()

@@ -1,0 +1,108 @@
+"""agents/scr.py:11-69 — Supervised Contrastive Replay inner loop.
+
+Per iteration: retrieve -> concat -> augment -> two views through SupConResNet -> SupCon loss -> SGD ->
+reservoir update.  The two views run as one batched pass with per-view BatchNorm statistics (the reference
+calls model.forward twice, scr.py:55)."""
+import math
+
+import torch
+
+from .. import ops
+from ..buffer import Buffer
+from ..data import DeviceLoader
+from ..setup_elements import input_size_match
+from ..utils import maybe_cuda, AverageMeter
+from .base import ContinualLearner
+
+
+class ScrAugment(object):
+    """Stand-in for the kornia pipeline of scr.py:18-24: RandomResizedCrop(scale=(0.2,1)) -> RandomHorizontalFlip ->
+    ColorJitter(0.4,0.4,0.4,0.1,p=0.8) -> RandomGrayscale(p=0.2).  kornia 0.4.1's RNG parameterisation is
+    unpinned: parameters are drawn here on the torch CPU generator and applied by one HIP kernel."""
+
+    def __init__(self, size, scale=(0.2, 1.0), ratio=(3. / 4., 4. / 3.), jitter=(0.4, 0.4, 0.4, 0.1), p_jitter=0.8,
+                 p_gray=0.2):
+        self.h, self.w = size
+        self.scale, self.ratio, self.jitter = scale, ratio, jitter
+        self.p_jitter, self.p_gray = p_jitter, p_gray
+
+    def sample_params(self, n):
+        u = torch.rand(n, 12)
+        h, w = float(self.h), float(self.w)
+        area = (self.scale[0] + (self.scale[1] - self.scale[0]) * u[:, 0]) * h * w
+        logr = math.log(self.ratio[0]) + (math.log(self.ratio[1]) - math.log(self.ratio[0])) * u[:, 1]
+        r = torch.exp(logr)
+        cw = torch.sqrt(area * r).clamp(1.0, w)
+        ch = torch.sqrt(area / r).clamp(1.0, h)
+        y0 = u[:, 2] * (h - ch)
+        x0 = u[:, 3] * (w - cw)
+        b, c, s, hue = self.jitter
+        p = torch.empty(n, ops.AUG_NPARAM)
+        p[:, 0], p[:, 1], p[:, 2], p[:, 3] = y0, x0, ch, cw
+        p[:, 4] = (u[:, 4] < 0.5).float()
+        p[:, 5] = (u[:, 5] < self.p_jitter).float()
+        p[:, 6] = 1.0 - b + 2 * b * u[:, 6]
+        p[:, 7] = 1.0 - c + 2 * c * u[:, 7]
+        p[:, 8] = 1.0 - s + 2 * s * u[:, 8]
+        p[:, 9] = -hue + 2 * hue * u[:, 9]
+        p[:, 10] = torch.floor(u[:, 10] * 24).clamp(0, 23)
+        p[:, 11] = (u[:, 11] < self.p_gray).float()
+        return p
+
+    def __call__(self, x):
+        params = self.sample_params(x.shape[0]).to(x.device)
+        return ops.scr_augment(x, params)
+
+
+class SupContrastReplay(ContinualLearner):
+    def __init__(self, model, opt, params):
+        super(SupContrastReplay, self).__init__(model, opt, params)
+        self.buffer = Buffer(model, params)
+        self.mem_size = params.mem_size
+        self.eps_mem_batch = params.eps_mem_batch
+        self.mem_iters = params.mem_iters
+        self.transform = ScrAugment(size=(input_size_match[self.params.data][1], input_size_match[self.params.data][2]),
+                                    scale=(0.2, 1.))
+
+    def train_learner(self, x_train, y_train):
+        self.before_train(x_train, y_train)
+        # set up loader
+        train_loader = DeviceLoader(x_train, y_train, self.batch, shuffle=True, drop_last=True)
+        # set up model
+        self.model = self.model.train()
+
+        # setup tracker
+        losses = AverageMeter()
+        acc_batch = AverageMeter()
+
+        for ep in range(self.epoch):
+            for i, batch_data in enumerate(train_loader):
+                # batch update
+                batch_x, batch_y = batch_data
+                batch_y_host = train_loader.last_y_host
+
+                for j in range(self.mem_iters):
+                    mem_x, mem_y = self.buffer.retrieve(x=batch_x, y=batch_y)
+
+                    if mem_x.size(0) > 0:
+                        mem_x = maybe_cuda(mem_x, self.cuda)
+                        mem_y = maybe_cuda(mem_y, self.cuda)
+                        combined_batch = torch.cat((mem_x, batch_x))
+                        combined_labels = torch.cat((mem_y, batch_y))
+                        combined_batch_aug = self.transform(combined_batch)
+                        features = self.model.forward_views([combined_batch, combined_batch_aug])
+                        loss = self.criterion_views(features, combined_labels, 2)
+                        if self.verbose:
+                            losses.update(loss, batch_y.size(0))
+                        self.opt.zero_grad()
+                        loss.backward()
+                        self.opt.step()
+
+                # update mem
+                self.buffer.update(batch_x, batch_y, y_host=batch_y_host)
+                if i % 100 == 1 and self.verbose:
+                        print(
+                            '==>>> it: {}, avg. loss: {:.6f}, '
+                                .format(i, losses.avg(), acc_batch.avg())
+                        )
+        self.after_train()

@@ -1,0 +1,169 @@
+// Internal interface of the conv / batch-norm kernels (conv.hip) used by the network engine (net.hip).
+// Activations are NHWC fp32 with C in {4,20,40,80,160}; weights are re-packed per call from the
+// PyTorch OIHW master copy.  Everything is exact fp32 (v_mfma_f32_16x16x4_f32).
+#pragma once
+#include "common.h"
+
+namespace ocl {
+
+enum ConvEpi : int {
+    EPI_STORE = 0,       // out = acc
+    EPI_STATS = 1,       // + per-(group,channel) sum / sum-of-squares into `stats` (fp64 atomics)
+    EPI_AFFINE = 2,      // out = acc*scale[c] + shift[c]        (eval-mode BN folded)
+    EPI_RES = 4,         // out += res[same offset]
+    EPI_RESMASK = 8,     // out += res * (resmask > 0)           (ReLU-masked gradient of an identity shortcut)
+    EPI_RELU = 16,       // out = max(out, 0)
+    EPI_ACCUM = 32,      // out = out_old + value                (second gradient contribution)
+};
+
+struct ConvArgs {
+    const float* in;
+    const float* w;       // packed [tap][Cin][CoutP]
+    float* out;
+    const float* scale;
+    const float* shift;
+    const float* res;
+    const float* resmask;
+    double* stats;        // [groups][2][Cout]
+    int N, Hin, Win, Cin;
+    int Hout, Wout, Cout;
+    int CoutP;
+    int LH, LW, os, oy0, ox0;   // output lattice: (oy,ox) = (ly*os+oy0, lx*os+ox0)
+    int is;                     // input step per lattice step
+    int ntaps;
+    int tdy[9], tdx[9], tw[9];  // input offset of each tap and its index in the weight pack
+    int min_dy, min_dx, max_dy, max_dx;
+    int KC, CP, PC, PR;         // channels per LDS chunk, LDS pixel stride, patch cols, patch rows
+    int ppi, imgs, tiles_per_img;
+    int group_size, tiles_per_group;
+    int BNP;                    // LDS weight row stride (floats)
+    int flags;
+    int n_splits;               // grid.y
+};
+
+struct ConvPlan {
+    ConvArgs a;
+    int MT, NT;
+    int grid_x, grid_y;
+    size_t lds_bytes;
+};
+
+// geometry description used by the planner
+struct ConvGeomDesc {
+    int N, groups;
+    int Hin, Win, Cin;          // input tensor
+    int Hout, Wout, Cout;       // output tensor (storage dims)
+    int LH, LW, os, oy0, ox0, is;
+    int ntaps;
+    int tdy[9], tdx[9], tw[9];
+};
+
+int plan_conv(const ConvGeomDesc& g, ConvPlan* p);
+int launch_conv(const ConvPlan& p, hipStream_t s);
+
+// ---- wgrad -------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float* x;     // conv input  [N,Hin,Win,Cin]
+    const float* dy;    // grad wrt conv output [N,Ho,Wo,Cout]
+    float* partial;     // [S][Mrows][CoutP]   Mrows = nchunks*ntaps*KC rounded up per block
+    int N, Hin, Win, Cin, Ho, Wo, Cout, CoutP;
+    int stride, ntaps;
+    int tdy[9], tdx[9];
+    int min_dy, min_dx, max_dy, max_dx;
+    int KC, nchunks;            // channel chunking of Cin
+    int CP, PC, PR, DP;         // LDS strides
+    int KP;                     // pixels per tile (multiple of 4)
+    int ppi, imgs, tiles_per_img, total_tiles;
+    int S;                      // pixel splits (grid.x)
+    int mblocks_per_chunk;      // blocks along (tap,cc) per chunk
+    int nblocks;                // blocks along Cout
+    int Mchunk;                 // ntaps*KC
+    int Mrows_total;            // nchunks * mblocks_per_chunk * (64*MTW)
+};
+struct WgradPlan {
+    WgradArgs a;
+    int MTW, NTW;
+    int grid_x, grid_y;
+    size_t lds_bytes;
+    size_t partial_floats;
+};
+int plan_wgrad(int N, int Hin, int Win, int Cin, int Ho, int Wo, int Cout, int ksize, int stride, WgradPlan* p);
+int launch_wgrad(const WgradPlan& p, hipStream_t s);
+// sums the S partials and writes/accumulates the OIHW gradient
+int launch_wgrad_reduce(const WgradPlan& p, float* grad_oihw, int accumulate, hipStream_t s);
+
+// ---- weight packing -----------------------------------------------------------------------------------
+// fwd pack:   wf[t][ci][coP] = w[co][ci][t]          (ci padded with zero rows up to CinP)
+// dgrad pack: wd[t][co][ciP] = w[co][ci][t]
+struct PackDesc {
+    int64_t w_off;      // offset of the OIHW tensor in the flat parameter array
+    int64_t f_off;      // offset in the pack arena (fwd), -1 = none
+    int64_t d_off;      // offset in the pack arena (dgrad), -1 = none
+    int Cout, Cin, ntaps, CinP, CoutP, CiP;
+};
+int launch_pack_weights(const float* params, float* arena, const PackDesc* descs_dev, int n_layers, int max_elems,
+                        hipStream_t s);
+
+// ---- layout / elementwise ------------------------------------------------------------------------------
+int launch_nchw3_to_nhwc4(const float* x, float* out, int N, int H, int W, hipStream_t s);
+
+struct BnFwdArgs {
+    const float* y;       // raw conv output [M,C]
+    float* z;             // output
+    const float* res;     // optional residual (already normalised), same shape
+    const double* stats;  // [G][2][C]
+    const float* gamma;
+    const float* beta;
+    float* running_mean;  // may be null (no update)
+    float* running_var;
+    int64_t* nbt;         // num_batches_tracked, may be null
+    float* save_mean;     // [G][C]
+    float* save_invstd;   // [G][C]
+    int64_t m_per_group;  // pixels per group
+    int G, C, relu;
+    float momentum, eps;
+};
+int launch_bn_fwd(const BnFwdArgs& a, hipStream_t s);
+
+// eval-mode fold: scale = gamma/sqrt(rv+eps), shift = beta - rm*scale for every BN at once
+struct BnFoldDesc {
+    int64_t gamma_off, beta_off, stat_off, out_off;
+    int C;
+};
+int launch_bn_fold(const float* params, const float* running, float* out, const BnFoldDesc* descs_dev, int n_bn, float eps,
+                   hipStream_t s);
+
+struct BnBwdArgs {
+    const float* dz;      // grad wrt block output (post-ReLU)   [M,C]
+    const float* z;       // post-ReLU output (mask); null = no ReLU mask
+    int64_t m_per_group;
+    int G, C;
+    int nsets;            // 1 or 2 BatchNorms sharing dz (main path + projection shortcut)
+    const float* y[2];
+    const float* mean[2];
+    const float* invstd[2];
+    const float* gamma[2];
+    float* dy[2];         // grad wrt raw conv output
+    float* dgamma[2];
+    float* dbeta[2];
+    double* sums;         // scratch [nsets][G][2][C], zeroed by the caller
+    int accumulate;       // dgamma/dbeta += (1) or = (0)
+};
+int launch_bn_bwd(const BnBwdArgs& a, hipStream_t s);
+
+// avg_pool2d(k=4) + flatten in PyTorch's (C,ph,pw) order; and its backward
+int launch_avgpool_fwd(const float* z, float* feat, int N, int H, int W, int C, hipStream_t s);
+int launch_avgpool_bwd(const float* dfeat, float* dz, int N, int H, int W, int C, hipStream_t s);
+
+// F.normalize(dim=1) forward/backward
+int launch_l2norm_fwd(const float* v, float* out, float* norms, int n, int d, hipStream_t s);
+int launch_l2norm_bwd(const float* out, const float* norms, const float* dout, float* dv, int n, int d, hipStream_t s);
+// dx = dy * (a > 0)
+int launch_relu_bwd(const float* dy, const float* a, float* dx, int64_t n, hipStream_t s);
+// out[c] (+)= sum_r m[r][c]
+int launch_colsum(const float* m, int rows, int cols, float* out, int accumulate, hipStream_t s);
+int launch_fill(float* p, int64_t n, float v, hipStream_t s);
+
+int conv_kernels_init();
+
+}  // namespace ocl

@@ -1,0 +1,875 @@
+// Reduced-ResNet18 / SupConResNet engine: owns the layer table, the workspace layout and the kernel sequences of
+// forward (train / eval) and backward.  Mirrors models/resnet.py:69-116 (ResNet(BasicBlock,[2,2,2,2],nf=20)) and
+// :140-168 (SupConResNet) of the reference; parameters stay in PyTorch's named_parameters() order and OIHW layout.
+#include "conv.h"
+#include <string.h>
+#include <string>
+#include <vector>
+#include <map>
+#include <algorithm>
+
+using namespace ocl;
+
+namespace {
+
+const int kGmax = 8;  // BN groups per forward (SCR uses 2)
+
+struct TensorInfo {
+    std::string name;
+    int64_t off;
+    int ndim;
+    int64_t shape[4];
+    int64_t numel;
+};
+struct BnInfo {
+    std::string name;
+    int C;
+    int gamma_t, beta_t;  // tensor indices
+    int64_t stat_off;     // into the running flat array: mean[C], var[C]
+    int64_t arena_off;    // into per-BN arenas of size kGmax*2*C (doubles) / 2*C floats for the fold
+    int64_t save_off;     // into the slot's saved mean/invstd area (floats): mean[kGmax*C], invstd[kGmax*C]
+};
+struct ConvInfo {
+    int Cin, CinT, Cout, k, stride, Hin, Win, Ho, Wo;  // CinT: channels of the NHWC input tensor (stem: 4)
+    int w_t;          // weight tensor index
+    int bn;           // following BatchNorm
+    int64_t f_off, d_off;  // pack arena offsets (floats)
+    int CoutP, CiP;
+    int64_t y_off;    // raw output inside a slot (floats)
+};
+struct BlockInfo {
+    int conv1, conv2, convs;  // convs = -1: identity shortcut
+    int64_t a1_off, z_off;    // post-ReLU activations inside a slot
+};
+
+struct PlanSet {
+    std::vector<ConvPlan> fwd;                  // per conv
+    std::vector<std::vector<ConvPlan>> dgrad;   // per conv: 0 (stem), 1 or 4 launches
+    std::vector<WgradPlan> wgrad;
+};
+
+}  // namespace
+
+struct ocl_net {
+    ocl_net_desc d;
+    std::vector<TensorInfo> tensors;
+    std::vector<BnInfo> bns;
+    std::vector<ConvInfo> convs;
+    std::vector<BlockInfo> blocks;
+    int64_t n_params = 0, n_stats = 0;
+    int feat_dim = 0, out_dim = 0, Hf = 0, Wf = 0;
+    int t_linear_w = -1, t_linear_b = -1, t_h0_w = -1, t_h0_b = -1, t_h2_w = -1, t_h2_b = -1;
+
+    // workspace layout (bytes)
+    int64_t ws_bytes = 0;
+    int64_t slot_bytes = 0, slot_base = 0;
+    int64_t x4_off = 0, zstem_off = 0, save_off_base = 0, feat_off = 0, h1_off = 0, h2_off = 0, norms_off = 0, out_off = 0;  // floats in slot
+    int64_t slot_floats = 0;
+    int64_t gbuf_floats = 0;
+    int64_t off_g[5] = {0, 0, 0, 0, 0};
+    int64_t off_partial = 0, partial_floats = 0;
+    int64_t off_stats = 0, stats_doubles = 0;
+    int64_t off_bsums = 0, bsums_doubles = 0;
+    int64_t off_pack = 0, pack_floats = 0;
+    int64_t off_fold = 0, fold_floats = 0;
+    int64_t off_descs = 0;
+    int64_t off_head = 0, head_floats = 0;  // dh2, dh1, dfeat, eval feat scratch
+    int64_t max_act_floats = 0;
+
+    // bound storage
+    float* params = nullptr;
+    float* grads = nullptr;
+    float* running = nullptr;
+    int64_t* nbt = nullptr;
+    unsigned char* ws = nullptr;
+    bool bound = false;
+    bool descs_uploaded = false;
+
+    std::vector<int> slot_n, slot_groups;
+    std::vector<bool> slot_valid;
+    std::map<std::pair<int, int>, PlanSet> plans;
+
+    float* slotf(int slot) const { return (float*)(ws + slot_base + (int64_t)slot * slot_bytes); }
+    float* gbuf(int i) const { return (float*)(ws + off_g[i]); }
+};
+
+// -----------------------------------------------------------------------------------------------------
+static int add_tensor(ocl_net* n, const std::string& name, std::initializer_list<int64_t> shape) {
+    TensorInfo t;
+    t.name = name;
+    t.off = n->n_params;
+    t.ndim = (int)shape.size();
+    t.numel = 1;
+    int i = 0;
+    for (auto s : shape) {
+        t.shape[i++] = s;
+        t.numel *= s;
+    }
+    for (; i < 4; ++i) t.shape[i] = 1;
+    n->n_params += t.numel;
+    n->tensors.push_back(t);
+    return (int)n->tensors.size() - 1;
+}
+static int add_bn(ocl_net* n, const std::string& prefix, int C) {
+    BnInfo b;
+    b.name = prefix;
+    b.C = C;
+    b.gamma_t = add_tensor(n, prefix + ".weight", {C});
+    b.beta_t = add_tensor(n, prefix + ".bias", {C});
+    b.stat_off = n->n_stats;
+    n->n_stats += 2 * C;
+    n->bns.push_back(b);
+    return (int)n->bns.size() - 1;
+}
+static int add_conv(ocl_net* n, const std::string& name, int Cin, int Cout, int k, int stride, int Hin, int Win) {
+    ConvInfo c;
+    memset(&c, 0, sizeof(c));
+    c.Cin = Cin;
+    c.CinT = Cin == 3 ? 4 : Cin;
+    c.Cout = Cout;
+    c.k = k;
+    c.stride = stride;
+    c.Hin = Hin;
+    c.Win = Win;
+    const int pad = k == 3 ? 1 : 0;
+    c.Ho = (Hin + 2 * pad - k) / stride + 1;
+    c.Wo = (Win + 2 * pad - k) / stride + 1;
+    c.w_t = add_tensor(n, name + ".weight", {Cout, Cin, k, k});
+    c.bn = -1;
+    n->convs.push_back(c);
+    return (int)n->convs.size() - 1;
+}
+
+static int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+static int build_layout(ocl_net* n) {
+    const ocl_net_desc& d = n->d;
+    const std::string pre = d.head == 0 ? "" : "encoder.";
+    int H = d.in_h, W = d.in_w;
+    // stem
+    int c = add_conv(n, pre + "conv1", 3, d.nf, 3, 1, H, W);
+    n->convs[c].bn = add_bn(n, pre + "bn1", d.nf);
+    int in_planes = d.nf;
+    for (int layer = 0; layer < 4; ++layer) {
+        const int planes = d.nf << layer;
+        for (int b = 0; b < 2; ++b) {
+            const int stride = (b == 0 && layer > 0) ? 2 : 1;
+            const std::string bp = pre + "layer" + std::to_string(layer + 1) + "." + std::to_string(b);
+            BlockInfo bi;
+            memset(&bi, 0, sizeof(bi));
+            bi.conv1 = add_conv(n, bp + ".conv1", in_planes, planes, 3, stride, H, W);
+            n->convs[bi.conv1].bn = add_bn(n, bp + ".bn1", planes);
+            const int Ho = n->convs[bi.conv1].Ho, Wo = n->convs[bi.conv1].Wo;
+            bi.conv2 = add_conv(n, bp + ".conv2", planes, planes, 3, 1, Ho, Wo);
+            n->convs[bi.conv2].bn = add_bn(n, bp + ".bn2", planes);
+            bi.convs = -1;
+            if (stride != 1 || in_planes != planes) {
+                bi.convs = add_conv(n, bp + ".shortcut.0", in_planes, planes, 1, stride, H, W);
+                // nn.Sequential(conv, bn): parameter names shortcut.0.weight, shortcut.1.weight, shortcut.1.bias
+                n->convs[bi.convs].bn = add_bn(n, bp + ".shortcut.1", planes);
+            }
+            n->blocks.push_back(bi);
+            in_planes = planes;
+            H = Ho;
+            W = Wo;
+        }
+    }
+    n->Hf = H;
+    n->Wf = W;
+    const int PH = H / 4, PW = W / 4;
+    OCL_REQUIRE(PH >= 1 && PW >= 1, "net: input %dx%d too small for avg_pool2d(4)", d.in_h, d.in_w);
+    n->feat_dim = in_planes * PH * PW;
+    // SupConResNet always builds encoder = Reduced_ResNet18(100): its (unused) linear is [100, nf*8] even for 84x84
+    // inputs (models/resnet.py:144); the plain ResNet's linear is replaced to match the feature size
+    // (utils/setup_elements.py:63-66).
+    const int lin_in = d.head == 0 ? n->feat_dim : in_planes;
+    n->t_linear_w = add_tensor(n, pre + "linear.weight", {d.n_classes, lin_in});
+    n->t_linear_b = add_tensor(n, pre + "linear.bias", {d.n_classes});
+    if (d.head == 0) {
+        n->out_dim = d.n_classes;
+    } else if (d.head == 1) {
+        n->t_h0_w = add_tensor(n, "head.0.weight", {n->feat_dim, n->feat_dim});
+        n->t_h0_b = add_tensor(n, "head.0.bias", {n->feat_dim});
+        n->t_h2_w = add_tensor(n, "head.2.weight", {d.feat_dim, n->feat_dim});
+        n->t_h2_b = add_tensor(n, "head.2.bias", {d.feat_dim});
+        n->out_dim = d.feat_dim;
+    } else if (d.head == 2) {
+        n->t_h2_w = add_tensor(n, "head.weight", {d.feat_dim, n->feat_dim});
+        n->t_h2_b = add_tensor(n, "head.bias", {d.feat_dim});
+        n->out_dim = d.feat_dim;
+    } else {
+        n->out_dim = n->feat_dim;
+    }
+
+    // ---- pack arena -------------------------------------------------------------------------------
+    int64_t pk = 0;
+    for (auto& cv : n->convs) {
+        const int nt = cdiv(cv.Cout, 16);
+        int NT = nt <= 5 ? nt : 5;
+        const int sp = cdiv(nt, NT);
+        if (sp > 1) NT = cdiv(nt, sp);
+        cv.CoutP = sp * NT * 16;
+        cv.f_off = pk;
+        pk += (int64_t)cv.k * cv.k * cv.CinT * cv.CoutP;
+        if (cv.Cin != 3) {
+            const int nti = cdiv(cv.Cin, 16);
+            int NTi = nti <= 5 ? nti : 5;
+            const int spi = cdiv(nti, NTi);
+            if (spi > 1) NTi = cdiv(nti, spi);
+            cv.CiP = spi * NTi * 16;
+            cv.d_off = pk;
+            pk += (int64_t)cv.k * cv.k * cv.Cout * cv.CiP;
+        } else {
+            cv.CiP = 0;
+            cv.d_off = -1;
+        }
+        pk = align_up(pk, 64);
+    }
+    n->pack_floats = pk;
+
+    // ---- slot layout (floats) -------------------------------------------------------------------------
+    const int64_t N = d.max_batch;
+    int64_t o = 0;
+    auto take = [&](int64_t nfl) {
+        const int64_t r = o;
+        o = align_up(o + nfl, 64);
+        return r;
+    };
+    n->x4_off = take(N * d.in_h * d.in_w * 4);
+    int64_t max_act = N * d.in_h * d.in_w * 4;
+    for (auto& cv : n->convs) {
+        const int64_t sz = N * cv.Ho * cv.Wo * cv.Cout;
+        cv.y_off = take(sz);
+        max_act = std::max(max_act, sz);
+    }
+    n->zstem_off = take(N * n->convs[0].Ho * n->convs[0].Wo * n->convs[0].Cout);
+    for (auto& b : n->blocks) {
+        const ConvInfo& c1 = n->convs[b.conv1];
+        const int64_t sz = N * c1.Ho * c1.Wo * c1.Cout;
+        b.a1_off = take(sz);
+        b.z_off = take(sz);
+    }
+    n->save_off_base = o;
+    for (auto& b : n->bns) {
+        b.save_off = take((int64_t)2 * kGmax * b.C);
+    }
+    n->feat_off = take(N * n->feat_dim);
+    n->h1_off = take(N * n->feat_dim);
+    n->h2_off = take(N * std::max(n->out_dim, 1));
+    n->norms_off = take(N);
+    n->out_off = take(N * n->out_dim);
+    n->slot_floats = o;
+    n->max_act_floats = max_act;
+
+    // ---- global workspace (bytes) ---------------------------------------------------------------------
+    int64_t w = 0;
+    auto takeb = [&](int64_t bytes) {
+        const int64_t r = w;
+        w = align_up(w + bytes, 256);
+        return r;
+    };
+    n->gbuf_floats = max_act;
+    for (int i = 0; i < 5; ++i) n->off_g[i] = takeb(max_act * 4);
+    // wgrad partial: worst case over layers for the largest batch
+    int64_t pmax = 0;
+    for (auto& cv : n->convs) {
+        WgradPlan wp;
+        int rc = plan_wgrad((int)N, cv.Hin, cv.Win, cv.CinT, cv.Ho, cv.Wo, cv.Cout, cv.k, cv.stride, &wp);
+        if (rc != OCL_OK) return rc;
+        pmax = std::max<int64_t>(pmax, (int64_t)wp.partial_floats);
+    }
+    n->partial_floats = pmax + 1024;
+    n->off_partial = takeb(n->partial_floats * 4);
+    int64_t so = 0;
+    for (auto& b : n->bns) {
+        b.arena_off = so;
+        so += (int64_t)kGmax * 2 * b.C;
+    }
+    n->stats_doubles = so;
+    n->off_stats = takeb(so * 8);
+    n->bsums_doubles = so;  // backward: [G][2][C] per BN as well
+    n->off_bsums = takeb(so * 8);
+    n->off_pack = takeb(n->pack_floats * 4);
+    n->fold_floats = n->n_stats;  // scale[C], shift[C] per BN, same layout as running stats
+    n->off_fold = takeb(n->fold_floats * 4);
+    n->off_descs = takeb((int64_t)(n->convs.size() * sizeof(PackDesc) + n->bns.size() * sizeof(BnFoldDesc) + 256));
+    n->head_floats = N * ((int64_t)n->feat_dim * 3 + n->out_dim * 2 + 64);
+    n->off_head = takeb(n->head_floats * 4);
+    n->slot_base = w;
+    n->slot_bytes = align_up(n->slot_floats * 4, 256);
+    w += n->slot_bytes * d.n_slots;
+    n->ws_bytes = w;
+    n->slot_n.assign(d.n_slots, 0);
+    n->slot_groups.assign(d.n_slots, 1);
+    n->slot_valid.assign(d.n_slots, false);
+    return OCL_OK;
+}
+
+// -----------------------------------------------------------------------------------------------------
+// geometry builders
+// -----------------------------------------------------------------------------------------------------
+static void geom_fwd(const ConvInfo& c, int N, int groups, ConvGeomDesc* g) {
+    memset(g, 0, sizeof(*g));
+    g->N = N; g->groups = groups;
+    g->Hin = c.Hin; g->Win = c.Win; g->Cin = c.CinT;
+    g->Hout = c.Ho; g->Wout = c.Wo; g->Cout = c.Cout;
+    g->LH = c.Ho; g->LW = c.Wo; g->os = 1; g->oy0 = 0; g->ox0 = 0; g->is = c.stride;
+    const int pad = c.k == 3 ? 1 : 0;
+    g->ntaps = c.k * c.k;
+    for (int t = 0; t < g->ntaps; ++t) {
+        g->tdy[t] = t / c.k - pad;
+        g->tdx[t] = t % c.k - pad;
+        g->tw[t] = t;
+    }
+}
+// data gradient: "input" = dy [N,Ho,Wo,Cout], "output" = dx [N,Hin,Win,Cin]
+static int geom_dgrad(const ConvInfo& c, int N, std::vector<ConvGeomDesc>* out) {
+    out->clear();
+    ConvGeomDesc g;
+    memset(&g, 0, sizeof(g));
+    g.N = N; g.groups = 1;
+    g.Hin = c.Ho; g.Win = c.Wo; g.Cin = c.Cout;
+    g.Hout = c.Hin; g.Wout = c.Win; g.Cout = c.Cin;
+    g.is = 1;
+    if (c.stride == 1) {
+        g.LH = c.Hin; g.LW = c.Win; g.os = 1;
+        const int pad = c.k == 3 ? 1 : 0;
+        g.ntaps = c.k * c.k;
+        for (int t = 0; t < g.ntaps; ++t) {
+            g.tdy[t] = pad - t / c.k;
+            g.tdx[t] = pad - t % c.k;
+            g.tw[t] = t;
+        }
+        out->push_back(g);
+    } else if (c.k == 1) {  // 1x1 stride 2, pad 0: only even pixels receive gradient
+        g.os = 2; g.oy0 = 0; g.ox0 = 0;
+        g.LH = (c.Hin + 1) / 2; g.LW = (c.Win + 1) / 2;
+        g.ntaps = 1;
+        g.tdy[0] = 0; g.tdx[0] = 0; g.tw[0] = 0;
+        out->push_back(g);
+    } else {  // 3x3 stride 2 pad 1: four dense parity classes of the dx lattice
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px) {
+                ConvGeomDesc q = g;
+                q.os = 2; q.oy0 = py; q.ox0 = px;
+                q.LH = (c.Hin - py + 1) / 2; q.LW = (c.Win - px + 1) / 2;
+                if (q.LH <= 0 || q.LW <= 0) continue;
+                int nt = 0;
+                for (int ky = 0; ky < 3; ++ky) {
+                    if (((py + 1 - ky) & 1) != 0) continue;
+                    for (int kx = 0; kx < 3; ++kx) {
+                        if (((px + 1 - kx) & 1) != 0) continue;
+                        q.tdy[nt] = (py + 1 - ky) / 2;  // exact: even numerator
+                        q.tdx[nt] = (px + 1 - kx) / 2;
+                        q.tw[nt] = ky * 3 + kx;
+                        ++nt;
+                    }
+                }
+                q.ntaps = nt;
+                out->push_back(q);
+            }
+    }
+    return OCL_OK;
+}
+
+static int get_plans(ocl_net* n, int N, int groups, PlanSet** out) {
+    auto key = std::make_pair(N, groups);
+    auto it = n->plans.find(key);
+    if (it != n->plans.end()) {
+        *out = &it->second;
+        return OCL_OK;
+    }
+    PlanSet ps;
+    ps.fwd.resize(n->convs.size());
+    ps.dgrad.resize(n->convs.size());
+    ps.wgrad.resize(n->convs.size());
+    for (size_t i = 0; i < n->convs.size(); ++i) {
+        const ConvInfo& c = n->convs[i];
+        ConvGeomDesc g;
+        geom_fwd(c, N, groups, &g);
+        int rc = plan_conv(g, &ps.fwd[i]);
+        if (rc != OCL_OK) return rc;
+        if (c.Cin != 3) {
+            std::vector<ConvGeomDesc> dg;
+            geom_dgrad(c, N, &dg);
+            for (auto& q : dg) {
+                ConvPlan p;
+                rc = plan_conv(q, &p);
+                if (rc != OCL_OK) return rc;
+                ps.dgrad[i].push_back(p);
+            }
+        }
+        rc = plan_wgrad(N, c.Hin, c.Win, c.CinT, c.Ho, c.Wo, c.Cout, c.k, c.stride, &ps.wgrad[i]);
+        if (rc != OCL_OK) return rc;
+        if ((int64_t)ps.wgrad[i].partial_floats > n->partial_floats) {
+            set_error("net: wgrad partial workspace too small (%zu > %lld floats)", ps.wgrad[i].partial_floats,
+                      (long long)n->partial_floats);
+            return OCL_ERR_STATE;
+        }
+    }
+    auto res = n->plans.emplace(key, std::move(ps));
+    *out = &res.first->second;
+    return OCL_OK;
+}
+
+// -----------------------------------------------------------------------------------------------------
+static int upload_descs(ocl_net* n, hipStream_t s) {
+    std::vector<PackDesc> pd(n->convs.size());
+    for (size_t i = 0; i < n->convs.size(); ++i) {
+        const ConvInfo& c = n->convs[i];
+        pd[i].w_off = n->tensors[c.w_t].off;
+        pd[i].f_off = c.f_off;
+        pd[i].d_off = c.d_off;
+        pd[i].Cout = c.Cout;
+        pd[i].Cin = c.Cin;
+        pd[i].ntaps = c.k * c.k;
+        pd[i].CinP = c.CinT;
+        pd[i].CoutP = c.CoutP;
+        pd[i].CiP = c.CiP;
+    }
+    std::vector<BnFoldDesc> fd(n->bns.size());
+    for (size_t i = 0; i < n->bns.size(); ++i) {
+        fd[i].gamma_off = n->tensors[n->bns[i].gamma_t].off;
+        fd[i].beta_off = n->tensors[n->bns[i].beta_t].off;
+        fd[i].stat_off = n->bns[i].stat_off;
+        fd[i].out_off = n->bns[i].stat_off;
+        fd[i].C = n->bns[i].C;
+    }
+    unsigned char* dst = n->ws + n->off_descs;
+    OCL_HIP(hipMemcpyAsync(dst, pd.data(), pd.size() * sizeof(PackDesc), hipMemcpyHostToDevice, s));
+    OCL_HIP(hipMemcpyAsync(dst + align_up((int64_t)(pd.size() * sizeof(PackDesc)), 64), fd.data(), fd.size() * sizeof(BnFoldDesc),
+                           hipMemcpyHostToDevice, s));
+    OCL_HIP(hipMemsetAsync(n->ws + n->off_pack, 0, n->pack_floats * 4, s));
+    OCL_HIP(hipStreamSynchronize(s));  // host vectors go out of scope
+    n->descs_uploaded = true;
+    return OCL_OK;
+}
+static const PackDesc* pack_descs(const ocl_net* n) { return (const PackDesc*)(n->ws + n->off_descs); }
+static const BnFoldDesc* fold_descs(const ocl_net* n) {
+    return (const BnFoldDesc*)(n->ws + n->off_descs + align_up((int64_t)(n->convs.size() * sizeof(PackDesc)), 64));
+}
+
+static int run_conv(ocl_net* n, ConvPlan p, const float* in, const float* w, float* out, int flags, double* stats,
+                    const float* scale, const float* shift, const float* res, const float* resmask, hipStream_t s) {
+    p.a.in = in;
+    p.a.w = w;
+    p.a.out = out;
+    p.a.flags = flags;
+    p.a.stats = stats;
+    p.a.scale = scale;
+    p.a.shift = shift;
+    p.a.res = res;
+    p.a.resmask = resmask;
+    return launch_conv(p, s);
+}
+
+static int head_forward(ocl_net* n, const float* P, float* feat, float* h1, float* h2, float* norms, float* out, int N,
+                        hipStream_t s) {
+    const int FD = n->feat_dim;
+    auto T = [&](int t) { return P + n->tensors[t].off; };
+    int rc = OCL_OK;
+    switch (n->d.head) {
+        case 0:
+            rc = ocl_gemm_small(feat, FD, 1, T(n->t_linear_w), 1, FD, out, n->out_dim, N, n->out_dim, FD, T(n->t_linear_b), 0, 0, s);
+            break;
+        case 1:
+            rc = ocl_gemm_small(feat, FD, 1, T(n->t_h0_w), 1, FD, h1, FD, N, FD, FD, T(n->t_h0_b), 1, 0, s);
+            if (rc) return rc;
+            rc = ocl_gemm_small(h1, FD, 1, T(n->t_h2_w), 1, FD, h2, n->out_dim, N, n->out_dim, FD, T(n->t_h2_b), 0, 0, s);
+            if (rc) return rc;
+            rc = launch_l2norm_fwd(h2, out, norms, N, n->out_dim, s);
+            break;
+        case 2:
+            rc = ocl_gemm_small(feat, FD, 1, T(n->t_h2_w), 1, FD, h2, n->out_dim, N, n->out_dim, FD, T(n->t_h2_b), 0, 0, s);
+            if (rc) return rc;
+            rc = launch_l2norm_fwd(h2, out, norms, N, n->out_dim, s);
+            break;
+        default:
+            rc = launch_l2norm_fwd(feat, out, norms, N, FD, s);
+            break;
+    }
+    return rc;
+}
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+extern "C" {
+
+int ocl_net_create(const ocl_net_desc* desc, ocl_net** out) {
+    OCL_REQUIRE(desc && out, "net_create: null pointer");
+    OCL_REQUIRE(desc->in_h >= 32 && desc->in_w >= 32 && desc->nf > 0 && desc->nf % 4 == 0, "net_create: bad input size / nf");
+    OCL_REQUIRE(desc->head >= 0 && desc->head <= 3, "net_create: head=%d", desc->head);
+    OCL_REQUIRE(desc->n_classes > 0 && desc->max_batch > 0 && desc->n_slots >= 1, "net_create: n_classes/max_batch/n_slots");
+    OCL_REQUIRE(desc->head == 0 || desc->head == 3 || desc->feat_dim > 0, "net_create: feat_dim");
+    ocl_net* n = new ocl_net();
+    n->d = *desc;
+    int rc = build_layout(n);
+    if (rc != OCL_OK) {
+        delete n;
+        return rc;
+    }
+    *out = n;
+    return OCL_OK;
+}
+
+void ocl_net_destroy(ocl_net* net) { delete net; }
+
+int64_t ocl_net_param_count(const ocl_net* net) { return net ? net->n_params : -1; }
+int32_t ocl_net_num_tensors(const ocl_net* net) { return net ? (int32_t)net->tensors.size() : -1; }
+int ocl_net_tensor_info(const ocl_net* net, int i, char* name64, int64_t* offset, int32_t* ndim, int64_t* shape4) {
+    OCL_REQUIRE(net && i >= 0 && i < (int)net->tensors.size(), "tensor_info: index %d", i);
+    const TensorInfo& t = net->tensors[i];
+    if (name64) {
+        strncpy(name64, t.name.c_str(), 63);
+        name64[63] = 0;
+    }
+    if (offset) *offset = t.off;
+    if (ndim) *ndim = t.ndim;
+    if (shape4)
+        for (int k = 0; k < 4; ++k) shape4[k] = t.shape[k];
+    return OCL_OK;
+}
+int32_t ocl_net_num_bn(const ocl_net* net) { return net ? (int32_t)net->bns.size() : -1; }
+int64_t ocl_net_bn_stat_count(const ocl_net* net) { return net ? net->n_stats : -1; }
+int ocl_net_bn_info(const ocl_net* net, int i, char* name64, int64_t* offset, int32_t* channels) {
+    OCL_REQUIRE(net && i >= 0 && i < (int)net->bns.size(), "bn_info: index %d", i);
+    if (name64) {
+        strncpy(name64, net->bns[i].name.c_str(), 63);
+        name64[63] = 0;
+    }
+    if (offset) *offset = net->bns[i].stat_off;
+    if (channels) *channels = net->bns[i].C;
+    return OCL_OK;
+}
+int32_t ocl_net_feature_dim(const ocl_net* net) { return net ? net->feat_dim : -1; }
+int32_t ocl_net_out_dim(const ocl_net* net) { return net ? net->out_dim : -1; }
+int64_t ocl_net_workspace_bytes(const ocl_net* net) { return net ? net->ws_bytes : -1; }
+
+int ocl_net_bind(ocl_net* net, float* params, float* grads, float* running, int64_t* nbt, void* workspace, int64_t workspace_bytes) {
+    OCL_REQUIRE(net && params && grads && running && nbt && workspace, "net_bind: null pointer");
+    OCL_REQUIRE(workspace_bytes >= net->ws_bytes, "net_bind: workspace %lld < %lld bytes", (long long)workspace_bytes,
+                (long long)net->ws_bytes);
+    OCL_REQUIRE(((uintptr_t)workspace % 256) == 0 && ((uintptr_t)params % 16) == 0 && ((uintptr_t)grads % 16) == 0,
+                "net_bind: alignment (workspace 256 B, params/grads 16 B)");
+    int rc = conv_kernels_init();
+    if (rc != OCL_OK) return rc;
+    net->params = params;
+    net->grads = grads;
+    net->running = running;
+    net->nbt = nbt;
+    net->ws = (unsigned char*)workspace;
+    net->bound = true;
+    net->descs_uploaded = false;
+    for (size_t i = 0; i < net->slot_valid.size(); ++i) net->slot_valid[i] = false;
+    return OCL_OK;
+}
+
+int ocl_net_forward(ocl_net* n, const float* x, int N, int groups, uint32_t flags, const float* params_override, float* feat_out,
+                    float* out, int slot, void* stream) {
+    OCL_REQUIRE(n && n->bound, "net_forward: net not bound");
+    OCL_REQUIRE(x && N > 0 && N <= n->d.max_batch, "net_forward: n=%d (max_batch %d)", N, n->d.max_batch);
+    OCL_REQUIRE(groups >= 1 && groups <= kGmax && N % groups == 0, "net_forward: groups=%d must divide n=%d (<= %d)", groups, N, kGmax);
+    OCL_REQUIRE(slot >= 0 && slot < n->d.n_slots, "net_forward: slot %d", slot);
+    hipStream_t s = (hipStream_t)stream;
+    const bool train = (flags & OCL_FWD_TRAIN) != 0;
+    OCL_REQUIRE(train || groups == 1, "net_forward: groups only apply to train-mode BatchNorm");
+    if (!n->descs_uploaded) {
+        int rc = upload_descs(n, s);
+        if (rc != OCL_OK) return rc;
+    }
+    const float* P = params_override ? params_override : n->params;
+    PlanSet* ps = nullptr;
+    int rc = get_plans(n, N, train ? groups : 1, &ps);
+    if (rc != OCL_OK) return rc;
+    float* pack = (float*)(n->ws + n->off_pack);
+    int max_elems = 0;
+    for (auto& c : n->convs) max_elems = std::max(max_elems, c.Cout * c.Cin * c.k * c.k);
+    rc = launch_pack_weights(P, pack, pack_descs(n), (int)n->convs.size(), max_elems, s);
+    if (rc != OCL_OK) return rc;
+
+    float* S = n->slotf(slot);
+    float* x4 = S + n->x4_off;
+    rc = launch_nchw3_to_nhwc4(x, x4, N, n->d.in_h, n->d.in_w, s);
+    if (rc != OCL_OK) return rc;
+    n->slot_valid[slot] = false;
+
+    float* feat = S + n->feat_off;
+    if (train) {
+        double* stats = (double*)(n->ws + n->off_stats);
+        OCL_HIP(hipMemsetAsync(stats, 0, n->stats_doubles * 8, s));
+        const bool upd = (flags & OCL_FWD_UPDATE_RUNNING) != 0;
+        auto bn_fwd = [&](int conv_i, const float* y, float* z, const float* res, int relu) -> int {
+            const ConvInfo& c = n->convs[conv_i];
+            const BnInfo& b = n->bns[c.bn];
+            BnFwdArgs a;
+            memset(&a, 0, sizeof(a));
+            a.y = y; a.z = z; a.res = res;
+            a.stats = stats + b.arena_off;
+            a.gamma = P + n->tensors[b.gamma_t].off;
+            a.beta = P + n->tensors[b.beta_t].off;
+            a.running_mean = upd ? n->running + b.stat_off : nullptr;
+            a.running_var = upd ? n->running + b.stat_off + b.C : nullptr;
+            a.nbt = upd ? n->nbt + c.bn : nullptr;
+            a.save_mean = S + b.save_off;
+            a.save_invstd = S + b.save_off + (int64_t)kGmax * b.C;
+            a.m_per_group = (int64_t)(N / groups) * c.Ho * c.Wo;
+            a.G = groups; a.C = b.C; a.relu = relu;
+            a.momentum = 0.1f; a.eps = 1e-5f;
+            return launch_bn_fwd(a, s);
+        };
+        auto conv_stats = [&](int conv_i, const float* in) -> int {
+            const ConvInfo& c = n->convs[conv_i];
+            return run_conv(n, ps->fwd[conv_i], in, pack + c.f_off, S + c.y_off, EPI_STATS, stats + n->bns[c.bn].arena_off, nullptr,
+                            nullptr, nullptr, nullptr, s);
+        };
+        // stem
+        if ((rc = conv_stats(0, x4))) return rc;
+        float* cur = S + n->zstem_off;
+        if ((rc = bn_fwd(0, S + n->convs[0].y_off, cur, nullptr, 1))) return rc;
+        for (auto& b : n->blocks) {
+            float* a1 = S + b.a1_off;
+            float* z = S + b.z_off;
+            if ((rc = conv_stats(b.conv1, cur))) return rc;
+            if ((rc = bn_fwd(b.conv1, S + n->convs[b.conv1].y_off, a1, nullptr, 1))) return rc;
+            if ((rc = conv_stats(b.conv2, a1))) return rc;
+            const float* res = cur;
+            if (b.convs >= 0) {
+                if ((rc = conv_stats(b.convs, cur))) return rc;
+                float* sc = n->gbuf(0);
+                if ((rc = bn_fwd(b.convs, S + n->convs[b.convs].y_off, sc, nullptr, 0))) return rc;
+                res = sc;
+            }
+            if ((rc = bn_fwd(b.conv2, S + n->convs[b.conv2].y_off, z, res, 1))) return rc;
+            cur = z;
+        }
+        if ((rc = launch_avgpool_fwd(cur, feat, N, n->Hf, n->Wf, n->convs[n->blocks.back().conv2].Cout, s))) return rc;
+    } else {
+        float* fold = (float*)(n->ws + n->off_fold);
+        if ((rc = launch_bn_fold(P, n->running, fold, fold_descs(n), (int)n->bns.size(), 1e-5f, s))) return rc;
+        auto conv_eval = [&](int conv_i, const float* in, float* o, const float* res, int relu) -> int {
+            const ConvInfo& c = n->convs[conv_i];
+            const BnInfo& b = n->bns[c.bn];
+            int fl = EPI_AFFINE | (res ? EPI_RES : 0) | (relu ? EPI_RELU : 0);
+            return run_conv(n, ps->fwd[conv_i], in, pack + c.f_off, o, fl, nullptr, fold + b.stat_off, fold + b.stat_off + b.C, res,
+                            nullptr, s);
+        };
+        float* bufs[4] = {n->gbuf(0), n->gbuf(1), n->gbuf(2), n->gbuf(3)};
+        float* cur = bufs[0];
+        if ((rc = conv_eval(0, x4, cur, nullptr, 1))) return rc;
+        int ci = 0;
+        for (auto& b : n->blocks) {
+            float* a1 = bufs[(ci + 1) & 3];
+            float* sc = bufs[(ci + 2) & 3];
+            float* z = bufs[(ci + 3) & 3];
+            if ((rc = conv_eval(b.conv1, cur, a1, nullptr, 1))) return rc;
+            const float* res = cur;
+            if (b.convs >= 0) {
+                if ((rc = conv_eval(b.convs, cur, sc, nullptr, 0))) return rc;
+                res = sc;
+            }
+            if ((rc = conv_eval(b.conv2, a1, z, res, 1))) return rc;
+            cur = z;
+            ci = (ci + 3) & 3;
+        }
+        if ((rc = launch_avgpool_fwd(cur, feat, N, n->Hf, n->Wf, n->convs[n->blocks.back().conv2].Cout, s))) return rc;
+    }
+    if (feat_out) OCL_HIP(hipMemcpyAsync(feat_out, feat, (size_t)N * n->feat_dim * 4, hipMemcpyDeviceToDevice, s));
+    if (out || (flags & OCL_FWD_SAVE_TAPE)) {
+        float* o = S + n->out_off;
+        if ((rc = head_forward(n, P, feat, S + n->h1_off, S + n->h2_off, S + n->norms_off, o, N, s))) return rc;
+        if (out) OCL_HIP(hipMemcpyAsync(out, o, (size_t)N * n->out_dim * 4, hipMemcpyDeviceToDevice, s));
+    }
+    if (train && (flags & OCL_FWD_SAVE_TAPE) && !params_override) {
+        n->slot_valid[slot] = true;
+        n->slot_n[slot] = N;
+        n->slot_groups[slot] = groups;
+    }
+    return OCL_OK;
+}
+
+int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, void* stream) {
+    OCL_REQUIRE(n && n->bound, "net_backward: net not bound");
+    OCL_REQUIRE(slot >= 0 && slot < n->d.n_slots && n->slot_valid[slot],
+                "net_backward: slot %d holds no train-mode forward tape (forward with OCL_FWD_TRAIN|OCL_FWD_SAVE_TAPE first)", slot);
+    OCL_REQUIRE(dout, "net_backward: null dout");
+    hipStream_t s = (hipStream_t)stream;
+    const int N = n->slot_n[slot], G = n->slot_groups[slot];
+    PlanSet* ps = nullptr;
+    int rc = get_plans(n, N, G, &ps);
+    if (rc != OCL_OK) return rc;
+    n->slot_valid[slot] = false;  // a tape is consumed once (activation buffers are not preserved past this point)
+    float* S = n->slotf(slot);
+    const float* P = n->params;
+    float* Gr = n->grads;
+    float* pack = (float*)(n->ws + n->off_pack);
+    float* partial = (float*)(n->ws + n->off_partial);
+    double* bsums = (double*)(n->ws + n->off_bsums);
+    OCL_HIP(hipMemsetAsync(bsums, 0, n->bsums_doubles * 8, s));
+    {   // the pack arena may have been rewritten by another forward (eval scoring, MIR's virtual model) since
+        int max_elems = 0;
+        for (auto& c : n->convs) max_elems = std::max(max_elems, c.Cout * c.Cin * c.k * c.k);
+        if ((rc = launch_pack_weights(P, pack, pack_descs(n), (int)n->convs.size(), max_elems, s))) return rc;
+    }
+    auto T = [&](int t) { return P + n->tensors[t].off; };
+    auto GT = [&](int t) { return Gr + n->tensors[t].off; };
+    const int FD = n->feat_dim, OD = n->out_dim;
+    float* hb = (float*)(n->ws + n->off_head);
+    float* dfeat = hb;
+    float* dh1 = hb + (int64_t)N * FD;
+    float* dh2 = dh1 + (int64_t)N * FD;
+    float* feat = S + n->feat_off;
+    float* h1 = S + n->h1_off;
+    float* o = S + n->out_off;
+    float* norms = S + n->norms_off;
+
+    // ---- head -------------------------------------------------------------------------------------
+    auto lin_bwd = [&](const float* dy, int ncol, const float* xin, int kin, int tw, int tb, float* dx) -> int {
+        // y = x W^T + b, W [ncol, kin]
+        int r = ocl_gemm_small(dy, 1, ncol, xin, kin, 1, GT(tw), kin, ncol, kin, N, nullptr, 0, accumulate, s);  // dW = dy^T x
+        if (r) return r;
+        if ((r = launch_colsum(dy, N, ncol, GT(tb), accumulate, s))) return r;
+        if (dx) r = ocl_gemm_small(dy, ncol, 1, T(tw), kin, 1, dx, kin, N, kin, ncol, nullptr, 0, 0, s);  // dx = dy W
+        return r;
+    };
+    if (n->d.head == 0) {
+        if ((rc = lin_bwd(dout, OD, feat, FD, n->t_linear_w, n->t_linear_b, dfeat))) return rc;
+    } else {
+        if (!accumulate) {  // encoder.linear takes no part in SupConResNet.forward: its gradient is zero
+            if ((rc = launch_fill(GT(n->t_linear_w), n->tensors[n->t_linear_w].numel, 0.f, s))) return rc;
+            if ((rc = launch_fill(GT(n->t_linear_b), n->tensors[n->t_linear_b].numel, 0.f, s))) return rc;
+        }
+        if (n->d.head == 1) {
+            if ((rc = launch_l2norm_bwd(o, norms, dout, dh2, N, OD, s))) return rc;
+            if ((rc = lin_bwd(dh2, OD, h1, FD, n->t_h2_w, n->t_h2_b, dh1))) return rc;
+            if ((rc = launch_relu_bwd(dh1, h1, dh1, (int64_t)N * FD, s))) return rc;
+            if ((rc = lin_bwd(dh1, FD, feat, FD, n->t_h0_w, n->t_h0_b, dfeat))) return rc;
+        } else if (n->d.head == 2) {
+            if ((rc = launch_l2norm_bwd(o, norms, dout, dh2, N, OD, s))) return rc;
+            if ((rc = lin_bwd(dh2, OD, feat, FD, n->t_h2_w, n->t_h2_b, dfeat))) return rc;
+        } else {
+            if ((rc = launch_l2norm_bwd(o, norms, dout, dfeat, N, FD, s))) return rc;
+        }
+    }
+    // ---- trunk ------------------------------------------------------------------------------------
+    float* gA = n->gbuf(0);  // grad wrt current block output
+    float* gB = n->gbuf(1);
+    float* gC = n->gbuf(2);
+    float* gD = n->gbuf(3);
+    float* gE = n->gbuf(4);
+    const int Clast = n->convs[n->blocks.back().conv2].Cout;
+    if ((rc = launch_avgpool_bwd(dfeat, gA, N, n->Hf, n->Wf, Clast, s))) return rc;
+
+    auto bn_bwd = [&](const float* dz, const float* zmask, int conv_a, float* dya, int conv_b, float* dyb) -> int {
+        BnBwdArgs a;
+        memset(&a, 0, sizeof(a));
+        const ConvInfo& ca = n->convs[conv_a];
+        a.dz = dz; a.z = zmask;
+        a.m_per_group = (int64_t)(N / G) * ca.Ho * ca.Wo;
+        a.G = G; a.C = ca.Cout;
+        a.nsets = conv_b >= 0 ? 2 : 1;
+        const int cs[2] = {conv_a, conv_b};
+        float* dys[2] = {dya, dyb};
+        for (int k = 0; k < a.nsets; ++k) {
+            const ConvInfo& c = n->convs[cs[k]];
+            const BnInfo& b = n->bns[c.bn];
+            a.y[k] = S + c.y_off;
+            a.mean[k] = S + b.save_off;
+            a.invstd[k] = S + b.save_off + (int64_t)kGmax * b.C;
+            a.gamma[k] = T(b.gamma_t);
+            a.dy[k] = dys[k];
+            a.dgamma[k] = GT(b.gamma_t);
+            a.dbeta[k] = GT(b.beta_t);
+        }
+        // both sets live in conv_a's BN arena region followed by conv_b's: use separate regions per BN
+        a.sums = bsums + n->bns[ca.bn].arena_off;
+        if (conv_b >= 0) {
+            // the kernel addresses sums as [set][G][2][C]; both BNs have the same C and their arenas are
+            // kGmax*2*C doubles each, so set 1 would alias set 0's tail when G < kGmax.  Use a private layout:
+            // set k at offset k*G*2*C inside conv_a's region is only valid if 2*G <= kGmax.
+            if (2 * G > kGmax) {
+                set_error("bn_bwd: groups=%d too large for a shared reduction arena", G);
+                return OCL_ERR_ARG;
+            }
+        }
+        a.accumulate = accumulate;
+        return launch_bn_bwd(a, s);
+    };
+    auto wgrad = [&](int conv_i, const float* xin, const float* dy) -> int {
+        WgradPlan wp = ps->wgrad[conv_i];
+        wp.a.x = xin;
+        wp.a.dy = dy;
+        wp.a.partial = partial;
+        int r = launch_wgrad(wp, s);
+        if (r) return r;
+        return launch_wgrad_reduce(wp, GT(n->convs[conv_i].w_t), accumulate, s);
+    };
+    auto dgrad = [&](int conv_i, const float* dy, float* dx, const float* res, const float* resmask, int extra_flags) -> int {
+        const ConvInfo& c = n->convs[conv_i];
+        for (auto& p : ps->dgrad[conv_i]) {
+            int fl = extra_flags | (res ? (resmask ? EPI_RESMASK : EPI_RES) : 0);
+            int r = run_conv(n, p, dy, pack + c.d_off, dx, fl, nullptr, nullptr, nullptr, res, resmask, s);
+            if (r) return r;
+        }
+        return OCL_OK;
+    };
+
+    for (int bi = (int)n->blocks.size() - 1; bi >= 0; --bi) {
+        const BlockInfo& b = n->blocks[bi];
+        const float* xin = bi == 0 ? S + n->zstem_off : S + n->blocks[bi - 1].z_off;
+        const float* a1 = S + b.a1_off;
+        const float* z = S + b.z_off;
+        // gA = dL/dz.  bn2 (and the projection BN) share the ReLU-masked gradient.
+        if ((rc = bn_bwd(gA, z, b.conv2, gB, b.convs, gC))) return rc;
+        if (b.convs >= 0)
+            if ((rc = wgrad(b.convs, xin, gC))) return rc;
+        if ((rc = wgrad(b.conv2, a1, gB))) return rc;
+        if ((rc = dgrad(b.conv2, gB, gD, nullptr, nullptr, 0))) return rc;   // gD = dL/da1 (pre-mask)
+        if ((rc = bn_bwd(gD, a1, b.conv1, gB, -1, nullptr))) return rc;      // gB = dL/dy1
+        if ((rc = wgrad(b.conv1, xin, gB))) return rc;
+        if (b.convs >= 0) {
+            if ((rc = dgrad(b.conv1, gB, gE, nullptr, nullptr, 0))) return rc;
+            if ((rc = dgrad(b.convs, gC, gE, nullptr, nullptr, EPI_ACCUM))) return rc;
+        } else {
+            if ((rc = dgrad(b.conv1, gB, gE, gA, z, 0))) return rc;         // + identity shortcut: dz * (z>0)
+        }
+        std::swap(gA, gE);
+    }
+    // stem
+    if ((rc = bn_bwd(gA, S + n->zstem_off, 0, gB, -1, nullptr))) return rc;
+    if ((rc = wgrad(0, S + n->x4_off, gB))) return rc;
+    return OCL_OK;
+}
+
+int ocl_net_debug_copy(ocl_net* n, int slot, int what, int index, float* dst, int64_t max_floats, int64_t* n_written, void* stream) {
+    OCL_REQUIRE(n && n->bound && slot >= 0 && slot < n->d.n_slots && dst, "debug_copy: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    const int N = n->slot_n[slot] > 0 ? n->slot_n[slot] : n->d.max_batch;
+    const float* src = nullptr;
+    int64_t cnt = 0;
+    float* S = n->slotf(slot);
+    if (what == 0) {  // raw conv output
+        OCL_REQUIRE(index >= 0 && index < (int)n->convs.size(), "debug_copy: conv index");
+        const ConvInfo& c = n->convs[index];
+        src = S + c.y_off;
+        cnt = (int64_t)N * c.Ho * c.Wo * c.Cout;
+    } else if (what == 1) {  // block output
+        OCL_REQUIRE(index >= 0 && index < (int)n->blocks.size(), "debug_copy: block index");
+        const ConvInfo& c = n->convs[n->blocks[index].conv1];
+        src = S + n->blocks[index].z_off;
+        cnt = (int64_t)N * c.Ho * c.Wo * c.Cout;
+    } else if (what == 2) {  // gradient scratch buffer
+        OCL_REQUIRE(index >= 0 && index < 5, "debug_copy: gbuf index");
+        src = n->gbuf(index);
+        cnt = n->gbuf_floats;
+    } else {
+        set_error("debug_copy: what=%d", what);
+        return OCL_ERR_ARG;
+    }
+    cnt = std::min(cnt, max_floats);
+    OCL_HIP(hipMemcpyAsync(dst, src, (size_t)cnt * 4, hipMemcpyDeviceToDevice, s));
+    if (n_written) *n_written = cnt;
+    return OCL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,123 @@
+"""ctypes binding of libocl_hip.so (include/ocl_hip.h).
+
+This is the only place the product path touches native code; there is NO fallback: if the library is
+missing, or a call fails, a RuntimeError is raised (the reference's error convention is exceptions).
+PyTorch is used for device memory and streams only: every call takes raw `tensor.data_ptr()`s and
+torch's current HIP stream.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libocl_hip.so")
+_lib = None
+
+i64 = C.c_int64
+i32 = C.c_int32
+f32 = C.c_float
+vp = C.c_void_p
+
+
+class NetDesc(C.Structure):
+    _fields_ = [("in_h", i32), ("in_w", i32), ("nf", i32), ("n_classes", i32), ("head", i32),
+                ("feat_dim", i32), ("max_batch", i32), ("n_slots", i32)]
+
+
+# name -> (restype, argtypes); kept in one table so tests can check it against the header
+SIGNATURES = {
+    "ocl_version": (C.c_int, []),
+    "ocl_last_error": (C.c_char_p, []),
+    "ocl_init": (C.c_int, [C.c_int]),
+    "ocl_gather_rows": (C.c_int, [vp, vp, i64, i64, vp, vp]),
+    "ocl_scatter_rows": (C.c_int, [vp, vp, i64, i64, vp, vp]),
+    "ocl_gather_u8_hwc_to_f32_chw": (C.c_int, [vp, vp, i64, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "ocl_sgd_step": (C.c_int, [vp, vp, i64, f32, f32, f32, vp, vp]),
+    "ocl_ce_fwd_bwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+    "ocl_supcon_workspace_bytes": (i64, [C.c_int]),
+    "ocl_supcon_fwd_bwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, f32, vp, vp, vp, vp]),
+    "ocl_knn_sv": (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
+    "ocl_col_reduce": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "ocl_aser_score": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "ocl_argsort_desc": (C.c_int, [vp, C.c_int, vp, vp]),
+    "ocl_ncm_class_means": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp]),
+    "ocl_ncm_predict": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, vp, vp]),
+    "ocl_mir_scores": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, vp]),
+    "ocl_scr_augment": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
+    "ocl_gemm_small": (C.c_int, [vp, i64, i64, vp, i64, i64, vp, i64, C.c_int, C.c_int, C.c_int, vp,
+                                 C.c_int, C.c_int, vp]),
+    "ocl_net_create": (C.c_int, [C.POINTER(NetDesc), C.POINTER(vp)]),
+    "ocl_net_destroy": (None, [vp]),
+    "ocl_net_param_count": (i64, [vp]),
+    "ocl_net_num_tensors": (i32, [vp]),
+    "ocl_net_tensor_info": (C.c_int, [vp, C.c_int, C.c_char_p, C.POINTER(i64), C.POINTER(i32),
+                                      C.POINTER(i64)]),
+    "ocl_net_num_bn": (i32, [vp]),
+    "ocl_net_bn_stat_count": (i64, [vp]),
+    "ocl_net_bn_info": (C.c_int, [vp, C.c_int, C.c_char_p, C.POINTER(i64), C.POINTER(i32)]),
+    "ocl_net_feature_dim": (i32, [vp]),
+    "ocl_net_out_dim": (i32, [vp]),
+    "ocl_net_workspace_bytes": (i64, [vp]),
+    "ocl_net_bind": (C.c_int, [vp, vp, vp, vp, vp, vp, i64]),
+    "ocl_net_forward": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_uint32, vp, vp, vp, C.c_int, vp]),
+    "ocl_net_backward": (C.c_int, [vp, C.c_int, vp, C.c_int, vp]),
+    "ocl_net_debug_copy": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, i64, C.POINTER(i64), vp]),
+    "ocl_prof_enable": (C.c_int, [C.c_int]),
+    "ocl_prof_reset": (C.c_int, []),
+    "ocl_prof_query": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(i64)]),
+}
+
+FWD_TRAIN, FWD_SAVE_TAPE, FWD_UPDATE_RUNNING = 1, 2, 4
+
+
+def lib():
+    """Loads the shared library (once). Raises if it has not been built: no CPU fallback exists."""
+    global _lib
+    if _lib is None:
+        if not os.path.isfile(LIB_PATH):
+            raise RuntimeError(
+                "libocl_hip.so not found at %s — build it with `python -c 'import __graft_entry__ as g; "
+                "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().ocl_last_error()
+        raise RuntimeError("libocl_hip %s failed (%d): %s" % (what, rc, msg.decode() if msg else "?"))
+
+
+_inited = set()
+
+
+def init(device_index=None):
+    """ocl_init on the current (or given) device: verifies gfx950."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("online-continual-learning_amd needs an MI355X (gfx950) visible to PyTorch-ROCm; "
+                           "no GPU is visible and there is no CPU fallback.")
+    if device_index is None:
+        device_index = torch.cuda.current_device()
+    if device_index not in _inited:
+        check(lib().ocl_init(int(device_index)), "ocl_init")
+        _inited.add(device_index)
+    return device_index
+
+
+def stream():
+    return vp(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Raw device pointer of a contiguous tensor (None -> NULL)."""
+    if t is None:
+        return vp(0)
+    if not t.is_contiguous():
+        raise RuntimeError("ffi.ptr: tensor must be contiguous")
+    return vp(t.data_ptr())

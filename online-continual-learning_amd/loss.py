@@ -1,0 +1,69 @@
+"""Loss functions of the hot path as autograd nodes over the HIP kernels (K6, K7)."""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class _CEFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels):
+        loss, dl = ops.cross_entropy(logits, labels, "mean", want_grad=True)
+        ctx.save_for_backward(dl)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g, None
+
+
+def cross_entropy_mean(logits, labels):
+    """torch.nn.CrossEntropyLoss(reduction='mean') (agents/base.py:95,113)."""
+    return _CEFunction.apply(logits, labels)
+
+
+class _SupConFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feat_vm, labels, n_views, temperature):
+        loss, df = ops.supcon(feat_vm, labels, n_views, temperature, want_grad=True)
+        ctx.save_for_backward(df)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (df,) = ctx.saved_tensors
+        return df * g, None, None, None
+
+
+class SupConLoss(nn.Module):
+    """utils/loss.py:12-96 (contrast_mode='all'; labels required — the SimCLR / explicit-mask branches are not on
+    the replay path).  `features` is [bsz, n_views, ...] like the reference; `forward_view_major` takes the
+    engine's native [n_views*bsz, dim] layout and avoids the permute."""
+
+    def __init__(self, temperature=0.07, contrast_mode='all'):
+        super().__init__()
+        if contrast_mode != 'all':
+            raise ValueError('Unknown mode: {}'.format(contrast_mode))
+        self.temperature = temperature
+        self.contrast_mode = contrast_mode
+
+    def forward(self, features, labels=None, mask=None):
+        if len(features.shape) < 3:
+            raise ValueError('`features` needs to be [bsz, n_views, ...],'
+                             'at least 3 dimensions are required')
+        if len(features.shape) > 3:
+            features = features.view(features.shape[0], features.shape[1], -1)
+        if labels is not None and mask is not None:
+            raise ValueError('Cannot define both `labels` and `mask`')
+        if labels is None:
+            raise NotImplementedError("only the supervised (labels=) branch is implemented")
+        labels = labels.contiguous().view(-1)
+        if labels.shape[0] != features.shape[0]:
+            raise ValueError('Num of labels does not match num of features')
+        n_views = features.shape[1]
+        vm = torch.cat(torch.unbind(features, dim=1), dim=0)  # loss.py:56
+        return _SupConFunction.apply(vm, labels, n_views, self.temperature)
+
+    def forward_view_major(self, feat_vm, labels, n_views):
+        return _SupConFunction.apply(feat_vm, labels.contiguous().view(-1), n_views, self.temperature)

@@ -1,0 +1,49 @@
+"""utils/buffer/aser_utils.py: compute_knn_sv (:7-61), deep_features (:64-91), add_minority_class_input (:119-157).
+Distance matrix, per-row sort, indicator recursion and scatter are ONE HIP kernel (ocl_knn_sv); the deep features
+come from the engine's eval-mode forward."""
+import torch
+
+from .. import ops
+from ..utils import maybe_cuda, mini_batch_deep_features, nonzero_indices
+from .buffer_utils import ClassBalancedRandomSampling, _host_labels
+
+
+def deep_features(model, eval_x, n_eval, cand_x, n_cand):
+    """aser_utils.py:64-91."""
+    if cand_x is None:
+        num = n_eval
+        total_x = eval_x
+    else:
+        num = n_eval + n_cand
+        total_x = torch.cat((eval_x, cand_x), 0)
+    total_x = maybe_cuda(total_x)
+    deep_features_ = mini_batch_deep_features(model, total_x, num)
+    eval_df = deep_features_[0:n_eval]
+    cand_df = deep_features_[n_eval:]
+    return eval_df, cand_df
+
+
+def compute_knn_sv(model, eval_x, eval_y, cand_x, cand_y, k, device="cpu"):
+    """aser_utils.py:7-61: KNN Shapley value matrix [n_eval, n_cand] of candidates w.r.t. evaluation data."""
+    n_eval = eval_x.size(0)
+    n_cand = cand_x.size(0)
+    eval_df, cand_df = deep_features(model, eval_x, n_eval, cand_x, n_cand)
+    return ops.knn_sv(eval_df.contiguous(), eval_y, cand_df.contiguous(), cand_y, k)
+
+
+def add_minority_class_input(cur_x, cur_y, mem_size, num_class, cur_y_host=None):
+    """aser_utils.py:119-157.  Threshold ~ U(0, 1/num_class) on the torch CPU generator; class counts come from
+    ClassBalancedRandomSampling.class_num_cache (host)."""
+    # Select input instances from minority classes that will be concatenated to pre-selected data
+    threshold = torch.tensor(1).float().uniform_(0, 1 / num_class).item()
+
+    # If number of buffered samples from certain class is lower than random threshold,
+    #   that class is minority class
+    cls_proportion = ClassBalancedRandomSampling.class_num_cache.float() / mem_size
+    cur_y_cpu = torch.from_numpy(_host_labels(cur_y, cur_y_host))
+    minority_ind = nonzero_indices(cls_proportion[cur_y_cpu] < threshold)
+
+    ind_dev = minority_ind.to(cur_x.device)
+    minority_batch_x = ops.gather_rows(cur_x.contiguous(), ind_dev)
+    minority_batch_y = ops.gather_rows(cur_y.contiguous(), ind_dev)
+    return minority_batch_x, minority_batch_y
