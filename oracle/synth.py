@@ -1,0 +1,91 @@
+"""TEST INFRASTRUCTURE ONLY — seeded synthetic class-incremental streams (no datasets on disk, no
+network) and the small teacher-forced step cases shared by oracle/make_golden.py (reference side) and the tests
+(oracle side on CPU, HIP side on the MI355X)."""
+import random
+
+import numpy as np
+import torch
+
+SHAPES = {"cifar10": (32, 32), "cifar100": (32, 32), "mini_imagenet": (84, 84)}
+
+# Small cases: a handful of iterations per task so that a free-running comparison stays inside fp32 round-off.
+STEP_CASES = {
+    # ER random/random (BASELINE config 1 shape)
+    "er_c10": dict(agent="ER", retrieve="random", update="random", data="cifar10", mem_size=50, eps_mem_batch=10, seed=0,
+                   tasks=[[0, 1], [2, 3]], n_train=30, n_test=20),
+    # SCR random/random (config 2 shape), identity augmentation on both sides (kornia unpinned)
+    "scr_c100": dict(agent="SCR", retrieve="random", update="random", data="cifar100", mem_size=100, eps_mem_batch=20, seed=1,
+                     tasks=[[3, 17], [40, 41]], n_train=25, n_test=20, temp=0.07, head="mlp"),
+    # ER --retrieve ASER --update ASER (config 3 shape).  SV totals tie EXACTLY all the time (adjacent same-indicator
+    # candidates share a value, aser_utils.py:39-52) and torch's CPU argsort is unstable, so a free-running reference
+    # trajectory is only defined up to tie order: golden=False -> make_golden.py proves oracle(torch argsort) ==
+    # reference bit-for-bit, and the GPU tests compare single teacher-forced steps tie-aware.
+    "aser_c100": dict(agent="ER", retrieve="ASER", update="ASER", data="cifar100", mem_size=80, eps_mem_batch=10, seed=2,
+                      tasks=[list(range(20))], n_train=8, n_test=4, k=3, n_smp_cls=1.5, aser_type="asvm", golden=False),
+    # ER --retrieve MIR (config 4 shape, 84x84)
+    "mir_mini": dict(agent="ER", retrieve="MIR", update="random", data="mini_imagenet", mem_size=40, eps_mem_batch=5, seed=3,
+                     tasks=[[5, 6]], n_train=20, n_test=10, subsample=20),
+    # ER --retrieve MIR at 32x32, two tasks (seed chosen tie-free: saturated logits give exactly-zero scores otherwise)
+    "mir_c10": dict(agent="ER", retrieve="MIR", update="random", data="cifar10", mem_size=40, eps_mem_batch=10, seed=4,
+                    tasks=[[0, 1, 2, 3, 4], [5, 6, 7, 8, 9]], n_train=10, n_test=8, subsample=20),
+}
+
+
+def case_params(cfg):
+    keys = ("agent", "retrieve", "update", "data", "mem_size", "eps_mem_batch", "seed", "temp", "head", "k", "n_smp_cls", "aser_type",
+            "subsample")
+    p = {k: cfg[k] for k in keys if k in cfg}
+    p["num_tasks"] = len(cfg["tasks"])
+    return p
+
+
+def seed_all(seed):
+    """general_main.py:12-14."""
+    np.random.seed(seed)
+    random.seed(seed)
+    torch.manual_seed(seed)
+
+
+def class_images(cls, n, hw, rng, blend=0.5):
+    """Class-conditional uint8 images: per-class prototype blended with uniform noise."""
+    h, w = hw
+    proto = np.random.default_rng(1234 + int(cls)).integers(0, 256, (h, w, 3)).astype(np.float32)
+    noise = rng.integers(0, 256, (n, h, w, 3)).astype(np.float32)
+    return np.clip(blend * proto[None] + (1 - blend) * noise, 0, 255).astype(np.uint8)
+
+
+def make_stream(cfg):
+    """Returns (tasks, tests): lists of (x uint8 [N,H,W,3], y int64 [N]) per task, classes interleaved."""
+    hw = SHAPES[cfg["data"]]
+    rng = np.random.default_rng(9000 + cfg["seed"])
+    tasks, tests = [], []
+    for classes in cfg["tasks"]:
+        for store, n in ((tasks, cfg["n_train"]), (tests, cfg["n_test"])):
+            xs = np.concatenate([class_images(c, n, hw, rng) for c in classes], 0)
+            ys = np.concatenate([np.full(n, c, dtype=np.int64) for c in classes], 0)
+            store.append((xs, ys))
+    return tasks, tests
+
+
+def digest_state(state_dict):
+    """[n_tensors, 3] float64: (sum, L2 norm, first element) of every floating tensor in state_dict order."""
+    rows = []
+    for k, v in state_dict.items():
+        if torch.is_tensor(v) and v.is_floating_point():
+            d = v.detach().double().cpu().reshape(-1)
+            rows.append([float(d.sum()), float(d.norm()), float(d[0])])
+    return np.array(rows, dtype=np.float64)
+
+
+def throughput_stream(data, n_classes_per_task, n_tasks, n_per_class, seed):
+    """Uniform-noise uint8 stream for pure-throughput runs."""
+    hw = SHAPES[data]
+    rng = np.random.default_rng(seed)
+    out = []
+    for t in range(n_tasks):
+        classes = list(range(t * n_classes_per_task, (t + 1) * n_classes_per_task))
+        n = n_per_class * len(classes)
+        x = rng.integers(0, 256, (n,) + hw + (3,), dtype=np.uint8)
+        y = np.repeat(np.array(classes, dtype=np.int64), n_per_class)
+        out.append((x, y))
+    return out

@@ -1,0 +1,148 @@
+"""CPU: host-side logic of the product package — the C-ABI library loads and exports every symbol the header
+declares (no compute calls), the engine's parameter layout equals the reference's named_parameters() layout, the
+registries carry the reference's keys, the data path reproduces the DataLoader's RNG draws, and the product fails
+loudly without a GPU (no CPU fallback, no oracle import)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import ocl_amd
+from ocl_amd import ffi
+from conftest import ROOT
+from oracle import ocl_oracle as O
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "ocl_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ocl_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_header_symbol():
+    L = ffi.lib()
+    syms = _header_symbols()
+    assert len(syms) >= 35
+    for s in syms:
+        assert hasattr(L, s), "libocl_hip.so does not export %s" % s
+        assert s in ffi.SIGNATURES, "ffi.py has no signature for %s" % s
+    assert set(ffi.SIGNATURES) == set(syms)
+    assert L.ocl_version() >= 100
+
+
+def _layout(desc):
+    L = ffi.lib()
+    h = ffi.vp(0)
+    ffi.check(L.ocl_net_create(C.byref(desc), C.byref(h)), "create")
+    nb, off, nd, sh = C.create_string_buffer(64), ffi.i64(0), ffi.i32(0), (ffi.i64 * 4)()
+    out = []
+    for i in range(L.ocl_net_num_tensors(h)):
+        ffi.check(L.ocl_net_tensor_info(h, i, nb, C.byref(off), C.byref(nd), sh))
+        out.append((nb.value.decode(), off.value, tuple(sh[k] for k in range(nd.value))))
+    info = dict(n=L.ocl_net_param_count(h), fd=L.ocl_net_feature_dim(h), od=L.ocl_net_out_dim(h), nbn=L.ocl_net_num_bn(h))
+    L.ocl_net_destroy(h)
+    return out, info
+
+
+@pytest.mark.parametrize("agent,data,desc,n_params,fd,od", [
+    ("ER", "cifar100", (32, 32, 20, 100, 0, 0, 64, 2), 1109240, 160, 100),
+    ("ER", "cifar10", (32, 32, 20, 10, 0, 0, 64, 2), 1094750, 160, 10),
+    ("ER", "mini_imagenet", (84, 84, 20, 100, 0, 0, 16, 1), 1157240, 640, 100),
+    ("SCR", "cifar100", (32, 32, 20, 100, 1, 128, 64, 2), 1155608, 160, 128),
+])
+def test_engine_layout_equals_reference_named_parameters(agent, data, desc, n_params, fd, od):
+    lay, info = _layout(ffi.NetDesc(*desc))
+    st = O.init_state(agent, data, "mlp")
+    ref = [(k, tuple(v.shape)) for k, v in st.items() if v.requires_grad]
+    assert [(n, s) for n, _, s in lay] == ref
+    off = 0
+    for (n, o, s) in lay:
+        assert o == off
+        off += int(np.prod(s))
+    assert info == dict(n=n_params, fd=fd, od=od, nbn=20)     # SURVEY §2 K8 parameter counts
+
+
+def test_module_containers_match_reference_state_dict_and_seeded_init():
+    from ocl_amd.setup_elements import setup_architecture
+    from types import SimpleNamespace
+    for agent, data in [("ER", "cifar100"), ("SCR", "cifar100"), ("ER", "mini_imagenet")]:
+        torch.manual_seed(3)
+        m = setup_architecture(SimpleNamespace(agent=agent, data=data, head="mlp"))
+        torch.manual_seed(3)
+        st = O.init_state(agent, data, "mlp")
+        sd = m.state_dict()
+        assert list(sd.keys()) == list(st.keys())
+        for k in sd:
+            assert torch.equal(sd[k], st[k].detach()), k   # same construction order => same RNG draws => same weights
+
+
+def test_registries_have_reference_keys():
+    from ocl_amd import name_match
+    assert set(name_match.agents.keys()) == {"ER", "SCR"}
+    assert set(name_match.retrieve_methods.keys()) == {"MIR", "random", "ASER"}
+    assert set(name_match.update_methods.keys()) == {"random", "ASER"}
+    assert name_match.agents["SCR"].__name__ == "SupContrastReplay"
+    assert name_match.retrieve_methods["ASER"].__name__ == "ASER_retrieve"
+    with pytest.raises(KeyError):
+        name_match.agents["nope"]
+
+
+def test_index_loader_reproduces_dataloader_rng_and_order():
+    """DeviceLoader iterates a torch DataLoader over bare indices: the epoch order and the torch-RNG state afterwards
+    must equal those of the reference's DataLoader(dataset_transform(...), shuffle=True, drop_last=True)."""
+    from ocl_amd.data import _IndexDataset
+    from torch.utils import data
+    n, bs = 53, 10
+    ys = torch.arange(n)
+    torch.manual_seed(5)
+    ref = [b[1] for b in data.DataLoader(data.TensorDataset(torch.zeros(n, 2), ys), batch_size=bs, shuffle=True, drop_last=True)]
+    after_ref = torch.rand(1)
+    torch.manual_seed(5)
+    mine = [b for b in iter(data.DataLoader(_IndexDataset(n), batch_size=bs, shuffle=True, num_workers=0, drop_last=True))]
+    after_mine = torch.rand(1)
+    assert len(ref) == len(mine) == 5
+    assert all(torch.equal(a, b) for a, b in zip(ref, mine))
+    assert torch.equal(after_ref, after_mine)
+
+
+def test_product_fails_loudly_without_gpu_and_never_imports_the_oracle():
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):
+            ffi.init()
+        from ocl_amd import ops
+        with pytest.raises(RuntimeError):
+            ops.knn_sv(torch.zeros(2, 4), torch.zeros(2, dtype=torch.long), torch.zeros(3, 4), torch.zeros(3, dtype=torch.long), 3)
+    pkg = os.path.join(ROOT, "online-continual-learning_amd")
+    for dp, _, fs in os.walk(pkg):
+        for f in fs:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), "%s imports the oracle" % f
+                assert "/root/reference" not in src
+
+
+def test_scr_augment_parameter_ranges():
+    from ocl_amd.agents.scr import ScrAugment
+    torch.manual_seed(0)
+    p = ScrAugment((32, 32)).sample_params(500).numpy()
+    assert p.shape == (500, 12)
+    assert (p[:, 2] >= 1).all() and (p[:, 2] <= 32).all() and (p[:, 3] >= 1).all() and (p[:, 3] <= 32).all()
+    assert (p[:, 0] >= 0).all() and (p[:, 0] + p[:, 2] <= 32 + 1e-4).all()
+    assert (p[:, 1] >= 0).all() and (p[:, 1] + p[:, 3] <= 32 + 1e-4).all()
+    assert 0.12 < (p[:, 2] * p[:, 3] / 1024).min() and (p[:, 2] * p[:, 3] / 1024).max() <= 1.0 + 1e-5
+    assert set(np.unique(p[:, 4])) <= {0.0, 1.0} and 0.3 < p[:, 4].mean() < 0.7
+    assert 0.7 < p[:, 5].mean() < 0.9 and 0.1 < p[:, 11].mean() < 0.3
+    assert (p[:, 6:9] >= 0.6 - 1e-6).all() and (p[:, 6:9] <= 1.4 + 1e-6).all() and (np.abs(p[:, 9]) <= 0.1 + 1e-6).all()
+    assert (p[:, 10] >= 0).all() and (p[:, 10] <= 23).all()
+
+
+def test_metrics_match_hand_computation():
+    from ocl_amd.metrics import compute_performance
+    a = np.array([[[0.9, 0.0], [0.5, 0.8]], [[0.7, 0.1], [0.6, 0.6]]])
+    end, fgt, acc, bwtp, fwt = compute_performance(a)
+    assert abs(end[0] - np.mean([0.65, 0.6])) < 1e-12
+    assert abs(fgt[0] - np.mean([(0.4 + 0.0) / 2, (0.1 + 0.0) / 2])) < 1e-12
+    assert abs(fwt[0] - np.mean([0.0, 0.1])) < 1e-12
