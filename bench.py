@@ -1,0 +1,247 @@
+#!/usr/bin/env python
+"""bench.py — replay-step throughput of the MI355X-native hot path (BASELINE.json metric).
+
+One "step" = one iteration of the replay inner loop over one stream minibatch of 10 synthetic images.  Default
+workload (N=1): BASELINE.json configs[1] — SCR random/random, Split-CIFAR100 shape, mem_size 5000 (full),
+eps_mem_batch 100, temp 0.07: retrieve 100 rows from the device-resident buffer, augment, 110+110 views through
+SupConResNet (fwd+bwd, per-view BatchNorm), SupCon loss, SGD, reservoir update.  Inputs (uint8 task tensor, replay
+buffer, weights) are resident in HBM before the timed region.  N>1: one independent stream per rank/GPU (weak
+scaling, no data-path collective; one all_gather/all_reduce of scalars at the end).
+
+Prints ONE JSON line on rank 0 (see the task's bench contract) including
+  roofline     fp32-MFMA utilisation of the conv implicit-GEMM kernels, from HIP-event timing of every launch
+  cpu_baseline the oracle restatement of the same step timed on this box's host cores (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+# algorithmic work per image, Reduced-ResNet18 (MACs from forward hooks on the reference)
+MACS = {32: dict(fwd=54636160, stem=552960, fc=16000), 84: dict(fwd=385237440, stem=3810240, fc=64000)}
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2 peak (= vector fp32 peak)
+
+WORKLOADS = {
+    # name: (agent, retrieve, update, data, mem_size, eps_mem_batch, extra)
+    "scr": dict(agent="SCR", retrieve="random", update="random", data="cifar100", mem_size=5000, eps_mem_batch=100, temp=0.07, head="mlp"),
+    "aser": dict(agent="ER", retrieve="ASER", update="ASER", data="cifar100", mem_size=5000, eps_mem_batch=10, k=3, n_smp_cls=1.5,
+                 aser_type="asvm"),
+    "er": dict(agent="ER", retrieve="random", update="random", data="cifar10", mem_size=1000, eps_mem_batch=10),
+    "mir": dict(agent="ER", retrieve="MIR", update="random", data="mini_imagenet", mem_size=10000, eps_mem_batch=10, subsample=50),
+}
+
+
+def make_params(w, cuda=True):
+    from types import SimpleNamespace
+    trick = {k: False for k in ('labels_trick', 'kd_trick', 'separated_softmax', 'review_trick', 'ncm_trick', 'kd_trick_star')}
+    p = dict(agent="ER", retrieve="random", update="random", data="cifar100", mem_size=5000, eps_mem_batch=10, cuda=cuda, epoch=1,
+             batch=10, test_batch=128, verbose=False, optimizer="SGD", learning_rate=0.1, weight_decay=0, mem_iters=1, subsample=50,
+             k=3, aser_type="asvm", n_smp_cls=1.5, num_tasks=10, temp=0.07, head="mlp", buffer_tracker=False, error_analysis=False,
+             trick=trick)
+    p.update(w)
+    return SimpleNamespace(**p)
+
+
+def synth_u8(n, hw, n_classes, seed):
+    rng = np.random.default_rng(seed)
+    x = rng.integers(0, 256, (n, hw, hw, 3), dtype=np.uint8)
+    y = rng.integers(0, n_classes, n).astype(np.int64)
+    return x, y
+
+
+def flops_per_step(workload, hw, n_classes_in_buffer=100):
+    """Algorithmic conv flops per step by kernel class (fwd+dgrad GEMM vs wgrad); 2 flops per MAC."""
+    m = MACS[hw]
+    conv_fwd = m["fwd"] - m["fc"]
+    if workload == "scr":
+        train_imgs, eval_imgs = 220, 0
+    elif workload == "aser":
+        c = n_classes_in_buffer
+        train_imgs, eval_imgs = 40, (10 + c) + (2 * c) + (c + 160)
+    elif workload == "mir":
+        train_imgs, eval_imgs = 20, 100
+    else:
+        train_imgs, eval_imgs = 20, 0
+    gemm = 2.0 * (train_imgs * (conv_fwd + (conv_fwd - m["stem"])) + eval_imgs * conv_fwd)
+    wgrad = 2.0 * train_imgs * conv_fwd
+    return gemm, wgrad
+
+
+def build_agent(workload, seed, device):
+    import ocl_amd  # noqa: F401
+    from ocl_amd import name_match
+    from ocl_amd.setup_elements import setup_architecture, setup_opt, n_classes, input_size_match
+    import random
+    w = WORKLOADS[workload]
+    params = make_params(w)
+    np.random.seed(seed)
+    random.seed(seed)
+    torch.manual_seed(seed)
+    model = setup_architecture(params).to(device)
+    opt = setup_opt("SGD", model, params.learning_rate, params.weight_decay)
+    agent = name_match.agents[params.agent](model, opt, params)
+    hw = input_size_match[params.data][1]
+    ncls = n_classes[params.data]
+    # steady state: fill the replay buffer through the update plugin (builds ASER's class cache the reference's way)
+    rng = np.random.default_rng(seed + 1000)
+    chunk = 500
+    for s in range(0, params.mem_size, chunk):
+        n = min(chunk, params.mem_size - s)
+        ys = rng.integers(0, ncls, n).astype(np.int64)
+        xs = torch.from_numpy(rng.random((n, 3, hw, hw), dtype=np.float32)).to(device)
+        agent.buffer.update(xs, torch.from_numpy(ys).to(device), y_host=ys)
+    assert agent.buffer.current_index == params.mem_size
+    return params, model, agent, hw, ncls
+
+
+def gpu_leg(args, rank, world, local):
+    from ocl_amd import dist as odist
+    from ocl_amd import ops
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    params, model, agent, hw, ncls = build_agent(args.workload, args.seed + rank, device)
+    bs = params.batch
+    xw, yw = synth_u8(max(1, args.warmup) * bs, hw, ncls, 1 + rank)
+    xt, yt = synth_u8(args.steps * bs, hw, ncls, 2 + rank)
+    xw_d, xt_d = torch.from_numpy(xw).to(device), torch.from_numpy(xt).to(device)     # resident in HBM before timing
+    # warm-up (also builds kernel plans, allocates torch's caching pools)
+    agent.train_learner(xw_d, yw)
+    torch.cuda.synchronize()
+    odist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    agent.train_learner(xt_d, yt)          # EXACTLY args.steps iterations (drop_last, len = steps*batch)
+    torch.cuda.synchronize()
+    odist.barrier()
+    elapsed = time.perf_counter() - t0
+    elapsed = odist.max_over_ranks(elapsed, device)
+    total_steps = odist.sum_over_ranks(args.steps, device)
+    out = dict(elapsed=elapsed, total_steps=total_steps, hw=hw, bs=bs)
+
+    # ---- roofline leg: HIP events around every kernel launch, on the stream the kernels run on (rank 0) -----------
+    if rank == 0 and not args.no_roofline:
+        n_prof = min(args.steps, 20)
+        xp, yp = synth_u8(n_prof * bs, hw, ncls, 3)
+        xp_d = torch.from_numpy(xp).to(device)
+        ops.prof_enable(True)
+        ops.prof_reset()
+        agent.train_learner(xp_d, yp)
+        torch.cuda.synchronize()
+        cls = {}
+        for i, name in enumerate(["conv_gemm", "conv_wgrad", "bn_elementwise", "head_loss", "knn_buffer"]):
+            ms, n = ops.prof_query(i)
+            cls[name] = dict(ms=ms, launches=n)
+        ops.prof_enable(False)
+        ops.prof_reset()
+        gemm_fl, wgrad_fl = flops_per_step(args.workload, hw)
+        g = cls["conv_gemm"]
+        wg = cls["conv_wgrad"]
+        out["roofline"] = dict(
+            bound="mfma", kernel="conv_gemm_kernel (implicit-GEMM forward + data-gradient)",
+            achieved=(gemm_fl * n_prof / (g["ms"] * 1e-3) / 1e12) if g["ms"] > 0 else None,
+            peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+            frac=(gemm_fl * n_prof / (g["ms"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if g["ms"] > 0 else None,
+            traffic=None,
+            avg_launch_us=(g["ms"] * 1e3 / g["launches"]) if g["launches"] else None, launches_per_step=g["launches"] / n_prof,
+            algorithmic_gflop_per_step=gemm_fl / 1e9,
+            wgrad=dict(achieved=(wgrad_fl * n_prof / (wg["ms"] * 1e-3) / 1e12) if wg["ms"] > 0 else None,
+                       algorithmic_gflop_per_step=wgrad_fl / 1e9, launches_per_step=wg["launches"] / n_prof,
+                       avg_launch_us=(wg["ms"] * 1e3 / wg["launches"]) if wg["launches"] else None),
+            per_step_ms={k: v["ms"] / n_prof for k, v in cls.items()},
+            launches_per_step_all={k: v["launches"] / n_prof for k, v in cls.items()})
+    return out
+
+
+def cpu_leg(args):
+    """The oracle restatement of the same step on the host cores (bounded sample)."""
+    from oracle import ocl_oracle as O
+    w = WORKLOADS[args.workload]
+    cfg = dict(w, seed=args.seed, tasks=[[0]], n_train=0, n_test=0)
+    torch.manual_seed(args.seed)
+    np.random.seed(args.seed)
+    oa = O.OracleAgent(cfg)
+    hw = {"cifar10": 32, "cifar100": 32, "mini_imagenet": 84}[w["data"]]
+    ncls = {"cifar10": 10, "cifar100": 100, "mini_imagenet": 100}[w["data"]]
+    rng = np.random.default_rng(0)
+    n_fill = w["mem_size"]
+    for s in range(0, n_fill, 500):
+        n = min(500, n_fill - s)
+        ys = torch.from_numpy(rng.integers(0, ncls, n).astype(np.int64))
+        xs = torch.from_numpy(rng.random((n, 3, hw, hw), dtype=np.float32))
+        if w["update"] == "ASER":
+            O.aser_update(O.OracleNet(oa.state, head=oa.head, training=True), oa.buf, oa.cache, xs, ys, oa.p)
+        else:
+            O.reservoir_update(oa.buf, xs, ys)
+    n_warm, n_timed = 2, args.cpu_steps
+    x, y = synth_u8((n_warm + n_timed) * 10, hw, ncls, 4)
+    oa.train_learner(x[:n_warm * 10], y[:n_warm * 10])
+    t0 = time.perf_counter()
+    oa.train_learner(x[n_warm * 10:], y[n_warm * 10:])
+    dt = time.perf_counter() - t0
+    return dict(value=n_timed * 10 / dt, unit="stream images/s", cores=torch.get_num_threads(), kind="port",
+                sample="%d iterations of the %s step (oracle restatement: torch-CPU ATen ops, the reference's own backend) "
+                       "with the replay buffer full, %.1f s" % (n_timed, args.workload.upper(), dt),
+                ms_per_step=dt / n_timed * 1e3)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="scr", choices=sorted(WORKLOADS))
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--cpu-steps", type=int, default=40)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import ocl_amd  # noqa: F401
+    from ocl_amd import dist as odist
+    rank, world, local = odist.init_from_env()
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    res = gpu_leg(args, rank, world, local)
+    if rank != 0:
+        return
+    w = WORKLOADS[args.workload]
+    bs = res["bs"]
+    value = res["total_steps"] * bs / res["elapsed"]
+    line = {
+        "metric": "replay-step images/sec (%s, Split-CIFAR100-shaped synthetic stream, Reduced-ResNet18, mem_size %d)"
+                  % (args.workload.upper(), w["mem_size"]) if w["data"] != "mini_imagenet" else
+                  "replay-step images/sec (%s, Split-Mini-ImageNet-shaped synthetic stream, Reduced-ResNet18, mem_size %d)"
+                  % (args.workload.upper(), w["mem_size"]),
+        "value": value,
+        "unit": "stream images/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": res["elapsed"] / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[%d]: %s" % ({"er": 0, "scr": 1, "aser": 2, "mir": 3}[args.workload],
+                                                                  ", ".join("%s=%s" % kv for kv in sorted(w.items()))),
+                   "stream_batch": bs, "images_through_network_per_step": {"scr": 220, "aser": 610, "er": 20, "mir": 120}[args.workload],
+                   "parallelism": "%d independent stream(s), one per GPU" % world},
+    }
+    if "roofline" in res:
+        line["roofline"] = res["roofline"]
+    if not args.no_cpu_baseline and world == 1:
+        line["cpu_baseline"] = cpu_leg(args)
+    print(json.dumps(line))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,6 +1,7 @@
 """agents/exp_replay.py:10-104 — Experience Replay inner loop (also hosts MIR / ASER through the plugins)."""
 import torch
 
+from .. import debug
 from ..buffer import Buffer
 from ..data import DeviceLoader
 from ..utils import maybe_cuda, AverageMeter
@@ -42,6 +43,8 @@ class ExperienceReplay(ContinualLearner):
                         _, pred_label = torch.max(logits, 1)
                         acc_batch.update((pred_label == batch_y).sum() / batch_y.size(0), batch_y.size(0))
                         losses_batch.update(loss, batch_y.size(0))
+                    if debug.on():
+                        debug.emit("er_loss", loss=float(loss.detach()))
                     # backward
                     self.opt.zero_grad()
                     loss.backward()
@@ -58,6 +61,8 @@ class ExperienceReplay(ContinualLearner):
                             _, pred_label = torch.max(mem_logits, 1)
                             acc_mem.update((pred_label == mem_y).sum() / mem_y.size(0), mem_y.size(0))
 
+                        if debug.on():
+                            debug.emit("er_loss_mem", loss=float(loss_mem.detach()))
                         loss_mem.backward()
 
                     if aser:
@@ -67,6 +72,8 @@ class ExperienceReplay(ContinualLearner):
                         combined_labels = torch.cat((mem_y, batch_y))
                         combined_logits = self.model.forward(combined_batch)
                         loss_combined = self.criterion(combined_logits, combined_labels)
+                        if debug.on():
+                            debug.emit("er_loss_combined", loss=float(loss_combined.detach()))
                         loss_combined.backward()
                         self.opt.step()
                     else:

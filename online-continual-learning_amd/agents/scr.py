@@ -8,6 +8,7 @@ import math
 import torch
 
 from .. import ops
+from .. import debug
 from ..buffer import Buffer
 from ..data import DeviceLoader
 from ..setup_elements import input_size_match
@@ -94,6 +95,8 @@ class SupContrastReplay(ContinualLearner):
                         loss = self.criterion_views(features, combined_labels, 2)
                         if self.verbose:
                             losses.update(loss, batch_y.size(0))
+                        if debug.on():
+                            debug.emit("scr_loss", loss=float(loss.detach()))
                         self.opt.zero_grad()
                         loss.backward()
                         self.opt.step()

@@ -4,6 +4,7 @@ device->host synchronisation."""
 import torch
 
 from .. import ops
+from .. import debug
 from ..setup_elements import n_classes
 from ..utils import maybe_cuda
 from .aser_utils import compute_knn_sv
@@ -66,6 +67,8 @@ class ASER_retrieve(object):
             sv = ops.aser_score(sv_matrix_adv, None, "neg_sv")
 
         ret_ind = ops.argsort_desc(sv)[:num_retrieve].contiguous()
+        if debug.on():
+            debug.emit("aser_retrieve", cand_ind=cand_ind.numpy().copy(), sv=sv.cpu().numpy(), ret=cand_ind[ret_ind.cpu()].numpy())
 
         ret_x = ops.gather_rows(cand_x, ret_ind)
         ret_y = ops.gather_rows(cand_y, ret_ind)

@@ -4,6 +4,7 @@ import numpy as np
 import torch
 
 from .. import ops
+from .. import debug
 from ..setup_elements import n_classes
 from ..utils import maybe_cuda, nonzero_indices
 from .aser_utils import compute_knn_sv, add_minority_class_input
@@ -97,6 +98,10 @@ class ASER_update(object):
         ind_buffer = cand_ind[arg_buffer]
 
         buffer.n_seen_so_far += n_cur
+        if debug.on():
+            debug.emit("aser_update", eval_indices=eval_indices.numpy().copy(), cand_ind=cand_ind.numpy().copy(), sv=sv.cpu().numpy(),
+                       order=sv_arg_sort.numpy().copy(), ind_buffer=ind_buffer.numpy().copy(), ind_cur=ind_cur.numpy().copy(),
+                       n_minority=int(minority_batch_x.size(0)))
 
         # perform overwrite op
         y_upt_host = cur_y_host[ind_cur.numpy()]

@@ -7,6 +7,7 @@ import numpy as np
 import torch
 
 from .. import ops
+from .. import debug
 
 
 def _host_labels(y, y_host=None):
@@ -26,6 +27,7 @@ def random_retrieve(buffer, num_retrieve, excl_indices=None, return_indices=Fals
     num_retrieve = min(num_retrieve, valid_indices.shape[0])
     indices = torch.from_numpy(np.random.choice(valid_indices, num_retrieve, replace=False)).long()
 
+    debug.emit("random_retrieve", indices=indices.numpy().copy())
     idx_dev = indices.to(buffer.buffer_img.device)
     x = ops.gather_rows(buffer.buffer_img, idx_dev)
     y = ops.gather_rows(buffer.buffer_label, idx_dev)

@@ -7,6 +7,7 @@ kernel writing a shadow flat array (no deepcopy) and the second forward reads th
 import torch
 
 from .. import ops
+from .. import debug
 from .buffer_utils import random_retrieve, get_grad_vector
 
 
@@ -33,6 +34,8 @@ class MIR_retrieve(object):
                 logits_post = model.forward_with_params(sub_x, self._shadow)
                 scores = ops.mir_scores(logits_pre, logits_post, sub_y)
                 big_ind = ops.argsort_desc(scores)[:self.num_retrieve].contiguous()
+                if debug.on():
+                    debug.emit("mir", scores=scores.cpu().numpy(), big_ind=big_ind.cpu().numpy())
             return ops.gather_rows(sub_x, big_ind), ops.gather_rows(sub_y, big_ind)
         else:
             return sub_x, sub_y

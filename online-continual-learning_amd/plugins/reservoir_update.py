@@ -5,6 +5,7 @@ import numpy as np
 import torch
 
 from .. import ops
+from .. import debug
 from .buffer_utils import _host_labels
 
 
@@ -30,6 +31,7 @@ class Reservoir_update(object):
             # everything was added
             if offset == x.size(0):
                 filled_idx = list(range(buffer.current_index - offset, buffer.current_index, ))
+                debug.emit("reservoir", slots=list(filled_idx))
                 return filled_idx
 
         # remove what is already in the buffer
@@ -45,6 +47,7 @@ class Reservoir_update(object):
         buffer.n_seen_so_far += x.size(0)
 
         if idx_buffer.numel() == 0:
+            debug.emit("reservoir", slots=[])
             return []
 
         assert idx_buffer.max() < buffer.buffer_img.size(0)
@@ -64,4 +67,5 @@ class Reservoir_update(object):
         ops.scatter_rows(buffer.buffer_img, keys_dev, ops.gather_rows(x.contiguous(), vals_dev))
         ops.scatter_rows(buffer.buffer_label, keys_dev, ops.gather_rows(y.contiguous(), vals_dev))
         buffer.label_host[np.asarray(keys, dtype=np.int64)] = y_host[np.asarray(vals, dtype=np.int64)]
+        debug.emit("reservoir", slots=list(keys))
         return keys

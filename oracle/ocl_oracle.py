@@ -159,9 +159,12 @@ class OracleNet(object):
         self.head = head
         self.training = training
         self.pre = "encoder." if head is not None else ""
+        self.rec = None   # set to a dict to record the raw conv output feeding every BatchNorm (layer-wise parity tests)
 
     def _bn(self, x, name):
         s = self.s
+        if self.rec is not None:
+            self.rec[name] = x.detach()
         if self.training:
             s[name + ".num_batches_tracked"] += 1
         return F.batch_norm(x, s[name + ".running_mean"], s[name + ".running_var"], s[name + ".weight"], s[name + ".bias"],
@@ -394,7 +397,8 @@ def aser_update(net, buf, cache, x, y, params):
     cache.update(buf.label, params["n_classes"], new_y=cur_y[ind_cur], ind=ind_buffer)
     buf.img[ind_buffer] = cur_x[ind_cur]
     buf.label[ind_buffer] = cur_y[ind_cur]
-    return ind_buffer, ind_cur, tot
+    return dict(ind_buffer=ind_buffer.numpy(), ind_cur=ind_cur.numpy(), sv=tot, eval_indices=ev.numpy(), cand_ind=cand_ind.numpy(),
+                order=order.numpy(), n_minority=int(minority.numel()))
 
 
 # ======================================================================================================
@@ -501,6 +505,8 @@ def aser_er_step(state, names, buf, cache, batch_x, batch_y, params):
     loss.backward()
     ret_idx, cand, sv = aser_retrieve(net, buf, cache, batch_x, batch_y, params)
     info["ret_idx"] = ret_idx.numpy() if torch.is_tensor(ret_idx) else ret_idx
+    info["cand"] = None if cand is None else cand.numpy()
+    info["sv"] = sv
     mem_x, mem_y = buf.img[ret_idx], buf.label[ret_idx]
     if mem_x.shape[0] > 0:
         ce_mean(net.forward(mem_x), mem_y).backward()

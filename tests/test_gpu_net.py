@@ -1,0 +1,268 @@
+"""GPU: the Reduced-ResNet18 / SupConResNet engine (conv implicit-GEMM fwd / dgrad / wgrad, BatchNorm, pool, heads)
+against the torch-fp32 oracle restatement (oracle.OracleNet, itself pinned against the reference modules).
+
+Tolerances (fp32 everywhere, different summation order than ATen): layer outputs 1e-5 relative-to-max per layer,
+network outputs / losses 1e-4 abs, gradients 1e-3 relative to the tensor's max |g| (BatchNorm's 1/std amplifies
+round-off over 20 layers)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import gold
+from oracle import ocl_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def build(agent, data, head="mlp", seed=11, cuda=None, max_batch=64):
+    from types import SimpleNamespace
+    from ocl_amd.setup_elements import setup_architecture
+    torch.manual_seed(seed)
+    m = setup_architecture(SimpleNamespace(agent=agent, data=data, head=head))
+    m.max_batch = max_batch
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    m = m.cuda()
+    return m, sd
+
+
+def relmax(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return np.abs(a - b).max() / (1e-12 + np.abs(b).max())
+
+
+def layer_report(m, net_rec, n):
+    """Per-conv raw output error (NHWC engine tape vs oracle NCHW record); returns list of (name, relerr)."""
+    from ocl_amd import ffi
+    L = ffi.lib()
+    rows = []
+    for i, (name, ref) in enumerate(net_rec.items()):
+        ref = ref.numpy()
+        cnt = ref.size
+        dst = torch.empty(cnt, dtype=torch.float32, device="cuda")
+        nw = ffi.i64(0)
+        slot = (m._slot_rr - 1) % m._desc.n_slots
+        ffi.check(L.ocl_net_debug_copy(m._net, slot, 0, i, ffi.ptr(dst), cnt, C.byref(nw), ffi.stream()))
+        got = dst.cpu().numpy().reshape(ref.shape[0], ref.shape[2], ref.shape[3], ref.shape[1]).transpose(0, 3, 1, 2)
+        rows.append((name, relmax(got, ref)))
+    return rows
+
+
+CASES = [
+    # agent, data, head, n, groups
+    ("ER", "cifar100", None, 10, 1),
+    ("ER", "cifar10", None, 20, 1),
+    ("ER", "cifar100", None, 3, 1),
+    ("SCR", "cifar100", "mlp", 14, 2),
+    ("SCR", "cifar100", "mlp", 220, 2),
+    ("ER", "mini_imagenet", None, 6, 1),
+    ("SCR", "cifar100", "linear", 8, 2),
+]
+
+
+@pytest.mark.parametrize("agent,data,head,n,groups", CASES)
+def test_train_forward_backward_vs_oracle(cuda, agent, data, head, n, groups):
+    hw = 84 if data == "mini_imagenet" else 32
+    m, sd = build(agent, data, head or "mlp", cuda=cuda, max_batch=max(64, n))
+    rng = np.random.default_rng(n)
+    x = rng.random((n, 3, hw, hw)).astype(np.float32)
+    y = rng.integers(0, 10, n).astype(np.int64)
+    st = O.clone_state(sd)
+    net = O.OracleNet(st, head=head, training=True)
+    net.rec = {}
+    xt = torch.from_numpy(x)
+    per = n // groups
+    o_ref = torch.cat([net.forward(xt[g * per:(g + 1) * per]) for g in range(groups)], 0)   # separate forward calls per view
+    rec = {}
+    if groups == 1:
+        rec = dict(net.rec)
+    w = torch.linspace(-1, 1, o_ref.numel()).view_as(o_ref)
+    if head is None:
+        loss_ref = torch.nn.functional.cross_entropy(o_ref, torch.from_numpy(y))
+    else:
+        loss_ref = (o_ref * w).sum()
+    loss_ref.backward()
+
+    m.train()
+    xd = torch.from_numpy(x).to(cuda)
+    if groups == 1:
+        out = m.forward(xd)
+    else:
+        out = m.forward_views([xd[g * per:(g + 1) * per] for g in range(groups)])
+    if rec:
+        rows = layer_report(m, rec, n)
+        print("\n".join("%-40s %.3e" % r for r in rows))
+        worst = max(r[1] for r in rows)
+        assert worst < 1e-4, "raw conv outputs diverge: %s" % (max(rows, key=lambda r: r[1]),)
+    err_out = np.abs(out.detach().cpu().numpy() - o_ref.detach().numpy()).max()
+    print("out err", err_out)
+    assert err_out < 1e-4
+    if head is None:
+        from ocl_amd.loss import cross_entropy_mean
+        loss = cross_entropy_mean(out, torch.from_numpy(y).to(cuda))
+    else:
+        loss = (out * w.to(cuda)).sum()
+    assert abs(float(loss) - float(loss_ref.detach())) < 1e-4 * max(1.0, abs(float(loss_ref.detach())))
+    loss.backward()
+    torch.cuda.synchronize()
+    names = [k for k, _ in m.named_parameters()]
+    worst, rows = 0.0, []
+    for k, p in m.named_parameters():
+        gref = st[k].grad
+        if gref is None:
+            assert float(p.grad.abs().max()) == 0.0, "%s should have a zero gradient" % k
+            continue
+        e = np.abs(p.grad.cpu().numpy() - gref.numpy()).max() / (1e-12 + float(gref.abs().max()))
+        rows.append((k, e, float(gref.abs().max())))
+        worst = max(worst, e)
+    print("\n".join("%-44s rel %.3e  max|g| %.3e" % r for r in rows))
+    assert worst < 1e-3, max(rows, key=lambda r: r[1])
+    # BatchNorm running statistics (momentum 0.1, unbiased variance, one update per forward call / group)
+    sd_new = m.state_dict()
+    for k in sd_new:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert relmax(sd_new[k].cpu().numpy(), st[k].numpy()) < 1e-4, k
+        if k.endswith("num_batches_tracked"):
+            assert int(sd_new[k]) == int(st[k]) == groups
+
+
+def test_gradient_accumulation_and_zero_grad_semantics(cuda):
+    """loss.backward() twice accumulates (agents/exp_replay.py:55,77); opt.zero_grad() makes the next one overwrite;
+    FusedSGD.step equals torch.optim.SGD.step."""
+    from ocl_amd.setup_elements import setup_opt
+    from ocl_amd.loss import cross_entropy_mean
+    m, sd = build("ER", "cifar10", cuda=cuda)
+    opt = setup_opt("SGD", m, 0.1, 0)
+    rng = np.random.default_rng(1)
+    xa, xb = rng.random((10, 3, 32, 32)).astype(np.float32), rng.random((10, 3, 32, 32)).astype(np.float32)
+    ya, yb = rng.integers(0, 10, 10), rng.integers(0, 10, 10)
+    st = O.clone_state(sd)
+    names = [k for k in st if st[k].requires_grad]
+    net = O.OracleNet(st, training=True)
+    O.ce_mean(net.forward(torch.from_numpy(xa)), torch.from_numpy(ya)).backward()
+    O.ce_mean(net.forward(torch.from_numpy(xb)), torch.from_numpy(yb)).backward()
+    gref = O.flat_grad(st, names).numpy()
+    m.train()
+    opt.zero_grad()
+    cross_entropy_mean(m.forward(torch.from_numpy(xa).to(cuda)), torch.from_numpy(ya).to(cuda)).backward()
+    cross_entropy_mean(m.forward(torch.from_numpy(xb).to(cuda)), torch.from_numpy(yb).to(cuda)).backward()
+    g = m.flat_grads().cpu().numpy()
+    assert np.abs(g - gref).max() < 1e-3 * np.abs(gref).max()
+    O.sgd_step(st, names, 0.1)
+    opt.step()
+    pref = torch.cat([st[k].detach().reshape(-1) for k in names]).numpy()
+    assert np.abs(m.flat_params().cpu().numpy() - pref).max() < 1e-4 * np.abs(pref).max()
+    # zero_grad then ONE backward overwrites
+    O.zero_grad(st, names)
+    O.ce_mean(O.OracleNet(st, training=True).forward(torch.from_numpy(xa)), torch.from_numpy(ya)).backward()
+    opt.zero_grad()
+    cross_entropy_mean(m.forward(torch.from_numpy(xa).to(cuda)), torch.from_numpy(ya).to(cuda)).backward()
+    g1 = O.flat_grad(st, names).numpy()
+    assert np.abs(m.flat_grads().cpu().numpy() - g1).max() < 2e-3 * np.abs(g1).max()
+    # p.grad views alias the flat gradient (get_grad_vector layout)
+    off = 0
+    for p in m.parameters():
+        assert p.grad.data_ptr() == m.flat_grads().data_ptr() + 4 * off
+        off += p.numel()
+
+
+@pytest.mark.parametrize("agent,data,head,n", [("ER", "cifar100", None, 70), ("SCR", "cifar100", "mlp", 33), ("ER", "mini_imagenet", None, 5)])
+def test_eval_forward_features_vs_oracle(cuda, agent, data, head, n):
+    """eval-mode (running statistics) features / outputs: the ASER scoring and NCM path (utils/utils.py:45-90)."""
+    hw = 84 if data == "mini_imagenet" else 32
+    m, sd = build(agent, data, head or "mlp", cuda=cuda, max_batch=32)
+    # make the running statistics non-trivial
+    rng = np.random.default_rng(2)
+    for k in sd:
+        if k.endswith("running_mean"):
+            sd[k] = torch.from_numpy(rng.standard_normal(sd[k].shape).astype(np.float32) * 0.1)
+        if k.endswith("running_var"):
+            sd[k] = torch.from_numpy((0.5 + rng.random(sd[k].shape)).astype(np.float32))
+    m.load_state_dict(sd)
+    x = rng.random((n, 3, hw, hw)).astype(np.float32)
+    st = O.clone_state(sd, requires_grad=False)
+    net = O.OracleNet(st, head=head, training=False)
+    with torch.no_grad():
+        f_ref = net.features(torch.from_numpy(x)).numpy()
+        o_ref = net.forward(torch.from_numpy(x)).numpy()
+    m.eval()
+    with torch.no_grad():
+        f = m.features_batched(torch.from_numpy(x).to(cuda)).cpu().numpy()     # n > max_batch: chunked
+        o = torch.cat([m.forward(torch.from_numpy(x[i:i + 32]).to(cuda)) for i in range(0, n, 32)]).cpu().numpy()
+    assert relmax(f, f_ref) < 1e-4 and np.abs(o - o_ref).max() < 1e-4
+    sd2 = m.state_dict()
+    for k in sd:
+        if "running" in k or "num_batches" in k:
+            assert torch.equal(sd2[k].cpu(), sd[k]), "eval forward must not touch BatchNorm buffers"
+
+
+def test_virtual_params_forward_does_not_touch_model(cuda):
+    """MIR's theta - lr*grad forward (mir_retrieve.py:21,25) through params_override."""
+    m, sd = build("ER", "cifar100", cuda=cuda)
+    rng = np.random.default_rng(3)
+    x = rng.random((12, 3, 32, 32)).astype(np.float32)
+    delta = (rng.standard_normal(m.flat_params().numel()) * 0.01).astype(np.float32) if False else None
+    m.train()
+    m._ensure_bound()
+    shadow = m.flat_params().clone()
+    shadow += torch.from_numpy((rng.standard_normal(shadow.numel()) * 0.01).astype(np.float32)).to(cuda)
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        out_v = m.forward_with_params(torch.from_numpy(x).to(cuda), shadow).cpu().numpy()
+    after = m.state_dict()
+    for k in before:
+        assert torch.equal(before[k], after[k]), "virtual forward modified %s" % k
+    st = O.clone_state(sd, requires_grad=False)
+    o = 0
+    for k in [kk for kk, _ in m.named_parameters()]:
+        nel = st[k].numel()
+        st[k] = shadow[o:o + nel].view_as(st[k]).cpu()
+        o += nel
+    with torch.no_grad():
+        ref = O.OracleNet(st, training=True).forward(torch.from_numpy(x)).numpy()
+    assert np.abs(out_v - ref).max() < 1e-4
+
+
+def test_resnet_matches_reference_golden(cuda):
+    """Directly against vectors recorded from the reference modules (tests/golden/resnet.npz)."""
+    from ocl_amd.loss import cross_entropy_mean
+    g = gold("resnet")
+    for name, agent, data, hw, n, head in [("rr18_c100", "ER", "cifar100", 32, 6, None), ("scr_mlp", "SCR", "cifar100", 32, 6, "mlp"),
+                                           ("rr18_mini", "ER", "mini_imagenet", 84, 3, None)]:
+        m, sd = build(agent, data, head or "mlp", seed=11, cuda=cuda, max_batch=16)
+        rng = np.random.default_rng(5)
+        x = torch.from_numpy(rng.random((n, 3, hw, hw)).astype(np.float32)).to(cuda)
+        y = torch.from_numpy(rng.integers(0, 100, n).astype(np.int64)).to(cuda)
+        m.train()
+        o = m.forward(x)
+        loss = cross_entropy_mean(o, y) if head is None else (o * torch.linspace(-1, 1, o.numel()).view_as(o).to(cuda)).sum()
+        loss.backward()
+        assert np.abs(o.detach().cpu().numpy() - g[name + "_out"]).max() < 1e-4
+        assert abs(float(loss) - float(g[name + "_loss"])) < 1e-4 * max(1.0, abs(float(g[name + "_loss"])))
+        named = dict(m.named_parameters())
+        for k in g[name + "_picked"]:
+            gg = g[name + "_g_" + str(k)]
+            got = named[str(k)].grad.cpu().numpy()
+            assert np.abs(got - gg).max() <= 1e-3 * (1e-12 + np.abs(gg).max()), (name, k)
+        m.eval()
+        with torch.no_grad():
+            fe = m.features(x).cpu().numpy()
+        assert relmax(fe, g[name + "_feat_eval"]) < 1e-4
+
+
+def test_backward_without_tape_fails_loudly(cuda):
+    from ocl_amd import ffi
+    m, _ = build("ER", "cifar10", cuda=cuda)
+    m.n_slots = 2
+    m.train()
+    x = torch.rand(4, 3, 32, 32, device=cuda)
+    o1 = m.forward(x)
+    m.forward(x)
+    m.forward(x)    # third forward overwrites the first one's tape (2 slots)
+    with pytest.raises(RuntimeError):
+        o1.sum().backward()
+    with pytest.raises(RuntimeError):
+        m.forward(torch.rand(4, 3, 16, 16, device=cuda))
+    with pytest.raises(RuntimeError):
+        m.forward(torch.rand(4, 3, 32, 32))     # CPU tensor: no CPU path
