@@ -196,9 +196,21 @@ int ocl_net_forward(ocl_net* net, const float* x, int n, int groups, uint32_t fl
  * encoder.linear) get zero / are left untouched respectively. */
 int ocl_net_backward(ocl_net* net, int slot, const float* dout, int accumulate, void* stream);
 
-/* Per-layer access for tests: raw conv output (NHWC) of conv layer `conv_index` in `slot`. */
+/* Test hooks. debug_stop: make ocl_net_backward return right after stage block*10+step (step 1: bn2 backward,
+ * 2: conv2 data gradient, 3: bn1 backward, 4: conv1 data gradient, 5: block input gradient complete; 990: after the
+ * head; -1: off).  debug_copy what: 0 raw conv output (NHWC) of conv `index`; 1 output of block `index`; 2 gradient
+ * scratch buffer `index`; 3 gradient buffer by role (0..4 = gA..gE) at the last stop; 4 activation a1 of block `index`; 5 stem output. */
+int ocl_net_debug_stop(ocl_net* net, int stage);
 int ocl_net_debug_copy(ocl_net* net, int slot, int what, int index, float* dst, int64_t max_floats,
                        int64_t* n_written, void* stream);
+
+/* ---- kernel-level entry points (single layers; tests and micro-benchmarks) ------------------------------
+ * BatchNorm2d backward (train mode) fused with the ReLU mask that follows it: dpre = dz * (zmask > 0) (zmask NULL =
+ * no ReLU); dy = gamma*invstd*(dpre - mean(dpre) - xhat*mean(dpre*xhat)); dgamma = sum(dpre*xhat), dbeta = sum(dpre).
+ * Tensors are NHWC [groups*m_per_group, c]; mean/invstd are [groups, c]. scratch: groups*2*c doubles. */
+int ocl_bn_bwd_nhwc(const float* dz, const float* zmask, const float* y, const float* mean, const float* invstd,
+                    const float* gamma, int64_t m_per_group, int groups, int c, float* dy, float* dgamma,
+                    float* dbeta, int accumulate, double* scratch, void* stream);
 
 /* ---- measurement helpers --------------------------------------------------------------------------
  * HIP-event timing on the caller's stream (bench.py's roofline leg: torch.cuda.Event only sees

@@ -85,6 +85,8 @@ struct ocl_net {
     bool bound = false;
     bool descs_uploaded = false;
 
+    int dbg_stop = -1;            // debug: return from backward right after stage (block*10 + step)
+    float* dbg_role[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<int> slot_n, slot_groups;
     std::vector<bool> slot_valid;
     std::map<std::pair<int, int>, PlanSet> plans;
@@ -814,6 +816,12 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
         return OCL_OK;
     };
 
+    auto stop_here = [&](int bi, int step) -> bool {
+        if (n->dbg_stop != bi * 10 + step) return false;
+        n->dbg_role[0] = gA; n->dbg_role[1] = gB; n->dbg_role[2] = gC; n->dbg_role[3] = gD; n->dbg_role[4] = gE;
+        return true;
+    };
+    if (stop_here(99, 0)) return OCL_OK;   // right after the head: gA = dL/dz of the last block
     for (int bi = (int)n->blocks.size() - 1; bi >= 0; --bi) {
         const BlockInfo& b = n->blocks[bi];
         const float* xin = bi == 0 ? S + n->zstem_off : S + n->blocks[bi - 1].z_off;
@@ -821,23 +829,34 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
         const float* z = S + b.z_off;
         // gA = dL/dz.  bn2 (and the projection BN) share the ReLU-masked gradient.
         if ((rc = bn_bwd(gA, z, b.conv2, gB, b.convs, gC))) return rc;
+        if (stop_here(bi, 1)) return OCL_OK;                                 // gB = dL/dy2, gC = dL/dys
         if (b.convs >= 0)
             if ((rc = wgrad(b.convs, xin, gC))) return rc;
         if ((rc = wgrad(b.conv2, a1, gB))) return rc;
         if ((rc = dgrad(b.conv2, gB, gD, nullptr, nullptr, 0))) return rc;   // gD = dL/da1 (pre-mask)
+        if (stop_here(bi, 2)) return OCL_OK;
         if ((rc = bn_bwd(gD, a1, b.conv1, gB, -1, nullptr))) return rc;      // gB = dL/dy1
+        if (stop_here(bi, 3)) return OCL_OK;
         if ((rc = wgrad(b.conv1, xin, gB))) return rc;
         if (b.convs >= 0) {
             if ((rc = dgrad(b.conv1, gB, gE, nullptr, nullptr, 0))) return rc;
+            if (stop_here(bi, 4)) return OCL_OK;
             if ((rc = dgrad(b.convs, gC, gE, nullptr, nullptr, EPI_ACCUM))) return rc;
         } else {
             if ((rc = dgrad(b.conv1, gB, gE, gA, z, 0))) return rc;         // + identity shortcut: dz * (z>0)
         }
+        if (stop_here(bi, 5)) return OCL_OK;                                 // gE = dL/dx of the block
         std::swap(gA, gE);
     }
     // stem
     if ((rc = bn_bwd(gA, S + n->zstem_off, 0, gB, -1, nullptr))) return rc;
     if ((rc = wgrad(0, S + n->x4_off, gB))) return rc;
+    return OCL_OK;
+}
+
+int ocl_net_debug_stop(ocl_net* n, int stage) {
+    OCL_REQUIRE(n, "debug_stop: null net");
+    n->dbg_stop = stage;
     return OCL_OK;
 }
 
@@ -862,6 +881,19 @@ int ocl_net_debug_copy(ocl_net* n, int slot, int what, int index, float* dst, in
         OCL_REQUIRE(index >= 0 && index < 5, "debug_copy: gbuf index");
         src = n->gbuf(index);
         cnt = n->gbuf_floats;
+    } else if (what == 3) {  // gradient buffer by role (gA..gE) at the last debug stop
+        OCL_REQUIRE(index >= 0 && index < 5 && n->dbg_role[index], "debug_copy: no debug stop recorded");
+        src = n->dbg_role[index];
+        cnt = n->gbuf_floats;
+    } else if (what == 5) {  // stem output
+        const ConvInfo& c = n->convs[0];
+        src = S + n->zstem_off;
+        cnt = (int64_t)N * c.Ho * c.Wo * c.Cout;
+    } else if (what == 4) {  // post-ReLU activation a1 of block `index`
+        OCL_REQUIRE(index >= 0 && index < (int)n->blocks.size(), "debug_copy: block index");
+        const ConvInfo& c = n->convs[n->blocks[index].conv1];
+        src = S + n->blocks[index].a1_off;
+        cnt = (int64_t)N * c.Ho * c.Wo * c.Cout;
     } else {
         set_error("debug_copy: what=%d", what);
         return OCL_ERR_ARG;

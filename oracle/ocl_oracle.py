@@ -149,6 +149,22 @@ def mir_scores(logits_pre, logits_post, y):
 # ======================================================================================================
 
 
+class _MaskedRelu(torch.autograd.Function):
+    """ReLU whose BACKWARD uses a given 0/1 mask instead of (output > 0).  Used by the parity tests to teacher-force the
+    activation pattern of the implementation under test: a pre-activation within fp32 round-off of zero may legitimately
+    land on either side, and the gradient is discontinuous there."""
+
+    @staticmethod
+    def forward(ctx, x, mask):
+        ctx.save_for_backward(mask)
+        return x.clamp(min=0)
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return g * mask, None
+
+
 class OracleNet(object):
     """Functional restatement: `state` maps the reference's state_dict keys to CPU tensors (parameters may
     require grad).  head: None -> logits = linear(features) (ResNet.forward); 'mlp' | 'linear' | 'None' ->
@@ -160,11 +176,24 @@ class OracleNet(object):
         self.training = training
         self.pre = "encoder." if head is not None else ""
         self.rec = None   # set to a dict to record the raw conv output feeding every BatchNorm (layer-wise parity tests)
+        self.tape = None  # set to a dict to keep LIVE intermediates with retain_grad (stage-wise backward diagnostics)
+        self.mask_override = None  # dict key -> float 0/1 NCHW mask used for the ReLU backward (keys "z:stem", "a1:<block>", "z:<block>")
+        self.pre_act = None   # set to a dict to record ReLU inputs (to judge how ambiguous a mask mismatch is)
+
+    def _relu(self, x, key):
+        if self.pre_act is not None:
+            self.pre_act[key] = x.detach()
+        if self.mask_override is not None and key in self.mask_override:
+            return _MaskedRelu.apply(x, self.mask_override[key])
+        return F.relu(x)
 
     def _bn(self, x, name):
         s = self.s
         if self.rec is not None:
             self.rec[name] = x.detach()
+        if self.tape is not None and x.requires_grad:
+            x.retain_grad()
+            self.tape["y:" + name] = x
         if self.training:
             s[name + ".num_batches_tracked"] += 1
         return F.batch_norm(x, s[name + ".running_mean"], s[name + ".running_var"], s[name + ".weight"], s[name + ".bias"],
@@ -172,17 +201,27 @@ class OracleNet(object):
 
     def _block(self, x, p, stride):
         s = self.s
-        out = F.relu(self._bn(F.conv2d(x, s[p + ".conv1.weight"], None, stride, 1), p + ".bn1"))
+        out = self._relu(self._bn(F.conv2d(x, s[p + ".conv1.weight"], None, stride, 1), p + ".bn1"), "a1:" + p)
+        if self.tape is not None and out.requires_grad:
+            out.retain_grad()
+            self.tape["a1:" + p] = out
         out = self._bn(F.conv2d(out, s[p + ".conv2.weight"], None, 1, 1), p + ".bn2")
         if (p + ".shortcut.0.weight") in s:
             sc = self._bn(F.conv2d(x, s[p + ".shortcut.0.weight"], None, stride, 0), p + ".shortcut.1")
         else:
             sc = x
-        return F.relu(out + sc)
+        res = self._relu(out + sc, "z:" + p)
+        if self.tape is not None and res.requires_grad:
+            res.retain_grad()
+            self.tape["z:" + p] = res
+        return res
 
     def features(self, x):
         s, pre = self.s, self.pre
-        out = F.relu(self._bn(F.conv2d(x, s[pre + "conv1.weight"], None, 1, 1), pre + "bn1"))
+        out = self._relu(self._bn(F.conv2d(x, s[pre + "conv1.weight"], None, 1, 1), pre + "bn1"), "z:stem")
+        if self.tape is not None and out.requires_grad:
+            out.retain_grad()
+            self.tape["z:stem"] = out
         for layer in range(1, 5):
             for b in range(2):
                 out = self._block(out, "%slayer%d.%d" % (pre, layer, b), 2 if (b == 0 and layer > 1) else 1)
@@ -463,6 +502,7 @@ def er_step(state, names, buf, batch_x, batch_y, params, retrieve="random"):
         sub = random_retrieve_indices(buf, params["subsample"])
         g = flat_grad(state, names)
         info["sub"] = sub
+        info["grad"] = g.clone()
         if sub.shape[0] > 0:
             virt = OrderedDict()
             o = 0

@@ -60,53 +60,91 @@ CASES = [
     ("SCR", "cifar100", "linear", 8, 2),
 ]
 
+BLOCKS = ["layer%d.%d" % (l, b) for l in range(1, 5) for b in range(2)]
+
+
+def fetch_act(m, what, index, shape_nchw):
+    from ocl_amd import ffi
+    n, c, h, w = shape_nchw
+    cnt = n * c * h * w
+    dst = torch.empty(cnt, dtype=torch.float32, device="cuda")
+    nw = ffi.i64(0)
+    slot = (m._slot_rr - 1) % m._desc.n_slots
+    ffi.check(ffi.lib().ocl_net_debug_copy(m._net, slot, what, index, ffi.ptr(dst), cnt, C.byref(nw), ffi.stream()))
+    return dst.cpu().view(n, h, w, c).permute(0, 3, 1, 2).contiguous()
+
+
+def engine_masks(m, shapes, pre):
+    """ReLU activation patterns of the engine's last train-mode forward, keyed like OracleNet._relu."""
+    masks = {"z:stem": (fetch_act(m, 5, 0, shapes["z:stem"]) > 0).float()}
+    for bi, p in enumerate(BLOCKS):
+        masks["a1:" + pre + p] = (fetch_act(m, 4, bi, shapes["a1:" + pre + p]) > 0).float()
+        masks["z:" + pre + p] = (fetch_act(m, 1, bi, shapes["z:" + pre + p]) > 0).float()
+    return masks
+
 
 @pytest.mark.parametrize("agent,data,head,n,groups", CASES)
 def test_train_forward_backward_vs_oracle(cuda, agent, data, head, n, groups):
+    """Forward: raw conv outputs, network output, loss, running statistics vs the oracle.  Backward: every parameter
+    gradient vs autograd on the oracle with the ReLU activation pattern teacher-forced to the engine's (a ReLU input
+    within fp32 round-off of zero may land on either side — about one element per 10^5 — and the gradient is
+    discontinuous there); every element whose pattern differs from ATen's must be such an ambiguous one."""
     hw = 84 if data == "mini_imagenet" else 32
     m, sd = build(agent, data, head or "mlp", cuda=cuda, max_batch=max(64, n))
+    pre = "encoder." if head is not None else ""
     rng = np.random.default_rng(n)
     x = rng.random((n, 3, hw, hw)).astype(np.float32)
     y = rng.integers(0, 10, n).astype(np.int64)
+    xt = torch.from_numpy(x)
+    per = n // groups
+    # ---- engine forward
+    m.train()
+    xd = torch.from_numpy(x).to(cuda)
+    out = m.forward(xd) if groups == 1 else m.forward_views([xd[g * per:(g + 1) * per] for g in range(groups)])
+    torch.cuda.synchronize()
+    # ---- oracle forward (one call per group = per view), masks teacher-forced
     st = O.clone_state(sd)
     net = O.OracleNet(st, head=head, training=True)
     net.rec = {}
-    xt = torch.from_numpy(x)
-    per = n // groups
-    o_ref = torch.cat([net.forward(xt[g * per:(g + 1) * per]) for g in range(groups)], 0)   # separate forward calls per view
-    rec = {}
+    probe = O.OracleNet(O.clone_state(sd, requires_grad=False), head=head, training=True)
+    probe.pre_act = {}
+    with torch.no_grad():
+        probe.forward(xt[:per])
+    shapes = {k: (n,) + tuple(v.shape[1:]) for k, v in probe.pre_act.items()}
+    masks = engine_masks(m, shapes, pre)
+    outs, n_mis, n_tot, worst_amb = [], 0, 0, 0.0
+    for g in range(groups):
+        net.mask_override = {k: v[g * per:(g + 1) * per] for k, v in masks.items()}
+        net.pre_act = {}
+        outs.append(net.forward(xt[g * per:(g + 1) * per]))
+        for k, pa in net.pre_act.items():
+            mis = (pa > 0).float() != net.mask_override[k]
+            n_mis += int(mis.sum())
+            n_tot += pa.numel()
+            if mis.any():
+                worst_amb = max(worst_amb, float(pa[mis].abs().max() / pa.abs().max()))
+    o_ref = torch.cat(outs, 0)
+    print("relu pattern mismatches: %d of %d, worst |pre-activation| / max = %.2e" % (n_mis, n_tot, worst_amb))
+    assert n_mis <= 5 + 2e-5 * n_tot and worst_amb < 1e-5, "activation patterns differ beyond fp32 round-off"
     if groups == 1:
-        rec = dict(net.rec)
-    w = torch.linspace(-1, 1, o_ref.numel()).view_as(o_ref)
-    if head is None:
-        loss_ref = torch.nn.functional.cross_entropy(o_ref, torch.from_numpy(y))
-    else:
-        loss_ref = (o_ref * w).sum()
-    loss_ref.backward()
-
-    m.train()
-    xd = torch.from_numpy(x).to(cuda)
-    if groups == 1:
-        out = m.forward(xd)
-    else:
-        out = m.forward_views([xd[g * per:(g + 1) * per] for g in range(groups)])
-    if rec:
-        rows = layer_report(m, rec, n)
+        rows = layer_report(m, net.rec, n)
         print("\n".join("%-40s %.3e" % r for r in rows))
-        worst = max(r[1] for r in rows)
-        assert worst < 1e-4, "raw conv outputs diverge: %s" % (max(rows, key=lambda r: r[1]),)
+        assert max(r[1] for r in rows) < 1e-4, "raw conv outputs diverge: %s" % (max(rows, key=lambda r: r[1]),)
     err_out = np.abs(out.detach().cpu().numpy() - o_ref.detach().numpy()).max()
     print("out err", err_out)
     assert err_out < 1e-4
+    w = torch.linspace(-1, 1, o_ref.numel()).view_as(o_ref)
     if head is None:
         from ocl_amd.loss import cross_entropy_mean
+        loss_ref = torch.nn.functional.cross_entropy(o_ref, torch.from_numpy(y))
         loss = cross_entropy_mean(out, torch.from_numpy(y).to(cuda))
     else:
+        loss_ref = (o_ref * w).sum()
         loss = (out * w.to(cuda)).sum()
     assert abs(float(loss) - float(loss_ref.detach())) < 1e-4 * max(1.0, abs(float(loss_ref.detach())))
+    loss_ref.backward()
     loss.backward()
     torch.cuda.synchronize()
-    names = [k for k, _ in m.named_parameters()]
     worst, rows = 0.0, []
     for k, p in m.named_parameters():
         gref = st[k].grad
@@ -117,7 +155,7 @@ def test_train_forward_backward_vs_oracle(cuda, agent, data, head, n, groups):
         rows.append((k, e, float(gref.abs().max())))
         worst = max(worst, e)
     print("\n".join("%-44s rel %.3e  max|g| %.3e" % r for r in rows))
-    assert worst < 1e-3, max(rows, key=lambda r: r[1])
+    assert worst < 2e-4, max(rows, key=lambda r: r[1])
     # BatchNorm running statistics (momentum 0.1, unbiased variance, one update per forward call / group)
     sd_new = m.state_dict()
     for k in sd_new:
@@ -148,18 +186,18 @@ def test_gradient_accumulation_and_zero_grad_semantics(cuda):
     cross_entropy_mean(m.forward(torch.from_numpy(xa).to(cuda)), torch.from_numpy(ya).to(cuda)).backward()
     cross_entropy_mean(m.forward(torch.from_numpy(xb).to(cuda)), torch.from_numpy(yb).to(cuda)).backward()
     g = m.flat_grads().cpu().numpy()
-    assert np.abs(g - gref).max() < 1e-3 * np.abs(gref).max()
+    assert np.linalg.norm(g - gref) < 5e-2 * np.linalg.norm(gref)   # loose: ReLU sign flips at ~0 (see the teacher-forced test)
     O.sgd_step(st, names, 0.1)
     opt.step()
     pref = torch.cat([st[k].detach().reshape(-1) for k in names]).numpy()
-    assert np.abs(m.flat_params().cpu().numpy() - pref).max() < 1e-4 * np.abs(pref).max()
+    assert np.abs(m.flat_params().cpu().numpy() - pref).max() < 5e-3 * np.abs(pref).max()
     # zero_grad then ONE backward overwrites
     O.zero_grad(st, names)
     O.ce_mean(O.OracleNet(st, training=True).forward(torch.from_numpy(xa)), torch.from_numpy(ya)).backward()
     opt.zero_grad()
     cross_entropy_mean(m.forward(torch.from_numpy(xa).to(cuda)), torch.from_numpy(ya).to(cuda)).backward()
     g1 = O.flat_grad(st, names).numpy()
-    assert np.abs(m.flat_grads().cpu().numpy() - g1).max() < 2e-3 * np.abs(g1).max()
+    assert np.linalg.norm(m.flat_grads().cpu().numpy() - g1) < 5e-2 * np.linalg.norm(g1)
     # p.grad views alias the flat gradient (get_grad_vector layout)
     off = 0
     for p in m.parameters():
@@ -244,7 +282,7 @@ def test_resnet_matches_reference_golden(cuda):
         for k in g[name + "_picked"]:
             gg = g[name + "_g_" + str(k)]
             got = named[str(k)].grad.cpu().numpy()
-            assert np.abs(got - gg).max() <= 1e-3 * (1e-12 + np.abs(gg).max()), (name, k)
+            assert np.linalg.norm(got - gg) <= 5e-2 * np.linalg.norm(gg), (name, k)   # loose: ReLU flips; tight check is teacher-forced above
         m.eval()
         with torch.no_grad():
             fe = m.features(x).cpu().numpy()
