@@ -3,8 +3,11 @@
 // PyTorch OIHW master copy.  Everything is exact fp32 (v_mfma_f32_16x16x4_f32).
 #pragma once
 #include "common.h"
+#include <vector>
 
 namespace ocl {
+
+constexpr int kStatReps = 8;   // replicas of the BatchNorm statistic accumulators (atomics contention)
 
 enum ConvEpi : int {
     EPI_STORE = 0,       // out = acc
@@ -18,25 +21,32 @@ enum ConvEpi : int {
 
 struct ConvArgs {
     const float* in;
-    const float* w;       // packed [tap][Cin][CoutP]
+    const float* w;       // packed [tap][Cin][WP]
     float* out;
     const float* scale;
     const float* shift;
     const float* res;
     const float* resmask;
-    double* stats;        // [groups][2][Cout]
+    double* stats;        // [kStatReps][groups][2][Cout], replica stride stat_rep_stride doubles
+    int64_t stat_rep_stride;
     int N, Hin, Win, Cin;
     int Hout, Wout, Cout;
-    int CoutP;
+    int CoutP;                  // n_splits * 16*NT (columns the grid covers)
+    int WP;                     // row stride of the weight pack (multiple of 16, >= Cout)
     int LH, LW, os, oy0, ox0;   // output lattice: (oy,ox) = (ly*os+oy0, lx*os+ox0)
     int is;                     // input step per lattice step
     int ntaps;
     int tdy[9], tdx[9], tw[9];  // input offset of each tap and its index in the weight pack
+    int tpo[9];                 // LDS patch offset of each tap (floats)
+    int d_c4, d_pc, d_row;      // patch-staging walk: 256 units = d_row rows + d_pc pixels + d_c4 float4s
+    float inv_PR;
     int min_dy, min_dx, max_dy, max_dx;
     int KC, CP, PC, PR;         // channels per LDS chunk, LDS pixel stride, patch cols, patch rows
     int ppi, imgs, tiles_per_img;
-    int group_size, tiles_per_group;
+    int groups, group_size, tiles_per_group;
     int BNP;                    // LDS weight row stride (floats)
+    int KU;                     // k-steps issued per unrolled group (5 when KC/4 is a multiple of 5)
+    int TG, gpc, WS;            // taps per weight stage, stages per channel chunk, floats per stage buffer
     int flags;
     int n_splits;               // grid.y
 };
@@ -56,9 +66,22 @@ struct ConvGeomDesc {
     int LH, LW, os, oy0, ox0, is;
     int ntaps;
     int tdy[9], tdx[9], tw[9];
+    int WP;                     // weight pack row stride (0: the plan's own CoutP)
+    int force_MT, force_NT, force_bpc;   // 0 = planner's choice (benchmarks / tests)
 };
 
 int plan_conv(const ConvGeomDesc& g, ConvPlan* p);
+
+// One convolution layer of the network (models/resnet.py:10-12,25-30): shapes and weight-pack row strides.
+struct ConvShape {
+    int Cin, CinT, Cout, k, stride, Hin, Win, Ho, Wo;  // CinT: channels of the NHWC input tensor (stem: 3 -> 4)
+    int CoutP, CiP;                                    // row strides of the forward / data-gradient weight packs
+};
+int pack_width(int channels);   // row stride of a weight pack with `channels` columns (multiple of 16)
+// forward geometry; data-gradient geometry ("input" = dy, "output" = dx): one launch for stride 1 and for the 1x1
+// stride-2 shortcut, four dense parity classes of the dx lattice for 3x3 stride 2.
+void geom_fwd(const ConvShape& c, int N, int groups, ConvGeomDesc* g);
+void geom_dgrad(const ConvShape& c, int N, std::vector<ConvGeomDesc>* out);
 int launch_conv(const ConvPlan& p, hipStream_t s);
 
 // ---- wgrad -------------------------------------------------------------------------------------------
@@ -111,7 +134,8 @@ struct BnFwdArgs {
     const float* y;       // raw conv output [M,C]
     float* z;             // output
     const float* res;     // optional residual (already normalised), same shape
-    const double* stats;  // [G][2][C]
+    const double* stats;  // [kStatReps][G][2][C] (replica stride stat_rep_stride doubles), summed here
+    int64_t stat_rep_stride;
     const float* gamma;
     const float* beta;
     float* running_mean;  // may be null (no update)

@@ -14,6 +14,8 @@
 #include "conv.h"
 #include <string.h>
 #include <algorithm>
+#include <type_traits>
+#include <cmath>
 
 namespace ocl {
 
@@ -23,186 +25,449 @@ static const size_t kLdsTarget = 72 * 1024;      // planner target (2 workgroups
 // =====================================================================================================
 // implicit-GEMM convolution
 // =====================================================================================================
-template <int MT, int NT>
+// Block = 4 waves stacked along M (64*MT output pixels) x 16*NT output channels.  K runs over (channel chunk, tap).
+// The input patch of a chunk is staged once and shared by all taps; weights stream through a DOUBLE-BUFFERED LDS
+// stage of TG taps: the global loads of stage s+1 are issued before the MFMAs of stage s and land in registers
+// while they run, so the only exposed global latency is the first stage's (one __syncthreads per stage).
+// LDS banking (ds_read_b32: 32 banks, two 32-lane halves): A reads want CP = 2 (mod 4), B reads BNP = 16 (mod 32).
+// exact u / d for 0 <= u < 2^22 with a precomputed float reciprocal (one correction step either way)
+__device__ __forceinline__ int fdiv(int u, int d, float inv, int& rem) {
+    int q = (int)((float)u * inv);
+    int r = u - q * d;
+    if (r < 0) { --q; r += d; }
+    else if (r >= d) { ++q; r -= d; }
+    rem = r;
+    return q;
+}
+
+constexpr int kMaxStageFloats = 4096;   // 16 KiB per weight stage buffer -> <= 4 float4 prefetch registers per thread
+
+// value of a small per-tap table at a block-uniform index, without dynamic indexing of the kernel-argument struct
+// (which would spill it to scratch): a 9-way select chain on scalars.
+__device__ __forceinline__ int tap_sel(const int (&tab)[9], int t) {
+    int v = tab[0];
+#pragma unroll
+    for (int i = 1; i < 9; ++i) v = (t == i) ? tab[i] : v;
+    return v;
+}
+
+// Persistent implicit-GEMM block: walks output tiles blockIdx.x, blockIdx.x + gridDim.x, ... of its channel split.
+// Software pipeline (all global latency except the very first patch hidden behind MFMAs):
+//   patch stage  = (tile, channel chunk): the input patch is fetched into REGISTERS one patch stage ahead and written
+//                  to LDS after the consumers of the previous patch have passed a barrier;
+//   weight stage = TG taps of a chunk: double-buffered in LDS, fetched into registers one weight stage ahead.
+constexpr int kPatchPF = 8;     // max float4 patch-prefetch registers per thread (planner: patch units <= 256*kPatchPF)
+
+struct TileGeom {
+    int grp, img0, p0, ly0, nrows, grp_end;
+};
+
+template <int MT, int NT, int PF>   // PF: float4 patch-prefetch registers per thread (patch units <= 256*PF)
 __global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     constexpr int BM = 64 * MT;
     constexpr int BN = 16 * NT;
-    double* red = (double*)lds_raw;                 // [4 waves][2][BN]
-    int* rowoff = (int*)(red + 8 * BN);             // [BM]
-    float* wl = (float*)(rowoff + BM);              // [KC][BNP]
-    float* patch = wl + ((a.KC * a.BNP + 3) & ~3);  // [imgs][PR][PC][CP]
+    constexpr int Q = BN / 4;                       // float4 per weight row
+    constexpr int CS = BN + 4;                      // row stride of the epilogue tile: 4*CS = 16 (mod 32) -> conflict-free
+    int* tapw = (int*)lds_raw;                      // [16] weight-pack index of each tap
+    int* rowoff = tapw + 16;                        // [BM]
+    float* wl = (float*)(rowoff + BM);              // [2][WS] weight stages
+    float* patch = wl + 2 * a.WS;                   // [imgs][PR][PC][CP]
+    float* ct = wl;                                 // epilogue alias: output tile [BM][CS] (+ fp64 stat scratch)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.y * BN;
-
-    // ---- tile decode ------------------------------------------------------------------------------
-    const int tile = blockIdx.x;
-    const int grp = tile / a.tiles_per_group;
-    const int tg = tile - grp * a.tiles_per_group;
-    const int ti = tg / a.tiles_per_img;
-    const int img0 = grp * a.group_size + ti * a.imgs;
-    const int p0 = (tg - ti * a.tiles_per_img) * a.ppi;
-    const int grp_end = min(a.N, (grp + 1) * a.group_size);
     const int LP = a.LH * a.LW;
-    const int ly0 = p0 / a.LW;
-    const int pend = min(p0 + a.ppi, LP);
-    const int ly1 = (pend - 1) / a.LW;
-    const int pr_use = (ly1 - ly0) * a.is + (a.max_dy - a.min_dy) + 1;
+    const int ntiles = a.groups * a.tiles_per_group;
+    if ((int)blockIdx.x >= ntiles) return;
+    if (tid < 9) tapw[tid] = tap_sel(a.tw, tid);
+    __syncthreads();
 
-    // per-row decode: LDS patch offset of the pixel's origin and output element offset
-    auto decode = [&](int r, int& poff, int& ooff) -> bool {
-        const int il = r / a.ppi;
-        const int pl = r - il * a.ppi;
-        const int p = p0 + pl;
-        const int n = img0 + il;
-        const bool v = (il < a.imgs) && (n < grp_end) && (p < LP);
-        const int ly = p / a.LW, lx = p - ly * a.LW;
-        poff = v ? ((il * a.PR + (ly - ly0) * a.is) * a.PC + lx * a.is) * a.CP : 0;
-        ooff = ((n * a.Hout + ly * a.os + a.oy0) * a.Wout + lx * a.os + a.ox0) * a.Cout;
-        return v;
+    auto geom = [&](int tile) __attribute__((always_inline)) -> TileGeom {
+        TileGeom t;
+        t.grp = tile / a.tiles_per_group;
+        const int tg_ = tile - t.grp * a.tiles_per_group;
+        const int ti = tg_ / a.tiles_per_img;
+        t.img0 = t.grp * a.group_size + ti * a.imgs;
+        t.p0 = (tg_ - ti * a.tiles_per_img) * a.ppi;
+        t.grp_end = min(a.N, (t.grp + 1) * a.group_size);
+        t.ly0 = t.p0 / a.LW;
+        const int pend = min(t.p0 + a.ppi, LP);
+        const int ly1 = (pend - 1) / a.LW;
+        // patch rows to stage: one image's used rows, or (imgs > 1: whole images of PR rows) the images inside the group
+        t.nrows = a.imgs > 1 ? min(a.imgs, t.grp_end - t.img0) * a.PR : (ly1 - t.ly0) * a.is + (a.max_dy - a.min_dy) + 1;
+        return t;
     };
-    if (tid < BM) {
-        int po, oo;
-        const bool v = decode(tid, po, oo);
-        rowoff[tid] = v ? oo : -1;
-    }
-    int abase[MT];
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        int po, oo;
-        decode(wave * 16 * MT + mt * 16 + r16, po, oo);
-        abase[mt] = po + g;
-    }
-    const int bbase = g * a.BNP + r16;
 
-    f32x4 acc[MT][NT];
+    // ---- weight-stage prefetch bookkeeping: unit u = tid + q*256 -> (tap-in-group, kc, float4 column) -------------
+    const int rows_full = a.TG * a.KC;              // weight rows of a full stage
+    int pf_tg[4], pf_src[4], pf_dst[4];
+    {
+        const float inv_q = 1.0f / (float)Q, inv_kc = 1.0f / (float)a.KC;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < 4; ++q) {
+            const int u = tid + q * 256;
+            int q4, kc;
+            const int row = fdiv(u, Q, inv_q, q4);
+            const int tgi = fdiv(row, a.KC, inv_kc, kc);
+            pf_tg[q] = (row < rows_full && n0 + q4 * 4 < a.WP) ? tgi : -1;   // columns past the pack's row stride: never stored
+            pf_src[q] = kc * a.WP + q4 * 4;
+            pf_dst[q] = row * a.BNP + q4 * 4;
+        }
+    }
+    // The four prefetch registers are named variables (not an array): with the nested select chain the array form is
+    // left in scratch memory by the compiler, which serialises every load behind an s_waitcnt.
+    float4 pf0, pf1, pf2, pf3;
+#define OCL_PF_LOAD(Q, REG)                                                                               \
+    {                                                                                                     \
+        const int t = t0_ + pf_tg[Q];                                                                     \
+        const bool ok = pf_tg[Q] >= 0 && t < a.ntaps;                                                     \
+        const int wt = tapw[ok ? t : 0];                                                                  \
+        const float* p = ok ? a.w + ((int64_t)wt * a.Cin + c0_) * a.WP + n0 + pf_src[Q] : a.w;           \
+        REG = *(const float4*)p; /* unconditional (clamped address): no exec-mask branch around the load */ \
+    }
+#define OCL_PF_STORE(Q, REG)                                                           \
+    {                                                                                  \
+        const int t = t0_ + pf_tg[Q];                                                  \
+        if (pf_tg[Q] >= 0 && t < a.ntaps) *(float4*)(dst_ + pf_dst[Q]) = REG;          \
+    }
+    auto prefetch = [&](int t0_, int c0_) __attribute__((always_inline)) {
+        OCL_PF_LOAD(0, pf0) OCL_PF_LOAD(1, pf1) OCL_PF_LOAD(2, pf2) OCL_PF_LOAD(3, pf3)
+    };
+    auto commit = [&](int t0_, int buf) __attribute__((always_inline)) {
+        float* dst_ = wl + buf * a.WS;
+        OCL_PF_STORE(0, pf0) OCL_PF_STORE(1, pf1) OCL_PF_STORE(2, pf2) OCL_PF_STORE(3, pf3)
+    };
+#undef OCL_PF_LOAD
+#undef OCL_PF_STORE
 
+    // ---- patch prefetch bookkeeping: this thread's units tid + i*256 of the flat [row][pc][c4] space are the same for
+    // every tile; their (il, pr, pc, c4) coordinates are packed into one register each.
     const int kc4 = a.KC >> 2;
-    for (int c0 = 0; c0 < a.Cin; c0 += a.KC) {
-        __syncthreads();  // previous chunk fully consumed (also publishes rowoff on the first trip)
-        // ---- stage the input patch for channels [c0, c0+KC) -----------------------------------------
-        const int units = a.imgs * pr_use * a.PC * kc4;
-        for (int u = tid; u < units; u += 256) {
-            const int c4 = u % kc4;
-            const int t1 = u / kc4;
-            const int pc = t1 % a.PC;
-            const int t2 = t1 / a.PC;
-            const int pr = t2 % pr_use;
-            const int il = t2 / pr_use;
-            const int iy = ly0 * a.is + a.min_dy + pr;
-            const int ix = a.min_dx + pc;
-            const int n = img0 + il;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n < grp_end && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win)
-                v = *(const float4*)(a.in + ((int64_t)(n * a.Hin + iy) * a.Win + ix) * a.Cin + c0 + c4 * 4);
-            float* d = patch + ((il * a.PR + pr) * a.PC + pc) * a.CP + c4 * 4;  // 8-B aligned (CP even)
-            *(float2*)d = make_float2(v.x, v.y);
-            *(float2*)(d + 2) = make_float2(v.z, v.w);
-        }
-        for (int t = 0; t < a.ntaps; ++t) {
-            if (t > 0) __syncthreads();  // previous tap's weight tile consumed
-            // ---- stage W[tap][c0:c0+KC][n0:n0+BN] ---------------------------------------------------
-            const float* wsrc = a.w + ((int64_t)a.tw[t] * a.Cin + c0) * a.CoutP + n0;
-            constexpr int Q = BN / 4;
-            for (int u = tid; u < a.KC * Q; u += 256) {
-                const int kc = u / Q, q = u - kc * Q;
-                *(float4*)(wl + kc * a.BNP + q * 4) = *(const float4*)(wsrc + (int64_t)kc * a.CoutP + q * 4);
-            }
-            __syncthreads();
-            const float* pa = patch + ((a.tdy[t] - a.min_dy) * a.PC + (a.tdx[t] - a.min_dx)) * a.CP;
-            const float* pb = wl + bbase;
-            for (int s = 0; s < a.KC; s += 4) {
-                float av[MT], bv[NT];
+    int pu_pos[PF];   // il << 24 | pr << 16 | pc << 8 | c4   (planner: il < 128, pr/pc < 256, c4 < 256)
+    {
+        int c4, pc;
+        const int pix = fdiv(tid, kc4, 1.0f / (float)kc4, c4);
+        int row = fdiv(pix, a.PC, 1.0f / (float)a.PC, pc);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) av[mt] = pa[abase[mt] + s];
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bv[nt] = pb[s * a.BNP + nt * 16];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
-            }
+        for (int i = 0; i < PF; ++i) {
+            int il = 0, pr = row;
+            if (a.imgs > 1) il = fdiv(row, a.PR, a.inv_PR, pr);
+            pu_pos[i] = (il << 24) | (pr << 16) | (pc << 8) | c4;
+            if (il >= 128 || pr >= 256) pu_pos[i] = 0x7fff0000;   // past any tile's last row
+            c4 += a.d_c4;                                   // advance by 256 units
+            pc += a.d_pc;
+            if (c4 >= kc4) { c4 -= kc4; pc += 1; }
+            row += a.d_row;
+            if (pc >= a.PC) { pc -= a.PC; row += 1; }
         }
     }
+    float4 pv[PF];
+    auto load_patch = [&](const TileGeom& t, int c0) __attribute__((always_inline)) {
+        const int iy0 = t.ly0 * a.is + a.min_dy;
+        const float* base = a.in + ((int64_t)(t.img0 * a.Hin + iy0) * a.Win + a.min_dx) * a.Cin + c0;
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int il = pu_pos[i] >> 24, pr = (pu_pos[i] >> 16) & 255, pc = (pu_pos[i] >> 8) & 255, c4 = pu_pos[i] & 255;
+            const int iy = iy0 + pr, ix = a.min_dx + pc;
+            const bool ok = il * a.PR + pr < t.nrows && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+            const float* p = ok ? base + ((il * a.Hin + pr) * a.Win + pc) * a.Cin + c4 * 4 : a.in;   // unconditional load
+            const float4 v = *(const float4*)p;
+            pv[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_patch = [&](const TileGeom& t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int il = pu_pos[i] >> 24, pr = (pu_pos[i] >> 16) & 255, pc = (pu_pos[i] >> 8) & 255, c4 = pu_pos[i] & 255;
+            const int row = il * a.PR + pr;
+            if (row < t.nrows) {
+                float* d = patch + (row * a.PC + pc) * a.CP + c4 * 4;  // 8-B aligned (CP even)
+                *(float2*)d = make_float2(pv[i].x, pv[i].y);
+                *(float2*)(d + 2) = make_float2(pv[i].z, pv[i].w);
+            }
+        }
+    };
 
-    // ---- epilogue: D layout col = lane&15, row = (lane>>4)*4 + reg -----------------------------------
+    const float inv_ppi = 1.0f / (float)a.ppi, inv_lw = 1.0f / (float)a.LW;
+    const int bbase = g * a.BNP + r16;
+    const int nchunks = a.Cin / a.KC;
     const int flags = a.flags;
-    double s1[NT], s2[NT];
+    double run1 = 0.0, run2 = 0.0;   // threads < BN: running BatchNorm sums of channel n0+tid over this block's tiles
+    int run_grp = -1;
+    auto flush_stats = [&]() __attribute__((always_inline)) {
+        if (tid < BN && run_grp >= 0) {
+            const int co = n0 + tid;
+            if (co < a.Cout) {
+                // kStatReps replicas of the accumulators spread the same-address atomics (they serialise at the L2)
+                double* st_ = a.stats + (int64_t)(blockIdx.x % kStatReps) * a.stat_rep_stride;
+                atomicAdd(&st_[((int64_t)run_grp * 2 + 0) * a.Cout + co], run1);
+                atomicAdd(&st_[((int64_t)run_grp * 2 + 1) * a.Cout + co], run2);
+            }
+        }
+        run1 = run2 = 0.0;
+    };
+
+    int st = 0;
+    TileGeom cur = geom(blockIdx.x);
+    load_patch(cur, 0);
+    prefetch(0, 0);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int next_tile = tile + gridDim.x;
+        TileGeom nxt = cur;
+        if (next_tile < ntiles) nxt = geom(next_tile);
+
+        // per-row decode: LDS patch offset of the pixel's origin and output element offset
+        auto decode = [&](int r, int& poff, int& ooff) __attribute__((always_inline)) -> bool {
+            int pl, lx;
+            const int il = fdiv(r, a.ppi, inv_ppi, pl);
+            const int p = cur.p0 + pl;
+            const int n = cur.img0 + il;
+            const bool v = (il < a.imgs) && (n < cur.grp_end) && (p < LP);
+            const int ly = fdiv(p, a.LW, inv_lw, lx);
+            poff = v ? ((il * a.PR + (ly - cur.ly0) * a.is) * a.PC + lx * a.is) * a.CP : 0;
+            ooff = ((n * a.Hout + ly * a.os + a.oy0) * a.Wout + lx * a.os + a.ox0) * a.Cout;
+            return v;
+        };
+        int abase[MT];
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) s1[nt] = s2[nt] = 0.0;
+        for (int mt = 0; mt < MT; ++mt) {
+            int po, oo;
+            decode(wave * 16 * MT + mt * 16 + r16, po, oo);
+            abase[mt] = po + g;
+        }
+        f32x4 acc[MT][NT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+        for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg) {
-            const int off = rowoff[wave * 16 * MT + mt * 16 + g * 4 + reg];
-            if (off < 0) continue;
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            const int c0 = chunk * a.KC;
+            __syncthreads();  // consumers of the previous patch / of the previous tile's epilogue tile are done
+            if (chunk == 0 && tid < BM) {
+                int po, oo;
+                const bool v = decode(tid, po, oo);
+                rowoff[tid] = v ? oo : -1;
+            }
+            store_patch(cur);
+            // next patch stage: next chunk of this tile, or the first chunk of this block's next tile
+            if (chunk + 1 < nchunks) load_patch(cur, c0 + a.KC);
+            else if (next_tile < ntiles) load_patch(nxt, 0);
+            auto mfma_taps = [&](const float* wbase, int t0, int tcnt) __attribute__((always_inline)) {
+                for (int tt = 0; tt < tcnt; ++tt) {
+                    const float* pa = patch + tap_sel(a.tpo, t0 + tt);
+                    const float* pb = wbase + tt * a.KC * a.BNP;
+                    auto ksteps = [&](int s, auto UC) __attribute__((always_inline)) {
+                        constexpr int U = decltype(UC)::value;
+                        float av[U][MT], bv[U][NT];
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt) av[u][mt] = pa[abase[mt] + s + 4 * u];
+#pragma unroll
+                            for (int nt = 0; nt < NT; ++nt) bv[u][nt] = pb[(s + 4 * u) * a.BNP + nt * 16];
+                        }
+#pragma unroll
+                        for (int u = 0; u < U; ++u)
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt)
+                                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][mt], bv[u][nt], acc[mt][nt], 0, 0, 0);
+                    };
+                    if (a.KU == 5) {
+                        for (int s = 0; s < a.KC; s += 20) ksteps(s, std::integral_constant<int, 5>());
+                    } else {
+                        for (int s = 0; s < a.KC; s += 4) ksteps(s, std::integral_constant<int, 1>());
+                    }
+                }
+            };
+            for (int t0 = 0; t0 < a.ntaps; t0 += a.TG, ++st) {
+                commit(t0, st & 1);
+                __syncthreads();      // stage st's weights (and the patch) visible; everyone is done with stage st-1
+                {   // prefetch the next weight stage (next tap group, next chunk, or the next tile's first)
+                    int nt0 = t0 + a.TG, nc0 = c0;
+                    if (nt0 >= a.ntaps) { nt0 = 0; nc0 = c0 + a.KC; }
+                    if (nc0 >= a.Cin) nc0 = next_tile < ntiles ? 0 : -1;
+                    if (nc0 >= 0) prefetch(nt0, nc0);
+                }
+                mfma_taps(wl + (st & 1) * a.WS + bbase, t0, min(a.TG, a.ntaps - t0));
+            }
+        }
+
+        // ---- epilogue ---------------------------------------------------------------------------------------------------
+        // D layout: col = lane&15, row = (lane>>4)*4 + reg.  BatchNorm statistics from the registers (fp32 partials over
+        // a lane's <= 16 rows, fp64 from there on), then the tile goes through LDS so that global traffic is 16-B
+        // vectors along the channel axis, with the affine / residual / ReLU epilogues applied in that pass.
+        __syncthreads();  // weight stages and patch are dead: `ct` aliases them
+        float s1[NT], s2[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) s1[nt] = s2[nt] = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int reg = 0; reg < 4; ++reg) {
+                const int row = wave * 16 * MT + mt * 16 + g * 4 + reg;
+                const bool valid = rowoff[row] >= 0;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float v = acc[mt][nt][reg];
+                    ct[row * CS + nt * 16 + r16] = v;
+                    if (valid) {
+                        s1[nt] += v;
+                        s2[nt] = fmaf(v, v, s2[nt]);
+                    }
+                }
+            }
+        if (flags & EPI_STATS) {
+            double* red = (double*)(ct + BM * CS);   // [4 waves][2][BN] doubles, after the tile
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const int co = n0 + nt * 16 + r16;
-                float v = acc[mt][nt][reg];
-                if (flags & EPI_STATS) {
-                    s1[nt] += (double)v;
-                    s2[nt] += (double)v * (double)v;
+                double x = (double)s1[nt], y = (double)s2[nt];
+                x += __shfl_xor(x, 16, 64);
+                x += __shfl_xor(x, 32, 64);
+                y += __shfl_xor(y, 16, 64);
+                y += __shfl_xor(y, 32, 64);
+                if (g == 0) {
+                    red[(wave * 2 + 0) * BN + nt * 16 + r16] = x;
+                    red[(wave * 2 + 1) * BN + nt * 16 + r16] = y;
                 }
-                if (co < a.Cout) {
-                    const int64_t o = (int64_t)off + co;
-                    if (flags & EPI_AFFINE) v = fmaf(v, a.scale[co], a.shift[co]);
-                    if (flags & EPI_RES) v += a.res[o];
-                    if (flags & EPI_RESMASK) v += (a.resmask[o] > 0.f) ? a.res[o] : 0.f;
-                    if (flags & EPI_ACCUM) v += a.out[o];
-                    if (flags & EPI_RELU) v = fmaxf(v, 0.f);
-                    a.out[o] = v;
-                }
-            }
-        }
-    }
-    if (flags & EPI_STATS) {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            double x = s1[nt], y = s2[nt];
-            x += __shfl_xor(x, 16, 64);
-            x += __shfl_xor(x, 32, 64);
-            y += __shfl_xor(y, 16, 64);
-            y += __shfl_xor(y, 32, 64);
-            if (g == 0) {
-                red[(wave * 2 + 0) * BN + nt * 16 + r16] = x;
-                red[(wave * 2 + 1) * BN + nt * 16 + r16] = y;
             }
         }
         __syncthreads();
-        if (tid < BN) {
-            const int co = n0 + tid;
-            if (co < a.Cout) {
-                const double t1 = red[0 * BN + tid] + red[2 * BN + tid] + red[4 * BN + tid] + red[6 * BN + tid];
-                const double t2 = red[1 * BN + tid] + red[3 * BN + tid] + red[5 * BN + tid] + red[7 * BN + tid];
-                atomicAdd(&a.stats[((int64_t)grp * 2 + 0) * a.Cout + co], t1);
-                atomicAdd(&a.stats[((int64_t)grp * 2 + 1) * a.Cout + co], t2);
+        if (flags & EPI_STATS) {
+            if (cur.grp != run_grp) {   // block-uniform: a block's tiles are visited in ascending group order
+                flush_stats();
+                run_grp = cur.grp;
+            }
+            if (tid < BN) {
+                const double* red = (const double*)(ct + BM * CS);
+                run1 += red[0 * BN + tid] + red[2 * BN + tid] + red[4 * BN + tid] + red[6 * BN + tid];
+                run2 += red[1 * BN + tid] + red[3 * BN + tid] + red[5 * BN + tid] + red[7 * BN + tid];
             }
         }
+        // vectorised store pass: unit = (row, float4 column)
+        const int ncol4 = min(BN, a.Cout - n0) >> 2;     // valid float4 columns of this block (Cout % 4 == 0)
+        if (ncol4 > 0) {
+            const float inv_nc = 1.0f / (float)ncol4;
+            const int units = BM * ncol4;
+            for (int u = tid; u < units; u += 256) {
+                int c4;
+                const int row = fdiv(u, ncol4, inv_nc, c4);
+                const int off = rowoff[row];
+                if (off < 0) continue;
+                const int co = n0 + c4 * 4;
+                float4 v = *(const float4*)(ct + row * CS + c4 * 4);
+                float* op = a.out + (int64_t)off + co;
+                if (flags & EPI_AFFINE) {
+                    const float4 sc = *(const float4*)(a.scale + co), sh = *(const float4*)(a.shift + co);
+                    v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+                }
+                if (flags & EPI_RES) {
+                    const float4 r = *(const float4*)(a.res + (int64_t)off + co);
+                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                }
+                if (flags & EPI_RESMASK) {
+                    const float4 r = *(const float4*)(a.res + (int64_t)off + co);
+                    const float4 m = *(const float4*)(a.resmask + (int64_t)off + co);
+                    v.x += m.x > 0.f ? r.x : 0.f; v.y += m.y > 0.f ? r.y : 0.f; v.z += m.z > 0.f ? r.z : 0.f; v.w += m.w > 0.f ? r.w : 0.f;
+                }
+                if (flags & EPI_ACCUM) {
+                    const float4 o = *(const float4*)op;
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                }
+                if (flags & EPI_RELU) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+                *(float4*)op = v;
+            }
+        }
+        cur = nxt;
     }
+    if (flags & EPI_STATS) flush_stats();
 }
 
 typedef void (*conv_fn_t)(const ConvArgs);
-static conv_fn_t conv_fn(int MT, int NT) {
-#define OCL_CASE(M, N) \
-    if (MT == M && NT == N) return conv_gemm_kernel<M, N>;
-    OCL_CASE(1, 1) OCL_CASE(1, 2) OCL_CASE(1, 3) OCL_CASE(1, 4) OCL_CASE(1, 5)
-    OCL_CASE(2, 1) OCL_CASE(2, 2) OCL_CASE(2, 3) OCL_CASE(2, 4) OCL_CASE(2, 5)
+// instantiated tilings (chosen from the kbench sweeps, profiles/): (MT, NT) x patch-prefetch depth {4, 8}
+#define OCL_CONV_TILINGS(X) X(1, 1) X(1, 2) X(1, 3) X(1, 5) X(2, 1) X(2, 2) X(2, 3) X(4, 2)
+static conv_fn_t conv_fn(int MT, int NT, int PF) {
+#define OCL_CASE(M, N)                                                  \
+    if (MT == M && NT == N) {                                           \
+        if (PF == 4) return conv_gemm_kernel<M, N, 4>;                  \
+        if (PF == 6) return conv_gemm_kernel<M, N, 6>;                  \
+        if (PF == 8) return conv_gemm_kernel<M, N, 8>;                  \
+    }
+    OCL_CONV_TILINGS(OCL_CASE)
 #undef OCL_CASE
     return nullptr;
 }
+static int conv_pf_for(int units) { return units <= 1024 ? 4 : units <= 1536 ? 6 : 8; }
 
 static int bnp_for(int bn) {  // LDS weight row stride with (stride mod 32) == 16: B reads conflict-free
     int p = bn;
     while ((p & 31) != 16) p += 16;
     return p;
+}
+
+// LDS bytes of a tile: row table + max(main loop: 2 weight stages + patch, epilogue: output tile + fp64 stat scratch)
+static size_t conv_lds_bytes(const ConvArgs& a, int BM, int NT) {
+    const size_t w_b = (size_t)2 * a.WS * 4;
+    const size_t main_b = w_b + (size_t)a.imgs * a.PR * a.PC * a.CP * 4;
+    const size_t epi_b = (size_t)BM * (16 * NT + 4) * 4 + (size_t)8 * 16 * NT * 8;
+    return (size_t)64 + (size_t)BM * 4 + std::max(main_b, epi_b);
+}
+
+// Fills the tile-dependent fields of `a` for a given (MT, NT); returns the LDS bytes (0 = does not fit).
+static size_t conv_tile_layout(const ConvGeomDesc& g, ConvArgs& a, int MT, int NT) {
+    const int ntiles16 = cdiv(g.Cout, 16);
+    const int splits = cdiv(ntiles16, NT);
+    a.n_splits = splits;
+    a.CoutP = splits * NT * 16;
+    a.BNP = bnp_for(NT * 16);
+    a.group_size = g.N / g.groups;
+    const int LP = g.LH * g.LW;
+    const int BM = 64 * MT;
+    if (LP >= BM) {
+        a.imgs = 1; a.ppi = BM; a.tiles_per_img = cdiv(LP, BM);
+    } else {
+        a.imgs = std::min(BM / LP, a.group_size); a.ppi = LP; a.tiles_per_img = 1;
+    }
+    a.PC = (g.LW - 1) * g.is + (a.max_dx - a.min_dx) + 1;
+    const int rows_l = (a.imgs == 1 && LP >= BM) ? std::min(g.LH, (BM + g.LW - 2) / g.LW + 1) : g.LH;
+    a.PR = (rows_l - 1) * g.is + (a.max_dy - a.min_dy) + 1;
+    // channel chunk: largest divisor of Cin (multiple of 4) whose patch + weight stages fit the LDS target
+    int KC = g.Cin;
+    size_t bytes = 0;
+    for (;;) {
+        a.KC = KC; a.CP = KC + 2;
+        int TG = std::max(1, std::min(g.ntaps, kMaxStageFloats / (KC * a.BNP)));
+        if (KC * a.BNP > kMaxStageFloats) TG = 0;   // a single tap does not fit one stage: shrink the chunk
+        if (TG > 0) {
+            a.TG = TG;
+            a.gpc = cdiv(g.ntaps, TG);
+            a.TG = cdiv(g.ntaps, a.gpc);            // balance the groups (9 taps: 5+4, 3x3, ...)
+            a.WS = (int)round_up(a.TG * KC * a.BNP, 4);
+            bytes = conv_lds_bytes(a, BM, NT);
+            if (bytes <= kLdsTarget && a.imgs * a.PR * a.PC * (KC / 4) <= 256 * kPatchPF) break;
+        }
+        // next smaller channel chunk: the largest divisor of Cin below KC that is a multiple of 4
+        int nk = 0;
+        for (int d = KC - 4; d >= 4; d -= 4)
+            if (g.Cin % d == 0) { nk = d; break; }
+        if (nk) KC = nk;
+        else if (TG > 0) break;
+        else return 0;
+    }
+    while ((bytes > kLdsLimit - 1024 || a.imgs * a.PR * a.PC * (a.KC / 4) > 256 * kPatchPF) && a.imgs > 1) {
+        a.imgs -= 1;   // shrink the tile (fewer images per block)
+        bytes = conv_lds_bytes(a, BM, NT);
+    }
+    if (bytes > kLdsLimit - 1024 || a.imgs * a.PR * a.PC * (a.KC / 4) > 256 * kPatchPF) return 0;
+    if (a.imgs > 127 || a.PR >= 256 || a.PC >= 256 || a.KC / 4 >= 256) return 0;   // packed (il, pr, pc, c4) prefetch bookkeeping
+    a.tiles_per_group = cdiv(a.group_size, a.imgs) * a.tiles_per_img;
+    return bytes;
 }
 
 int plan_conv(const ConvGeomDesc& g, ConvPlan* p) {
@@ -223,63 +488,133 @@ int plan_conv(const ConvGeomDesc& g, ConvPlan* p) {
         a.min_dy = std::min(a.min_dy, g.tdy[t]); a.max_dy = std::max(a.max_dy, g.tdy[t]);
         a.min_dx = std::min(a.min_dx, g.tdx[t]); a.max_dx = std::max(a.max_dx, g.tdx[t]);
     }
+    // ---- tile choice ---------------------------------------------------------------------------------------------
+    // Rule distilled from the kbench sweeps on MI355X (profiles/r1_kbench_conv_sweep.txt): 48 output channels per
+    // workgroup (NT = 3, or all of them when Cout <= 32), 128-pixel tiles (MT = 2) once there are >= 512 64-pixel
+    // tiles, else 64; persistent grid of two workgroups per CU (their barrier bubbles overlap).  Anything that does
+    // not fit the LDS / prefetch-register budget falls back to the nearest tiling that does.
     const int ntiles16 = cdiv(g.Cout, 16);
-    int NT = ntiles16 <= 5 ? ntiles16 : 5;
-    const int splits = cdiv(ntiles16, NT);
-    if (splits > 1) NT = cdiv(ntiles16, splits);  // balance (10 tiles -> 2 x 5)
-    a.n_splits = splits;
-    a.CoutP = splits * NT * 16;
-    a.BNP = bnp_for(NT * 16);
-    a.group_size = g.N / g.groups;
-    const int LP = g.LH * g.LW;
-    const int64_t tiles128 = (int64_t)g.groups * (LP >= 128 ? (int64_t)a.group_size * cdiv(LP, 128)
-                                                             : cdiv(a.group_size, std::max(1, 128 / LP)));
-    int MT = (tiles128 * splits >= 384) ? 2 : 1;
-    for (;; ) {
-        const int BM = 64 * MT;
-        if (LP >= BM) {
-            a.imgs = 1; a.ppi = BM; a.tiles_per_img = cdiv(LP, BM);
-        } else {
-            a.imgs = std::min(BM / LP, a.group_size); a.ppi = LP; a.tiles_per_img = 1;
-        }
-        a.tiles_per_group = cdiv(a.group_size, a.imgs) * a.tiles_per_img;
-        a.PC = (g.LW - 1) * g.is + (a.max_dx - a.min_dx) + 1;
-        int rows_l;
-        if (a.imgs == 1 && LP >= BM) rows_l = std::min(g.LH, (BM + g.LW - 2) / g.LW + 1);
-        else rows_l = g.LH;
-        a.PR = (rows_l - 1) * g.is + (a.max_dy - a.min_dy) + 1;
-        // channel chunk: largest divisor of Cin (multiple of 4) whose patch + weights fit the LDS target
-        int KC = g.Cin;
-        size_t bytes = 0;
-        for (;;) {
-            a.KC = KC; a.CP = KC + 2;
-            bytes = (size_t)8 * NT * 16 * 8 + (size_t)BM * 4 + (size_t)((KC * a.BNP + 3) & ~3) * 4 +
-                    (size_t)a.imgs * a.PR * a.PC * a.CP * 4;
-            if (bytes <= kLdsTarget) break;
-            if (KC % 8 == 0 && g.Cin % (KC / 2) == 0 && KC / 2 >= 4) KC /= 2; else break;
-        }
-        if (bytes > kLdsLimit - 1024 && a.imgs > 1) {  // shrink the tile (fewer images)
-            if (MT == 2) { MT = 1; continue; }
-            while (bytes > kLdsLimit - 1024 && a.imgs > 1) {
-                a.imgs -= 1;
-                a.tiles_per_group = cdiv(a.group_size, a.imgs) * a.tiles_per_img;
-                bytes = (size_t)8 * NT * 16 * 8 + (size_t)BM * 4 + (size_t)((a.KC * a.BNP + 3) & ~3) * 4 +
-                        (size_t)a.imgs * a.PR * a.PC * a.CP * 4;
+    int bestMT = 0, bestNT = 0, bestG = 0;
+    {
+        const int LPx = g.LH * g.LW;
+        const int64_t tiles64 = (int64_t)g.groups * (LPx >= 64 ? (int64_t)(g.N / g.groups) * cdiv(LPx, 64)
+                                                                : cdiv(g.N / g.groups, std::max(1, 64 / LPx)));
+        const int pref_nt = std::min(3, ntiles16), pref_mt = tiles64 >= 512 ? 2 : 1;
+        double best = 1e30;
+        const int MTs[3] = {1, 2, 4};
+        for (int mi = 0; mi < 3; ++mi)
+            for (int NT = 1; NT <= 5; ++NT) {
+                const int MT = MTs[mi];
+                if (g.force_MT && MT != g.force_MT) continue;
+                if (g.force_NT && NT != g.force_NT) continue;
+                if (!conv_fn(MT, NT, 8)) continue;
+                if (NT > ntiles16) continue;
+                ConvArgs t = a;
+                const size_t lds = conv_tile_layout(g, t, MT, NT);
+                if (!lds) continue;
+                // distance from the preferred tiling; shallow channel chunks (many patch stages) are penalised
+                const double cost = std::abs(NT - pref_nt) * 1.0 + std::abs(mi - (pref_mt == 2 ? 1 : 0)) * 1.5 +
+                                    (g.Cin / t.KC - 1) * 0.4 + (t.KC < std::min(20, g.Cin) ? 3.0 : 0.0);
+                if (cost < best) { best = cost; bestMT = MT; bestNT = NT; }
             }
+        if (bestMT) {
+            ConvArgs t = a;
+            const size_t lds = conv_tile_layout(g, t, bestMT, bestNT);
+            const int ntiles = g.groups * t.tiles_per_group;
+            int bpc = (int)std::min<size_t>(2, kLdsLimit / (lds + 512));
+            if (g.force_bpc) bpc = g.force_bpc;
+            bestG = std::max(1, std::min(ntiles, (256 * std::max(1, bpc)) / t.n_splits));
         }
-        OCL_REQUIRE(bytes <= kLdsLimit - 1024, "plan_conv: tile needs %zu B of LDS (Hin=%d Win=%d Cin=%d)", bytes, g.Hin, g.Win,
-                    g.Cin);
-        p->lds_bytes = bytes;
-        break;
     }
-    p->MT = MT; p->NT = NT;
-    p->grid_x = g.groups * a.tiles_per_group;
-    p->grid_y = splits;
+    OCL_REQUIRE(bestMT > 0, "plan_conv: no tile fits the LDS (Hin=%d Win=%d Cin=%d Cout=%d)", g.Hin, g.Win, g.Cin, g.Cout);
+    p->lds_bytes = conv_tile_layout(g, a, bestMT, bestNT);
+    a.WP = g.WP > 0 ? g.WP : a.CoutP;
+    a.KU = ((a.KC / 4) % 5 == 0) ? 5 : 1;
+    for (int t = 0; t < 9; ++t) a.tpo[t] = t < a.ntaps ? ((a.tdy[t] - a.min_dy) * a.PC + (a.tdx[t] - a.min_dx)) * a.CP : 0;
+    {   // patch staging walks its flat [row][pc][c4] unit space in steps of 256 units
+        const int kc4 = a.KC / 4;
+        a.d_c4 = 256 % kc4;
+        const int d_pix = 256 / kc4;
+        a.d_pc = d_pix % a.PC;
+        a.d_row = d_pix / a.PC;
+        a.inv_PR = 1.0f / (float)a.PR;
+    }
+    p->MT = bestMT; p->NT = bestNT;
+    a.groups = g.groups;
+    p->grid_x = bestG;
+    p->grid_y = a.n_splits;
     return OCL_OK;
 }
 
+int pack_width(int channels) { return (int)round_up(channels, 16); }
+
+void geom_fwd(const ConvShape& c, int N, int groups, ConvGeomDesc* g) {
+    memset(g, 0, sizeof(*g));
+    g->N = N; g->groups = groups;
+    g->Hin = c.Hin; g->Win = c.Win; g->Cin = c.CinT;
+    g->Hout = c.Ho; g->Wout = c.Wo; g->Cout = c.Cout;
+    g->LH = c.Ho; g->LW = c.Wo; g->os = 1; g->oy0 = 0; g->ox0 = 0; g->is = c.stride;
+    g->WP = c.CoutP;
+    const int pad = c.k == 3 ? 1 : 0;
+    g->ntaps = c.k * c.k;
+    for (int t = 0; t < g->ntaps; ++t) {
+        g->tdy[t] = t / c.k - pad;
+        g->tdx[t] = t % c.k - pad;
+        g->tw[t] = t;
+    }
+}
+
+void geom_dgrad(const ConvShape& c, int N, std::vector<ConvGeomDesc>* out) {
+    out->clear();
+    ConvGeomDesc g;
+    memset(&g, 0, sizeof(g));
+    g.N = N; g.groups = 1;
+    g.Hin = c.Ho; g.Win = c.Wo; g.Cin = c.Cout;
+    g.Hout = c.Hin; g.Wout = c.Win; g.Cout = c.Cin;
+    g.is = 1;
+    g.WP = c.CiP;
+    if (c.stride == 1) {
+        g.LH = c.Hin; g.LW = c.Win; g.os = 1;
+        const int pad = c.k == 3 ? 1 : 0;
+        g.ntaps = c.k * c.k;
+        for (int t = 0; t < g.ntaps; ++t) {
+            g.tdy[t] = pad - t / c.k;
+            g.tdx[t] = pad - t % c.k;
+            g.tw[t] = t;
+        }
+        out->push_back(g);
+    } else if (c.k == 1) {  // 1x1 stride 2, pad 0: only even pixels receive gradient
+        g.os = 2; g.oy0 = 0; g.ox0 = 0;
+        g.LH = (c.Hin + 1) / 2; g.LW = (c.Win + 1) / 2;
+        g.ntaps = 1;
+        g.tdy[0] = 0; g.tdx[0] = 0; g.tw[0] = 0;
+        out->push_back(g);
+    } else {  // 3x3 stride 2 pad 1: four dense parity classes of the dx lattice
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px) {
+                ConvGeomDesc q = g;
+                q.os = 2; q.oy0 = py; q.ox0 = px;
+                q.LH = (c.Hin - py + 1) / 2; q.LW = (c.Win - px + 1) / 2;
+                if (q.LH <= 0 || q.LW <= 0) continue;
+                int nt = 0;
+                for (int ky = 0; ky < 3; ++ky) {
+                    if (((py + 1 - ky) & 1) != 0) continue;
+                    for (int kx = 0; kx < 3; ++kx) {
+                        if (((px + 1 - kx) & 1) != 0) continue;
+                        q.tdy[nt] = (py + 1 - ky) / 2;  // exact: even numerator
+                        q.tdx[nt] = (px + 1 - kx) / 2;
+                        q.tw[nt] = ky * 3 + kx;
+                        ++nt;
+                    }
+                }
+                q.ntaps = nt;
+                out->push_back(q);
+            }
+    }
+}
+
 int launch_conv(const ConvPlan& p, hipStream_t s) {
-    conv_fn_t fn = conv_fn(p.MT, p.NT);
+    conv_fn_t fn = conv_fn(p.MT, p.NT, conv_pf_for(p.a.imgs * p.a.PR * p.a.PC * (p.a.KC / 4)));
     if (!fn) {
         set_error("launch_conv: no kernel for MT=%d NT=%d", p.MT, p.NT);
         return OCL_ERR_STATE;
@@ -328,6 +663,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
 
     const int kc4 = a.KC >> 2;
     constexpr int Q = BNW / 4;
+    const float inv_kc4 = 1.0f / (float)kc4, inv_pc = 1.0f / (float)a.PC, inv_ppi = 1.0f / (float)a.ppi, inv_wo = 1.0f / (float)a.Wo;
     for (int tile = blockIdx.x; tile < a.total_tiles; tile += a.S) {
         const int ti = tile / a.tiles_per_img;
         const int img0 = ti * a.imgs;
@@ -337,53 +673,92 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
         const int oy1 = (pend - 1) / a.Wo;
         const int pr_use = (oy1 - oy0) * a.stride + (a.max_dy - a.min_dy) + 1;
         __syncthreads();  // previous tile consumed
-        // pixel table + dy tile
-        for (int u = tid; u < a.KP * Q; u += 256) {
-            const int q = u / Q, c4 = u - q * Q;
-            const int il = q / a.ppi, pl = q - il * a.ppi;
-            const int p = p0 + pl, n = img0 + il;
-            const bool v = (il < a.imgs) && (n < a.N) && (p < LP);
-            const int oy = p / a.Wo, ox = p - oy * a.Wo;
-            if (c4 == 0) pixoff[q] = v ? ((il * a.PR + (oy - oy0) * a.stride) * a.PC + ox * a.stride) * a.CP : 0;
-            float4 d = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int co = n0 + c4 * 4;
-            if (v && co < a.Cout) d = *(const float4*)(a.dy + ((int64_t)(n * a.Ho + oy) * a.Wo + ox) * a.Cout + co);
-            *(float4*)(dyt + (size_t)q * a.DP + c4 * 4) = d;
+        // pixel table + dy tile (batches of 4 independent 16-B loads per thread)
+        const int dunits = a.KP * Q;
+        for (int u0 = tid; u0 < dunits; u0 += 1024) {
+            float4 d[4];
+            int q_[4], c4_[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int u = u0 + i * 256;
+                q_[i] = -1;
+                d[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (u < dunits) {
+                    int c4, pl;
+                    const int q = fdiv(u, Q, 1.0f / (float)Q, c4);
+                    const int il = fdiv(q, a.ppi, inv_ppi, pl);
+                    const int p = p0 + pl, n = img0 + il;
+                    const bool v = (il < a.imgs) && (n < a.N) && (p < LP);
+                    int ox;
+                    const int oy = fdiv(p, a.Wo, inv_wo, ox);
+                    if (c4 == 0) pixoff[q] = v ? ((il * a.PR + (oy - oy0) * a.stride) * a.PC + ox * a.stride) * a.CP : 0;
+                    const int co = n0 + c4 * 4;
+                    if (v && co < a.Cout) d[i] = *(const float4*)(a.dy + ((int64_t)(n * a.Ho + oy) * a.Wo + ox) * a.Cout + co);
+                    q_[i] = q; c4_[i] = c4;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (q_[i] >= 0) *(float4*)(dyt + (size_t)q_[i] * a.DP + c4_[i] * 4) = d[i];
         }
         // input patch, channels [c0, c0+KC)
         const int units = a.imgs * pr_use * a.PC * kc4;
-        for (int u = tid; u < units; u += 256) {
-            const int c4 = u % kc4;
-            const int u1 = u / kc4;
-            const int pc = u1 % a.PC;
-            const int u2 = u1 / a.PC;
-            const int pr = u2 % pr_use;
-            const int il = u2 / pr_use;
-            const int iy = oy0 * a.stride + a.min_dy + pr;
-            const int ix = a.min_dx + pc;
-            const int n = img0 + il;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n < a.N && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win)
-                v = *(const float4*)(a.x + ((int64_t)(n * a.Hin + iy) * a.Win + ix) * a.Cin + c0 + c4 * 4);
-            float* d = patch + ((il * a.PR + pr) * a.PC + pc) * a.CP + c4 * 4;
-            *(float2*)d = make_float2(v.x, v.y);
-            *(float2*)(d + 2) = make_float2(v.z, v.w);
+        const float inv_pr = 1.0f / (float)pr_use;
+        for (int u0 = tid; u0 < units; u0 += 1024) {
+            float4 v[4];
+            int doff[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int u = u0 + i * 256;
+                doff[i] = -1;
+                v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (u < units) {
+                    int c4, pc, pr;
+                    const int u1 = fdiv(u, kc4, inv_kc4, c4);
+                    const int u2 = fdiv(u1, a.PC, inv_pc, pc);
+                    const int il = fdiv(u2, pr_use, inv_pr, pr);
+                    const int iy = oy0 * a.stride + a.min_dy + pr;
+                    const int ix = a.min_dx + pc;
+                    const int n = img0 + il;
+                    doff[i] = ((il * a.PR + pr) * a.PC + pc) * a.CP + c4 * 4;
+                    if (n < a.N && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win)
+                        v[i] = *(const float4*)(a.x + ((int64_t)(n * a.Hin + iy) * a.Win + ix) * a.Cin + c0 + c4 * 4);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (doff[i] >= 0) {
+                    float* d = patch + doff[i];
+                    *(float2*)d = make_float2(v[i].x, v[i].y);
+                    *(float2*)(d + 2) = make_float2(v[i].z, v[i].w);
+                }
         }
         __syncthreads();
         const float* pb = dyt + (size_t)g * a.DP + r16;
-        for (int s = 0; s < a.KP; s += 4) {
-            const int po = pixoff[s + g];
-            float av[MTW], bv[NTW];
+        auto ksteps = [&](int s, auto UC) {
+            constexpr int U = decltype(UC)::value;
+            int po[U];
+            float av[U][MTW], bv[U][NTW];
 #pragma unroll
-            for (int mt = 0; mt < MTW; ++mt) av[mt] = patch[po + aoff[mt]];
+            for (int u = 0; u < U; ++u) po[u] = pixoff[s + 4 * u + g];
 #pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) bv[nt] = pb[(size_t)s * a.DP + nt * 16];
+            for (int u = 0; u < U; ++u) {
 #pragma unroll
-            for (int mt = 0; mt < MTW; ++mt)
+                for (int mt = 0; mt < MTW; ++mt) av[u][mt] = patch[po[u] + aoff[mt]];
 #pragma unroll
-                for (int nt = 0; nt < NTW; ++nt)
-                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt], bv[nt], acc[mt][nt], 0, 0, 0);
-        }
+                for (int nt = 0; nt < NTW; ++nt) bv[u][nt] = pb[(size_t)(s + 4 * u) * a.DP + nt * 16];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NTW; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][mt], bv[u][nt], acc[mt][nt], 0, 0, 0);
+        };
+        int s = 0;
+        for (; s + 16 <= a.KP; s += 16) ksteps(s, std::integral_constant<int, 4>());
+        for (; s < a.KP; s += 4) ksteps(s, std::integral_constant<int, 1>());
     }
     // partial tile out: rows (chunk, mblock, m), cols co
     const int mrows_chunk = a.mblocks_per_chunk * 64 * MTW;
@@ -410,40 +785,53 @@ static wgrad_fn_t wgrad_fn(int M, int N) {
     return nullptr;
 }
 
-// sums the split-K partials into the OIHW gradient: grad[co][ci][t] (+)= sum_s partial[s][(chunk,t,cc)][co]
+// sums the split-K partials into the OIHW gradient: grad[co][ci][t] (+)= sum_s partial[s][(chunk,t,cc)][co].
+// 32 consecutive outputs (co fastest: coalesced partial reads) x 8 split lanes per block; the 8 lane sums are combined
+// through LDS in a fixed order, so the result does not depend on scheduling.
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ partial, int S, int Mrows_total, int CoutP,
                                                            int mrows_chunk, int KC, int ntaps, int CinReal, int Cout,
                                                            float* __restrict__ grad, int accumulate) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;  // (t, ci, co) with co fastest
+    __shared__ float red[8][33];
+    const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
+    const int idx = blockIdx.x * 32 + o;  // (t, ci, co) with co fastest
     const int total = ntaps * CinReal * Cout;
-    if (idx >= total) return;
+    const bool valid = idx < total;
     const int co = idx % Cout;
     const int r = idx / Cout;
     const int ci = r % CinReal, t = r / CinReal;
     const int chunk = ci / KC, cc = ci - chunk * KC;
     const int row = chunk * mrows_chunk + t * KC + cc;
-    const float* p = partial + (int64_t)row * CoutP + co;
     const int64_t stride = (int64_t)Mrows_total * CoutP;
+    const float* p = partial + (int64_t)row * CoutP + co;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    int s = 0;
-    for (; s + 4 <= S; s += 4) {
-        s0 += p[(int64_t)s * stride];
-        s1 += p[(int64_t)(s + 1) * stride];
-        s2 += p[(int64_t)(s + 2) * stride];
-        s3 += p[(int64_t)(s + 3) * stride];
+    if (valid) {
+        int s = sl;
+        for (; s + 24 < S; s += 32) {
+            s0 += p[(int64_t)s * stride];
+            s1 += p[(int64_t)(s + 8) * stride];
+            s2 += p[(int64_t)(s + 16) * stride];
+            s3 += p[(int64_t)(s + 24) * stride];
+        }
+        for (; s < S; s += 8) s0 += p[(int64_t)s * stride];
     }
-    for (; s < S; ++s) s0 += p[(int64_t)s * stride];
-    float v = (s0 + s1) + (s2 + s3);
-    float* gp = grad + ((int64_t)co * CinReal + ci) * ntaps + t;
-    if (accumulate) v += *gp;
-    *gp = v;
+    red[sl][o] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl == 0 && valid) {
+        float v = ((red[0][o] + red[1][o]) + (red[2][o] + red[3][o])) + ((red[4][o] + red[5][o]) + (red[6][o] + red[7][o]));
+        float* gp = grad + ((int64_t)co * CinReal + ci) * ntaps + t;
+        if (accumulate) v += *gp;
+        *gp = v;
+    }
 }
 
-static int wg_cp(int kc, int stride) {  // LDS pixel stride for the wgrad A reads
-    int cp = kc;
-    if (stride == 1) { while ((cp & 31) != 16) cp += 2; }
-    else { while ((cp & 15) != 8) cp += 2; }
-    return cp;
+// LDS pixel stride of the wgrad input patch.  A reads (ds_read_b32, 32 banks, lanes 0-31 = 2 pixels x 16 channels)
+// are conflict-free when stride*CP = 16 (mod 32); take the smallest even CP >= KC within 4 banks of that.
+static int wg_cp(int kc, int stride) {
+    for (int cp = kc;; cp += 2) {
+        const int x = (stride * cp) & 31;
+        const int d = std::min(x, 32 - x);
+        if (16 - d <= 4) return cp;
+    }
 }
 
 int plan_wgrad(int N, int Hin, int Win, int Cin, int Ho, int Wo, int Cout, int ksize, int stride, WgradPlan* p) {
@@ -498,13 +886,29 @@ int plan_wgrad(int N, int Hin, int Win, int Cin, int Ho, int Wo, int Cout, int k
     a.nchunks = Cin / a.KC;
     a.Mchunk = a.ntaps * a.KC;
     const int mtiles = cdiv(a.Mchunk, 16);
-    int MTW = std::min(4, cdiv(mtiles, 4));
-    if (MTW * NTW > 20) MTW = std::max(1, 20 / NTW);
+    a.total_tiles = cdiv(N, a.imgs) * a.tiles_per_img;
+    // Block tile (64*MTW rows) and pixel split S: aim at >= 384 workgroups (1.5 per CU) with the largest tile that
+    // gets there, cap the split so that the fp32 partial slabs stay <= 12 MB (they are written and read once), and
+    // balance the pixel tiles over the S slices.
+    int MTW = 1, bestS = 1;
+    int64_t best_blocks = -1;
+    for (int m = std::min(4, cdiv(mtiles, 4)); m >= 1; --m) {
+        if (m * NTW > 20) continue;
+        const int mb = cdiv(mtiles, 4 * m);
+        const int by = a.nchunks * mb * a.nblocks;
+        const int64_t slab = (int64_t)a.nchunks * mb * 64 * m * a.CoutP * 4;
+        const int s_cap = (int)std::max<int64_t>(1, (12ll << 20) / slab);
+        int S = std::max(1, std::min(std::min(a.total_tiles, s_cap), cdiv(512, by)));
+        const int tpb = cdiv(a.total_tiles, S);
+        S = cdiv(a.total_tiles, tpb);
+        const int64_t blocks = (int64_t)by * S;
+        if (blocks > best_blocks) { best_blocks = blocks; MTW = m; bestS = S; }
+        if (blocks >= 384) break;
+    }
     a.mblocks_per_chunk = cdiv(mtiles, 4 * MTW);
     a.Mrows_total = a.nchunks * a.mblocks_per_chunk * 64 * MTW;
-    a.total_tiles = cdiv(N, a.imgs) * a.tiles_per_img;
     const int by = a.nchunks * a.mblocks_per_chunk * a.nblocks;
-    a.S = std::max(1, std::min(a.total_tiles, std::max(1, 768 / by)));
+    a.S = bestS;
     p->MTW = MTW; p->NTW = NTW;
     p->grid_x = a.S; p->grid_y = by;
     p->partial_floats = (size_t)a.S * a.Mrows_total * a.CoutP;
@@ -528,7 +932,7 @@ int launch_wgrad_reduce(const WgradPlan& p, float* grad_oihw, int accumulate, hi
     const int cin_real = a.Cin == 4 ? 3 : a.Cin;  // the stem's NHWC4 input carries a zero 4th channel
     const int total = a.ntaps * cin_real * a.Cout;
     ProfScope ps(PROF_WGRAD, s);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 256)), dim3(256), 0, s, a.partial, a.S, a.Mrows_total, a.CoutP,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 32)), dim3(256), 0, s, a.partial, a.S, a.Mrows_total, a.CoutP,
                        a.mblocks_per_chunk * 64 * p.MTW, a.KC, a.ntaps, cin_real, a.Cout, grad_oihw, accumulate);
     OCL_LAUNCH_CHECK();
     return OCL_OK;
@@ -591,7 +995,11 @@ __global__ void __launch_bounds__(256) bn_fwd_kernel(const BnFwdArgs a) {
     const int g = blockIdx.y, tid = threadIdx.x;
     const double M = (double)a.m_per_group;
     for (int c = tid; c < a.C; c += 256) {
-        const double s1 = a.stats[((int64_t)g * 2 + 0) * a.C + c], s2 = a.stats[((int64_t)g * 2 + 1) * a.C + c];
+        double s1 = 0.0, s2 = 0.0;
+        for (int r = 0; r < kStatReps; ++r) {   // fixed order: the replica sums are combined deterministically
+            s1 += a.stats[r * a.stat_rep_stride + ((int64_t)g * 2 + 0) * a.C + c];
+            s2 += a.stats[r * a.stat_rep_stride + ((int64_t)g * 2 + 1) * a.C + c];
+        }
         const double mean = s1 / M;
         double var = s2 / M - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -608,7 +1016,11 @@ __global__ void __launch_bounds__(256) bn_fwd_kernel(const BnFwdArgs a) {
         for (int c = tid; c < a.C; c += 256) {
             float rm = a.running_mean[c], rv = a.running_var[c];
             for (int gg = 0; gg < a.G; ++gg) {  // one update per group, in order (= separate forward calls)
-                const double s1 = a.stats[((int64_t)gg * 2 + 0) * a.C + c], s2 = a.stats[((int64_t)gg * 2 + 1) * a.C + c];
+                double s1 = 0.0, s2 = 0.0;
+                for (int r = 0; r < kStatReps; ++r) {
+                    s1 += a.stats[r * a.stat_rep_stride + ((int64_t)gg * 2 + 0) * a.C + c];
+                    s2 += a.stats[r * a.stat_rep_stride + ((int64_t)gg * 2 + 1) * a.C + c];
+                }
                 const double mean = s1 / M;
                 double var = s2 / M - mean * mean;
                 if (var < 0.0) var = 0.0;
@@ -801,8 +1213,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const BnBwdArgs a) {
 int launch_bn_bwd(const BnBwdArgs& a, hipStream_t s) {
     OCL_REQUIRE(a.nsets == 1 || a.nsets == 2, "bn_bwd: nsets=%d", a.nsets);
     const int C4 = a.C / 4, PT = 256 / C4;
-    const int64_t per_block_pixels = (int64_t)PT * 32;
-    const int bx = (int)std::max<int64_t>(1, std::min<int64_t>(512, (a.m_per_group + per_block_pixels - 1) / per_block_pixels));
+    const int64_t per_block_pixels = (int64_t)PT * 8;
+    const int bx = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (a.m_per_group + per_block_pixels - 1) / per_block_pixels));
     ProfScope ps(PROF_BN, s);
     const size_t sm1 = (size_t)a.nsets * 2 * PT * a.C * 4;
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(bx, a.G), dim3(256), sm1, s, a);
@@ -904,17 +1316,25 @@ int launch_relu_bwd(const float* dy, const float* a, float* dx, int64_t n, hipSt
     return OCL_OK;
 }
 
+// out[c] (+)= sum_r m[r][c]: 32 columns x 8 row lanes per workgroup, lane sums combined through LDS in a fixed order
 __global__ void __launch_bounds__(256) colsum_kernel(const float* __restrict__ m, int rows, int cols, float* __restrict__ out,
                                                      int accumulate) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= cols) return;
+    __shared__ float red[8][33];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     float s = 0.f;
-    for (int r = 0; r < rows; ++r) s += m[(int64_t)r * cols + c];
-    out[c] = accumulate ? out[c] + s : s;
+    if (c < cols)
+        for (int r = rl; r < rows; r += 8) s += m[(int64_t)r * cols + c];
+    red[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < cols) {
+        const float v = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) + ((red[4][cl] + red[5][cl]) + (red[6][cl] + red[7][cl]));
+        out[c] = accumulate ? out[c] + v : v;
+    }
 }
 int launch_colsum(const float* m, int rows, int cols, float* out, int accumulate, hipStream_t s) {
     ProfScope ps(PROF_HEAD, s);
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, s, m, rows, cols, out, accumulate);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(cols, 32)), dim3(256), 0, s, m, rows, cols, out, accumulate);
     OCL_LAUNCH_CHECK();
     return OCL_OK;
 }
@@ -934,9 +1354,11 @@ int launch_fill(float* p, int64_t n, float v, hipStream_t s) {
 int conv_kernels_init() {
     static bool done = false;
     if (done) return OCL_OK;
-    for (int m = 1; m <= 2; ++m)
+    for (int m = 1; m <= 4; ++m)
         for (int n = 1; n <= 5; ++n)
-            OCL_HIP(hipFuncSetAttribute((const void*)conv_fn(m, n), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+            for (int pf = 4; pf <= 8; pf += 2)
+                if (conv_fn(m, n, pf))
+                    OCL_HIP(hipFuncSetAttribute((const void*)conv_fn(m, n, pf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     for (int m = 1; m <= 4; ++m)
         for (int n = 1; n <= 5; ++n)
             OCL_HIP(hipFuncSetAttribute((const void*)wgrad_fn(m, n), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));

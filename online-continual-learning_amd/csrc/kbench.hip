@@ -1,0 +1,323 @@
+// kbench — per-layer micro-benchmark of the Reduced-ResNet18 kernels (measurement tool, not part of libocl_hip.so).
+//   kbench [n_images=220] [groups=2] [hw=32] [mode=all|conv|wgrad|bn] [sweep=1]
+// Times every convolution layer's forward / data-gradient geometry for the planner's tile choice and (sweep=1) for
+// every admissible forced (MT,NT), the weight-gradient kernels and the BatchNorm kernels, with HIP events.
+// Each forced configuration is also compared against the planner's output (max |diff|): all tilings must agree.
+#include "conv.h"
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <string>
+#include <vector>
+
+using namespace ocl;
+
+#define CK(x)                                                                              \
+    do {                                                                                   \
+        hipError_t e_ = (x);                                                               \
+        if (e_ != hipSuccess) {                                                            \
+            fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            exit(2);                                                                       \
+        }                                                                                  \
+    } while (0)
+#define OK(x)                                                                  \
+    do {                                                                       \
+        int r_ = (x);                                                          \
+        if (r_ != OCL_OK) {                                                    \
+            fprintf(stderr, "ocl error %d: %s (%s:%d)\n", r_, ocl_last_error(), __FILE__, __LINE__); \
+            exit(3);                                                           \
+        }                                                                      \
+    } while (0)
+
+struct Layer {
+    std::string name;
+    ConvShape s;
+};
+
+static std::vector<Layer> make_layers(int hw, int nf) {
+    std::vector<Layer> v;
+    auto add = [&](const std::string& name, int Cin, int Cout, int k, int stride, int H, int W) {
+        Layer l;
+        l.name = name;
+        memset(&l.s, 0, sizeof(l.s));
+        l.s.Cin = Cin; l.s.CinT = Cin == 3 ? 4 : Cin; l.s.Cout = Cout; l.s.k = k; l.s.stride = stride;
+        l.s.Hin = H; l.s.Win = W;
+        const int pad = k == 3 ? 1 : 0;
+        l.s.Ho = (H + 2 * pad - k) / stride + 1;
+        l.s.Wo = (W + 2 * pad - k) / stride + 1;
+        l.s.CoutP = pack_width(Cout);
+        l.s.CiP = Cin == 3 ? 0 : pack_width(Cin);
+        v.push_back(l);
+        return l.s;
+    };
+    int H = hw, W = hw;
+    add("conv1", 3, nf, 3, 1, H, W);
+    int in_planes = nf;
+    for (int layer = 0; layer < 4; ++layer) {
+        const int planes = nf << layer;
+        for (int b = 0; b < 2; ++b) {
+            const int stride = (b == 0 && layer > 0) ? 2 : 1;
+            char nm[64];
+            snprintf(nm, sizeof(nm), "layer%d.%d", layer + 1, b);
+            ConvShape c1 = add(std::string(nm) + ".conv1", in_planes, planes, 3, stride, H, W);
+            add(std::string(nm) + ".conv2", planes, planes, 3, 1, c1.Ho, c1.Wo);
+            if (stride != 1 || in_planes != planes) add(std::string(nm) + ".shortcut", in_planes, planes, 1, stride, H, W);
+            in_planes = planes;
+            H = c1.Ho;
+            W = c1.Wo;
+        }
+    }
+    return v;
+}
+
+static float* dev_rand(size_t n, unsigned seed, float scale = 1.f) {
+    std::vector<float> h(n);
+    unsigned s = seed * 2654435761u + 12345u;
+    for (size_t i = 0; i < n; ++i) {
+        s = s * 1664525u + 1013904223u;
+        h[i] = ((float)((s >> 8) & 0xffff) / 65535.0f - 0.5f) * scale;
+    }
+    float* d;
+    CK(hipMalloc(&d, n * 4));
+    CK(hipMemcpy(d, h.data(), n * 4, hipMemcpyHostToDevice));
+    return d;
+}
+
+template <class F>
+static double time_us(F&& fn, int iters = 10, int warm = 2) {
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    for (int i = 0; i < warm; ++i) fn();
+    CK(hipEventRecord(a, 0));
+    for (int i = 0; i < iters; ++i) fn();
+    CK(hipEventRecord(b, 0));
+    CK(hipEventSynchronize(b));
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, a, b));
+    CK(hipEventDestroy(a));
+    CK(hipEventDestroy(b));
+    return (double)ms * 1e3 / iters;
+}
+
+static double max_diff(const float* a, const float* b, size_t n) {
+    std::vector<float> ha(n), hb(n);
+    CK(hipMemcpy(ha.data(), a, n * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hb.data(), b, n * 4, hipMemcpyDeviceToHost));
+    double m = 0.0;
+    for (size_t i = 0; i < n; ++i) m = fmax(m, fabs((double)ha[i] - (double)hb[i]));
+    return m;
+}
+
+static void bench_geom(const char* lname, const char* kind, ConvGeomDesc g, const float* in, const float* w, float* out,
+                       float* out_ref, double* stats, int flags, double flops, size_t out_elems, bool sweep) {
+    ConvPlan p0;
+    OK(plan_conv(g, &p0));
+    auto run = [&](ConvPlan p, float* o) {
+        p.a.in = in; p.a.w = w; p.a.out = o; p.a.flags = flags; p.a.stats = stats; p.a.stat_rep_stride = 8 * 2 * 1024;
+        OK(launch_conv(p, 0));
+    };
+    CK(hipMemset(out_ref, 0, out_elems * 4));
+    run(p0, out_ref);
+    const double t0 = time_us([&] { run(p0, out_ref); });
+    printf("%-20s %-7s M=%7d N=%3d K=%4d  auto MT=%d NT=%d grid=%5dx%d lds=%6zu KC=%3d TG=%d  %7.1f us %6.1f TF/s\n", lname, kind,
+           g.N * g.LH * g.LW, g.Cout, g.ntaps * g.Cin, p0.MT, p0.NT, p0.grid_x, p0.grid_y, p0.lds_bytes, p0.a.KC, p0.a.TG, t0,
+           flops / t0 * 1e-6);
+    if (!sweep) return;
+    const int MTs[3] = {1, 2, 4};
+    const int ntile16 = (g.Cout + 15) / 16;
+    for (int mi = 0; mi < 3; ++mi)
+        for (int NT = 1; NT <= std::min(5, ntile16); ++NT)
+          for (int bpc = 1; bpc <= 3; ++bpc) {
+            ConvGeomDesc gf = g;
+            gf.force_MT = MTs[mi];
+            gf.force_NT = NT;
+            gf.force_bpc = bpc;
+            ConvPlan p;
+            if (plan_conv(gf, &p) != OCL_OK) continue;
+            CK(hipMemset(out, 0, out_elems * 4));
+            run(p, out);
+            const double d = max_diff(out, out_ref, out_elems);
+            const double t = time_us([&] { run(p, out); });
+            printf("    MT=%d NT=%d grid=%5dx%d lds=%6zu KC=%3d TG=%d  %7.1f us %6.1f TF/s  maxdiff=%.2e%s\n", p.MT, p.NT, p.grid_x,
+                   p.grid_y, p.lds_bytes, p.a.KC, p.a.TG, t, flops / t * 1e-6, d, d > 1e-3 ? "  <-- MISMATCH" : "");
+        }
+}
+
+// ---- calibration: what the f32 MFMA pipe delivers on this box ---------------------------------------------------------
+template <int NACC, bool LDS>
+__global__ void __launch_bounds__(256) mfma_peak_kernel(float* out, int iters) {
+    __shared__ float sm[4096];
+    for (int i = threadIdx.x; i < 4096; i += 256) sm[i] = (float)(i & 7) * 0.125f;
+    __syncthreads();
+    f32x4 acc[NACC];
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float a = (float)(threadIdx.x & 3) * 0.25f, b = 1.0f;
+    const int lane = threadIdx.x & 63;
+    for (int i = 0; i < iters; ++i) {
+        if (LDS) {   // the conv main loop's operand traffic: one A and one B ds_read_b32 per pair of MFMAs
+            float av[NACC / 2], bv[2];
+#pragma unroll
+            for (int j = 0; j < NACC / 2; ++j) av[j] = sm[(lane * 22 + j * 64 + i * 4) & 4095];
+            bv[0] = sm[(lane + i * 48) & 4095];
+            bv[1] = sm[(lane + 16 + i * 48) & 4095];
+#pragma unroll
+            for (int j = 0; j < NACC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j / 2], bv[j & 1], acc[j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NACC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[j], 0, 0, 0);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) s += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
+template <int NACC, bool LDS>
+static void peak_case(const char* name, int blocks_per_cu, float* out) {
+    const int iters = 4000;
+    const int blocks = 256 * blocks_per_cu;
+    const double t = time_us([&] { hipLaunchKernelGGL((mfma_peak_kernel<NACC, LDS>), dim3(blocks), dim3(256), 0, 0, out, iters); }, 5, 1);
+    const double flops = (double)blocks * 4 * iters * NACC * 2048.0;
+    printf("peak %-28s acc=%d blocks/CU=%d  %8.1f us  %6.1f TF/s  (%.1f cycles/MFMA/SIMD at 2.4 GHz)\n", name, NACC, blocks_per_cu, t,
+           flops / t * 1e-6, t * 1e-6 * 2.4e9 / ((double)blocks_per_cu * iters * NACC));
+}
+
+int main(int argc, char** argv) {
+    const int N = argc > 1 ? atoi(argv[1]) : 220;
+    const int groups = argc > 2 ? atoi(argv[2]) : 2;
+    const int hw = argc > 3 ? atoi(argv[3]) : 32;
+    const std::string mode = argc > 4 ? argv[4] : "all";
+    const bool sweep = argc > 5 ? atoi(argv[5]) != 0 : true;
+    std::vector<Layer> layers = make_layers(hw, 20);
+    if (mode == "plan") {   // host-only: print the planner's choices (works without a GPU)
+        for (auto& l : layers) {
+            const ConvShape& c = l.s;
+            ConvGeomDesc g;
+            geom_fwd(c, N, groups, &g);
+            std::vector<ConvGeomDesc> all(1, g), dg;
+            if (c.Cin != 3) geom_dgrad(c, N, &dg);
+            all.insert(all.end(), dg.begin(), dg.end());
+            for (size_t i = 0; i < all.size(); ++i) {
+                ConvPlan p;
+                OK(plan_conv(all[i], &p));
+                printf("%-20s %-6s M=%7d N=%3d K=%4d  MT=%d NT=%d grid=%5dx%d lds=%6zu KC=%3d CP=%3d TG=%d gpc=%d WS=%d imgs=%d ppi=%d PR=%d PC=%d\n",
+                       l.name.c_str(), i == 0 ? "fwd" : "dgrad", all[i].N * all[i].LH * all[i].LW, all[i].Cout, all[i].ntaps * all[i].Cin,
+                       p.MT, p.NT, p.grid_x, p.grid_y, p.lds_bytes, p.a.KC, p.a.CP, p.a.TG, p.a.gpc, p.a.WS, p.a.imgs, p.a.ppi, p.a.PR, p.a.PC);
+            }
+            WgradPlan wp;
+            OK(plan_wgrad(N, c.Hin, c.Win, c.CinT, c.Ho, c.Wo, c.Cout, c.k, c.stride, &wp));
+            printf("%-20s wgrad  M=%4d N=%3d K=%7d  MTW=%d NTW=%d grid=%4dx%3d lds=%6zu KC=%3d CP=%3d S=%4d tiles=%d partial=%6.2f MB\n", l.name.c_str(),
+                   c.k * c.k * c.CinT, c.Cout, N * c.Ho * c.Wo, wp.MTW, wp.NTW, wp.grid_x, wp.grid_y, wp.lds_bytes, wp.a.KC, wp.a.CP, wp.a.S,
+                   wp.a.total_tiles, wp.partial_floats * 4e-6);
+        }
+        return 0;
+    }
+    OK(ocl_init(0));
+    OK(conv_kernels_init());
+    size_t max_act = 0, max_w = 0;
+    for (auto& l : layers) {
+        max_act = std::max(max_act, (size_t)N * l.s.Hin * l.s.Win * l.s.CinT);
+        max_act = std::max(max_act, (size_t)N * l.s.Ho * l.s.Wo * l.s.Cout);
+        max_w = std::max(max_w, (size_t)9 * std::max(l.s.CinT * l.s.CoutP, l.s.Cout * std::max(l.s.CiP, 16)));
+    }
+    float* bufA = dev_rand(max_act, 1);
+    float* bufB = dev_rand(max_act, 2);
+    float* bufC = dev_rand(max_act, 3);
+    float* bufD = dev_rand(max_act, 4);
+    float* w = dev_rand(max_w + 4096, 5, 0.2f);
+    double* stats;
+    CK(hipMalloc(&stats, kStatReps * 8 * 2 * 1024 * 8));
+    CK(hipMemset(stats, 0, kStatReps * 8 * 2 * 1024 * 8));
+    printf("# kbench N=%d groups=%d hw=%d\n", N, groups, hw);
+    if (mode == "all" || mode == "peak") {
+        peak_case<4, false>("regs only", 1, bufB);
+        peak_case<4, false>("regs only", 2, bufB);
+        peak_case<8, false>("regs only", 1, bufB);
+        peak_case<8, false>("regs only", 2, bufB);
+        peak_case<4, true>("with ds_read_b32 operands", 1, bufB);
+        peak_case<4, true>("with ds_read_b32 operands", 2, bufB);
+        peak_case<4, true>("with ds_read_b32 operands", 3, bufB);
+        peak_case<8, true>("with ds_read_b32 operands", 2, bufB);
+    }
+
+    if (mode == "all" || mode == "conv") {
+        double tot_auto = 0.0;
+        for (auto& l : layers) {
+            const ConvShape& c = l.s;
+            const double macs = (double)N * c.Ho * c.Wo * c.Cout * c.Cin * c.k * c.k;
+            ConvGeomDesc g;
+            geom_fwd(c, N, groups, &g);
+            bench_geom(l.name.c_str(), "fwd", g, bufA, w, bufB, bufC, stats, EPI_STATS, 2.0 * macs, (size_t)N * c.Ho * c.Wo * c.Cout,
+                       sweep);
+            if (c.Cin != 3) {
+                std::vector<ConvGeomDesc> dg;
+                geom_dgrad(c, N, &dg);
+                int qi = 0;
+                for (auto& q : dg) {
+                    char kind[16];
+                    snprintf(kind, sizeof(kind), "dgrad%d", qi++);
+                    const double f = 2.0 * (double)N * q.LH * q.LW * q.Cout * q.Cin * q.ntaps;
+                    bench_geom(l.name.c_str(), kind, q, bufA, w, bufB, bufC, stats, 0, f, (size_t)N * c.Hin * c.Win * c.Cin, sweep);
+                }
+            }
+            (void)tot_auto;
+        }
+    }
+    if (mode == "all" || mode == "wgrad") {
+        float* partial = nullptr;
+        size_t pf = 0;
+        for (auto& l : layers) {
+            WgradPlan wp;
+            OK(plan_wgrad(N, l.s.Hin, l.s.Win, l.s.CinT, l.s.Ho, l.s.Wo, l.s.Cout, l.s.k, l.s.stride, &wp));
+            pf = std::max(pf, wp.partial_floats);
+        }
+        CK(hipMalloc(&partial, pf * 4 + 4096));
+        float* grad = dev_rand(max_w + 4096, 7);
+        for (auto& l : layers) {
+            const ConvShape& c = l.s;
+            WgradPlan wp;
+            OK(plan_wgrad(N, c.Hin, c.Win, c.CinT, c.Ho, c.Wo, c.Cout, c.k, c.stride, &wp));
+            wp.a.x = bufA; wp.a.dy = bufB; wp.a.partial = partial;
+            const double macs = (double)N * c.Ho * c.Wo * c.Cout * c.Cin * c.k * c.k;
+            const double t1 = time_us([&] { OK(launch_wgrad(wp, 0)); });
+            const double t2 = time_us([&] { OK(launch_wgrad_reduce(wp, grad, 0, 0)); });
+            printf("%-20s wgrad   M=%4d N=%3d K=%7d  MTW=%d NTW=%d grid=%4dx%3d lds=%6zu KC=%3d S=%4d partial=%6.2f MB  %7.1f us + reduce %6.1f us  %6.1f TF/s\n",
+                   l.name.c_str(), c.k * c.k * c.CinT, c.Cout, N * c.Ho * c.Wo, wp.MTW, wp.NTW, wp.grid_x, wp.grid_y, wp.lds_bytes, wp.a.KC,
+                   wp.a.S, wp.partial_floats * 4e-6, t1, t2, 2.0 * macs / (t1 + t2) * 1e-6);
+        }
+    }
+    if (mode == "all" || mode == "bn") {
+        int lastC = -1, lastH = -1;
+        float* small = dev_rand(64 * 1024, 9);
+        double* sums;
+        CK(hipMalloc(&sums, 8 * 4 * 1024 * 8));
+        for (auto& l : layers) {
+            const ConvShape& c = l.s;
+            if (c.Cout == lastC && c.Ho == lastH) continue;
+            lastC = c.Cout; lastH = c.Ho;
+            const int64_t mpg = (int64_t)(N / groups) * c.Ho * c.Wo;
+            BnFwdArgs f;
+            memset(&f, 0, sizeof(f));
+            f.y = bufA; f.z = bufB; f.res = bufC; f.stats = stats; f.stat_rep_stride = 8 * 2 * 1024; f.gamma = small; f.beta = small + 1024;
+            f.running_mean = small + 2048; f.running_var = small + 3072; f.save_mean = small + 4096; f.save_invstd = small + 8192;
+            f.m_per_group = mpg; f.G = groups; f.C = c.Cout; f.relu = 1; f.momentum = 0.1f; f.eps = 1e-5f;
+            const double tf = time_us([&] { OK(launch_bn_fwd(f, 0)); });
+            BnBwdArgs b;
+            memset(&b, 0, sizeof(b));
+            b.dz = bufA; b.z = bufB; b.m_per_group = mpg; b.G = groups; b.C = c.Cout; b.nsets = 1;
+            b.y[0] = bufC; b.mean[0] = small + 4096; b.invstd[0] = small + 8192; b.gamma[0] = small; b.dy[0] = bufD;
+            b.dgamma[0] = small + 12288; b.dbeta[0] = small + 13312; b.sums = sums;
+            const double tb = time_us([&] {
+                CK(hipMemsetAsync(sums, 0, 8 * 4 * 1024 * 8, 0));
+                OK(launch_bn_bwd(b, 0));
+            });
+            const double bytes = (double)N * c.Ho * c.Wo * c.Cout * 4;
+            printf("bn C=%3d HW=%2d  elems=%9.0f  fwd(3 tensors) %6.1f us %5.2f TB/s   bwd(reduce+apply, 7 tensor passes) %6.1f us %5.2f TB/s\n",
+                   c.Cout, c.Ho, bytes / 4, tf, 3 * bytes / tf * 1e-6, tb, 7 * bytes / tb * 1e-6);
+        }
+    }
+    return 0;
+}

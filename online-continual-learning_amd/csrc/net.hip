@@ -29,12 +29,10 @@ struct BnInfo {
     int64_t arena_off;    // into per-BN arenas of size kGmax*2*C (doubles) / 2*C floats for the fold
     int64_t save_off;     // into the slot's saved mean/invstd area (floats): mean[kGmax*C], invstd[kGmax*C]
 };
-struct ConvInfo {
-    int Cin, CinT, Cout, k, stride, Hin, Win, Ho, Wo;  // CinT: channels of the NHWC input tensor (stem: 4)
+struct ConvInfo : ConvShape {
     int w_t;          // weight tensor index
     int bn;           // following BatchNorm
     int64_t f_off, d_off;  // pack arena offsets (floats)
-    int CoutP, CiP;
     int64_t y_off;    // raw output inside a slot (floats)
 };
 struct BlockInfo {
@@ -68,7 +66,7 @@ struct ocl_net {
     int64_t gbuf_floats = 0;
     int64_t off_g[5] = {0, 0, 0, 0, 0};
     int64_t off_partial = 0, partial_floats = 0;
-    int64_t off_stats = 0, stats_doubles = 0;
+    int64_t off_stats = 0, stats_doubles = 0, stats_rep_stride = 0;
     int64_t off_bsums = 0, bsums_doubles = 0;
     int64_t off_pack = 0, pack_floats = 0;
     int64_t off_fold = 0, fold_floats = 0;
@@ -84,6 +82,7 @@ struct ocl_net {
     unsigned char* ws = nullptr;
     bool bound = false;
     bool descs_uploaded = false;
+    const float* pack_src = nullptr;   // parameter array the weight-pack arena was last written from (by a forward)
 
     int dbg_stop = -1;            // debug: return from backward right after stage (block*10 + step)
     float* dbg_role[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -125,7 +124,7 @@ static int add_bn(ocl_net* n, const std::string& prefix, int C) {
 }
 static int add_conv(ocl_net* n, const std::string& name, int Cin, int Cout, int k, int stride, int Hin, int Win) {
     ConvInfo c;
-    memset(&c, 0, sizeof(c));
+    memset((void*)&c, 0, sizeof(c));
     c.Cin = Cin;
     c.CinT = Cin == 3 ? 4 : Cin;
     c.Cout = Cout;
@@ -206,19 +205,11 @@ static int build_layout(ocl_net* n) {
     // ---- pack arena -------------------------------------------------------------------------------
     int64_t pk = 0;
     for (auto& cv : n->convs) {
-        const int nt = cdiv(cv.Cout, 16);
-        int NT = nt <= 5 ? nt : 5;
-        const int sp = cdiv(nt, NT);
-        if (sp > 1) NT = cdiv(nt, sp);
-        cv.CoutP = sp * NT * 16;
+        cv.CoutP = pack_width(cv.Cout);
         cv.f_off = pk;
         pk += (int64_t)cv.k * cv.k * cv.CinT * cv.CoutP;
         if (cv.Cin != 3) {
-            const int nti = cdiv(cv.Cin, 16);
-            int NTi = nti <= 5 ? nti : 5;
-            const int spi = cdiv(nti, NTi);
-            if (spi > 1) NTi = cdiv(nti, spi);
-            cv.CiP = spi * NTi * 16;
+            cv.CiP = pack_width(cv.Cin);
             cv.d_off = pk;
             pk += (int64_t)cv.k * cv.k * cv.Cout * cv.CiP;
         } else {
@@ -287,8 +278,9 @@ static int build_layout(ocl_net* n) {
         b.arena_off = so;
         so += (int64_t)kGmax * 2 * b.C;
     }
-    n->stats_doubles = so;
-    n->off_stats = takeb(so * 8);
+    n->stats_doubles = so * kStatReps;   // kStatReps replicas of the whole arena, replica stride `so`
+    n->stats_rep_stride = so;
+    n->off_stats = takeb(n->stats_doubles * 8);
     n->bsums_doubles = so;  // backward: [G][2][C] per BN as well
     n->off_bsums = takeb(so * 8);
     n->off_pack = takeb(n->pack_floats * 4);
@@ -304,73 +296,6 @@ static int build_layout(ocl_net* n) {
     n->slot_n.assign(d.n_slots, 0);
     n->slot_groups.assign(d.n_slots, 1);
     n->slot_valid.assign(d.n_slots, false);
-    return OCL_OK;
-}
-
-// -----------------------------------------------------------------------------------------------------
-// geometry builders
-// -----------------------------------------------------------------------------------------------------
-static void geom_fwd(const ConvInfo& c, int N, int groups, ConvGeomDesc* g) {
-    memset(g, 0, sizeof(*g));
-    g->N = N; g->groups = groups;
-    g->Hin = c.Hin; g->Win = c.Win; g->Cin = c.CinT;
-    g->Hout = c.Ho; g->Wout = c.Wo; g->Cout = c.Cout;
-    g->LH = c.Ho; g->LW = c.Wo; g->os = 1; g->oy0 = 0; g->ox0 = 0; g->is = c.stride;
-    const int pad = c.k == 3 ? 1 : 0;
-    g->ntaps = c.k * c.k;
-    for (int t = 0; t < g->ntaps; ++t) {
-        g->tdy[t] = t / c.k - pad;
-        g->tdx[t] = t % c.k - pad;
-        g->tw[t] = t;
-    }
-}
-// data gradient: "input" = dy [N,Ho,Wo,Cout], "output" = dx [N,Hin,Win,Cin]
-static int geom_dgrad(const ConvInfo& c, int N, std::vector<ConvGeomDesc>* out) {
-    out->clear();
-    ConvGeomDesc g;
-    memset(&g, 0, sizeof(g));
-    g.N = N; g.groups = 1;
-    g.Hin = c.Ho; g.Win = c.Wo; g.Cin = c.Cout;
-    g.Hout = c.Hin; g.Wout = c.Win; g.Cout = c.Cin;
-    g.is = 1;
-    if (c.stride == 1) {
-        g.LH = c.Hin; g.LW = c.Win; g.os = 1;
-        const int pad = c.k == 3 ? 1 : 0;
-        g.ntaps = c.k * c.k;
-        for (int t = 0; t < g.ntaps; ++t) {
-            g.tdy[t] = pad - t / c.k;
-            g.tdx[t] = pad - t % c.k;
-            g.tw[t] = t;
-        }
-        out->push_back(g);
-    } else if (c.k == 1) {  // 1x1 stride 2, pad 0: only even pixels receive gradient
-        g.os = 2; g.oy0 = 0; g.ox0 = 0;
-        g.LH = (c.Hin + 1) / 2; g.LW = (c.Win + 1) / 2;
-        g.ntaps = 1;
-        g.tdy[0] = 0; g.tdx[0] = 0; g.tw[0] = 0;
-        out->push_back(g);
-    } else {  // 3x3 stride 2 pad 1: four dense parity classes of the dx lattice
-        for (int py = 0; py < 2; ++py)
-            for (int px = 0; px < 2; ++px) {
-                ConvGeomDesc q = g;
-                q.os = 2; q.oy0 = py; q.ox0 = px;
-                q.LH = (c.Hin - py + 1) / 2; q.LW = (c.Win - px + 1) / 2;
-                if (q.LH <= 0 || q.LW <= 0) continue;
-                int nt = 0;
-                for (int ky = 0; ky < 3; ++ky) {
-                    if (((py + 1 - ky) & 1) != 0) continue;
-                    for (int kx = 0; kx < 3; ++kx) {
-                        if (((px + 1 - kx) & 1) != 0) continue;
-                        q.tdy[nt] = (py + 1 - ky) / 2;  // exact: even numerator
-                        q.tdx[nt] = (px + 1 - kx) / 2;
-                        q.tw[nt] = ky * 3 + kx;
-                        ++nt;
-                    }
-                }
-                q.ntaps = nt;
-                out->push_back(q);
-            }
-    }
     return OCL_OK;
 }
 
@@ -453,6 +378,7 @@ static const BnFoldDesc* fold_descs(const ocl_net* n) {
 
 static int run_conv(ocl_net* n, ConvPlan p, const float* in, const float* w, float* out, int flags, double* stats,
                     const float* scale, const float* shift, const float* res, const float* resmask, hipStream_t s) {
+    p.a.stat_rep_stride = n->stats_rep_stride;
     p.a.in = in;
     p.a.w = w;
     p.a.out = out;
@@ -563,6 +489,7 @@ int ocl_net_bind(ocl_net* net, float* params, float* grads, float* running, int6
     net->ws = (unsigned char*)workspace;
     net->bound = true;
     net->descs_uploaded = false;
+    net->pack_src = nullptr;
     for (size_t i = 0; i < net->slot_valid.size(); ++i) net->slot_valid[i] = false;
     return OCL_OK;
 }
@@ -587,8 +514,9 @@ int ocl_net_forward(ocl_net* n, const float* x, int N, int groups, uint32_t flag
     float* pack = (float*)(n->ws + n->off_pack);
     int max_elems = 0;
     for (auto& c : n->convs) max_elems = std::max(max_elems, c.Cout * c.Cin * c.k * c.k);
-    rc = launch_pack_weights(P, pack, pack_descs(n), (int)n->convs.size(), max_elems, s);
-    if (rc != OCL_OK) return rc;
+    rc = launch_pack_weights(P, pack, pack_descs(n), (int)n->convs.size(), max_elems, s);   // every forward: the caller
+    if (rc != OCL_OK) return rc;                                                               // may have stepped the weights
+    n->pack_src = P;
 
     float* S = n->slotf(slot);
     float* x4 = S + n->x4_off;
@@ -608,6 +536,7 @@ int ocl_net_forward(ocl_net* n, const float* x, int N, int groups, uint32_t flag
             memset(&a, 0, sizeof(a));
             a.y = y; a.z = z; a.res = res;
             a.stats = stats + b.arena_off;
+            a.stat_rep_stride = n->stats_rep_stride;
             a.gamma = P + n->tensors[b.gamma_t].off;
             a.beta = P + n->tensors[b.beta_t].off;
             a.running_mean = upd ? n->running + b.stat_off : nullptr;
@@ -708,10 +637,11 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
     float* partial = (float*)(n->ws + n->off_partial);
     double* bsums = (double*)(n->ws + n->off_bsums);
     OCL_HIP(hipMemsetAsync(bsums, 0, n->bsums_doubles * 8, s));
-    {   // the pack arena may have been rewritten by another forward (eval scoring, MIR's virtual model) since
+    if (n->pack_src != P) {   // the arena was rewritten by a forward of MIR's virtual model since the taped forward
         int max_elems = 0;
         for (auto& c : n->convs) max_elems = std::max(max_elems, c.Cout * c.Cin * c.k * c.k);
         if ((rc = launch_pack_weights(P, pack, pack_descs(n), (int)n->convs.size(), max_elems, s))) return rc;
+        n->pack_src = P;
     }
     auto T = [&](int t) { return P + n->tensors[t].off; };
     auto GT = [&](int t) { return Gr + n->tensors[t].off; };

@@ -197,17 +197,19 @@ __global__ void __launch_bounds__(256) supcon_rows(const float* __restrict__ fea
     }
 }
 // pass 2: dfeat_i = (1/T) * sum_j (G[i][j] + G[j][i]) f_j ; block 0 also reduces the loss.
+// The symmetrised coefficient row is staged in LDS first (the column read G[j][i] is strided: done once, in parallel),
+// then threads run over the feature dimension with coalesced reads of f_j.
 __global__ void __launch_bounds__(128) supcon_grad(const float* __restrict__ feat, int A, int dim, float T,
                                                    const float* __restrict__ G, const float* __restrict__ rowloss,
                                                    float* __restrict__ loss_out, float* __restrict__ dfeat) {
+    extern __shared__ __attribute__((aligned(16))) float cf[];   // A coefficients
     const int i = blockIdx.x;
     if (dfeat) {
+        for (int j = threadIdx.x; j < A; j += blockDim.x) cf[j] = G[(int64_t)i * A + j] + G[(int64_t)j * A + i];
+        __syncthreads();
         for (int d = threadIdx.x; d < dim; d += blockDim.x) {
             float acc = 0.f;
-            for (int j = 0; j < A; ++j) {
-                const float c = G[(int64_t)i * A + j] + G[(int64_t)j * A + i];
-                acc = fmaf(c, feat[(int64_t)j * dim + d], acc);
-            }
+            for (int j = 0; j < A; ++j) acc = fmaf(cf[j], feat[(int64_t)j * dim + d], acc);
             dfeat[(int64_t)i * dim + d] = acc / T;
         }
     }
@@ -689,8 +691,8 @@ int ocl_supcon_fwd_bwd(const float* feat, const int64_t* y, int bsz, int n_views
     const size_t sm = (size_t)(dim + A + 16) * sizeof(float);
     hipLaunchKernelGGL(supcon_rows, dim3(A), dim3(256), sm, s, feat, y, bsz, A, dim, temperature, G, rowloss);
     OCL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(supcon_grad, dim3(dfeat ? A : 1), dim3(128), 0, s, feat, A, dim, temperature, G, rowloss, loss_out,
-                       dfeat);
+    hipLaunchKernelGGL(supcon_grad, dim3(dfeat ? A : 1), dim3(128), (size_t)A * sizeof(float), s, feat, A, dim, temperature, G, rowloss,
+                       loss_out, dfeat);
     OCL_LAUNCH_CHECK();
     return OCL_OK;
 }

@@ -52,7 +52,11 @@ class ASER_retrieve(object):
 
         # Type 1 - Adversarial SV: eval <- current input
         eval_adv_x, eval_adv_y = cur_x, cur_y
-        sv_matrix_adv = compute_knn_sv(model, eval_adv_x, eval_adv_y, cand_x, cand_y, self.k, device=self.device)
+        dbg = debug.on()
+        sv_matrix_adv = compute_knn_sv(model, eval_adv_x, eval_adv_y, cand_x, cand_y, self.k, device=self.device, want_order=dbg)
+        order_adv = order_coop = None
+        if dbg:
+            sv_matrix_adv, order_adv = sv_matrix_adv
 
         if self.aser_type != "neg_sv":
             # Type 2 - Cooperative SV: eval <- class balanced subsamples from memory excluding the candidates
@@ -61,14 +65,17 @@ class ASER_retrieve(object):
                 ClassBalancedRandomSampling.sample(buffer_x, buffer_y, self.n_smp_cls,
                                                    excl_indices=excl_indices, device=self.device)
             sv_matrix_coop = \
-                compute_knn_sv(model, eval_coop_x, eval_coop_y, cand_x, cand_y, self.k, device=self.device)
+                compute_knn_sv(model, eval_coop_x, eval_coop_y, cand_x, cand_y, self.k, device=self.device, want_order=dbg)
+            if dbg:
+                sv_matrix_coop, order_coop = sv_matrix_coop
             sv = ops.aser_score(sv_matrix_adv, sv_matrix_coop, self.aser_type)
         else:
             sv = ops.aser_score(sv_matrix_adv, None, "neg_sv")
 
         ret_ind = ops.argsort_desc(sv)[:num_retrieve].contiguous()
         if debug.on():
-            debug.emit("aser_retrieve", cand_ind=cand_ind.numpy().copy(), sv=sv.cpu().numpy(), ret=cand_ind[ret_ind.cpu()].numpy())
+            debug.emit("aser_retrieve", cand_ind=cand_ind.numpy().copy(), sv=sv.cpu().numpy(), ret=cand_ind[ret_ind.cpu()].numpy(),
+                       order_adv=order_adv.cpu().numpy(), order_coop=None if order_coop is None else order_coop.cpu().numpy())
 
         ret_x = ops.gather_rows(cand_x, ret_ind)
         ret_y = ops.gather_rows(cand_y, ret_ind)

@@ -74,7 +74,11 @@ class ASER_update(object):
         cand_x = torch.cat((cand_x, cur_x))
         cand_y = torch.cat((cand_y, cur_y))
 
-        sv_matrix = compute_knn_sv(model, eval_x, eval_y, cand_x, cand_y, self.k, device=self.device)
+        dbg = debug.on()
+        sv_matrix = compute_knn_sv(model, eval_x, eval_y, cand_x, cand_y, self.k, device=self.device, want_order=dbg)
+        knn_order = None
+        if dbg:
+            sv_matrix, knn_order = sv_matrix
         sv = ops.col_reduce(sv_matrix, "sum")
 
         n_cur = cur_x.size(0)
@@ -101,7 +105,7 @@ class ASER_update(object):
         if debug.on():
             debug.emit("aser_update", eval_indices=eval_indices.numpy().copy(), cand_ind=cand_ind.numpy().copy(), sv=sv.cpu().numpy(),
                        order=sv_arg_sort.numpy().copy(), ind_buffer=ind_buffer.numpy().copy(), ind_cur=ind_cur.numpy().copy(),
-                       n_minority=int(minority_batch_x.size(0)))
+                       n_minority=int(minority_batch_x.size(0)), knn_order=knn_order.cpu().numpy())
 
         # perform overwrite op
         y_upt_host = cur_y_host[ind_cur.numpy()]

@@ -23,12 +23,13 @@ def deep_features(model, eval_x, n_eval, cand_x, n_cand):
     return eval_df, cand_df
 
 
-def compute_knn_sv(model, eval_x, eval_y, cand_x, cand_y, k, device="cpu"):
-    """aser_utils.py:7-61: KNN Shapley value matrix [n_eval, n_cand] of candidates w.r.t. evaluation data."""
+def compute_knn_sv(model, eval_x, eval_y, cand_x, cand_y, k, device="cpu", want_order=False):
+    """aser_utils.py:7-61: KNN Shapley value matrix [n_eval, n_cand] of candidates w.r.t. evaluation data.
+    want_order (parity tests): also return the per-row ascending-distance candidate order the kernel used."""
     n_eval = eval_x.size(0)
     n_cand = cand_x.size(0)
     eval_df, cand_df = deep_features(model, eval_x, n_eval, cand_x, n_cand)
-    return ops.knn_sv(eval_df.contiguous(), eval_y, cand_df.contiguous(), cand_y, k)
+    return ops.knn_sv(eval_df.contiguous(), eval_y, cand_df.contiguous(), cand_y, k, want_order=want_order)
 
 
 def add_minority_class_input(cur_x, cur_y, mem_size, num_class, cur_y_host=None):

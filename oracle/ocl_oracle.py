@@ -27,6 +27,9 @@ import torch.nn.functional as F
 # ======================================================================================================
 
 
+LAST_RETRIEVE_AUX = None
+
+
 def sq_dist_matrix(eval_f, cand_f):
     """utils/utils.py:93-95 applied pairwise (aser_utils.py:108-114): sum((u-v)^2) over features, fp32."""
     e = np.asarray(eval_f, dtype=np.float32)[:, None, :]
@@ -403,6 +406,10 @@ def aser_retrieve(net, buf, cache, cur_x, cur_y, params, is_aser_upt=True):
     else:
         sv = aser_score(sv_adv, None, "neg_sv")
     order = ARGSORT_DESC(sv)
+    global LAST_RETRIEVE_AUX   # features behind the scores, for the near-tie-aware parity checks in tests/
+    LAST_RETRIEVE_AUX = dict(adv=(f[:cur_x.shape[0]].numpy(), cur_y.numpy(), f[cur_x.shape[0]:].numpy(), buf.label[cand].numpy()))
+    if params["aser_type"] != "neg_sv":
+        LAST_RETRIEVE_AUX["coop"] = (f2[:coop.shape[0]].numpy(), buf.label[coop].numpy(), f2[coop.shape[0]:].numpy(), buf.label[cand].numpy())
     return cand[order[:params["eps_mem_batch"]]], cand, sv
 
 
@@ -437,7 +444,8 @@ def aser_update(net, buf, cache, x, y, params):
     buf.img[ind_buffer] = cur_x[ind_cur]
     buf.label[ind_buffer] = cur_y[ind_cur]
     return dict(ind_buffer=ind_buffer.numpy(), ind_cur=ind_cur.numpy(), sv=tot, eval_indices=ev.numpy(), cand_ind=cand_ind.numpy(),
-                order=order.numpy(), n_minority=int(minority.numel()))
+                order=order.numpy(), n_minority=int(minority.numel()),
+                aux=(f[:eval_x.shape[0]].numpy(), eval_y.numpy(), f[eval_x.shape[0]:].numpy(), cand_y.numpy()))
 
 
 # ======================================================================================================
@@ -547,6 +555,7 @@ def aser_er_step(state, names, buf, cache, batch_x, batch_y, params):
     info["ret_idx"] = ret_idx.numpy() if torch.is_tensor(ret_idx) else ret_idx
     info["cand"] = None if cand is None else cand.numpy()
     info["sv"] = sv
+    info["ret_aux"] = None if cand is None else LAST_RETRIEVE_AUX
     mem_x, mem_y = buf.img[ret_idx], buf.label[ret_idx]
     if mem_x.shape[0] > 0:
         ce_mean(net.forward(mem_x), mem_y).backward()
