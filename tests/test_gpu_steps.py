@@ -227,11 +227,12 @@ def test_mir_free_gradient_scores_close(cuda):
             assert np.abs(mir_ev[0]["scores"] - ol["scores"]).max() < 1e-2 * (1 + np.abs(ol["scores"]).max())
 
 
-def _sv_given_order(aux, order, k, dist_tol=1e-4):
+def _sv_given_order(aux, order, k, dist_tol=5e-3):
     """Near-tie-aware kNN-SV check: the HIP kernel's per-row candidate order must be a valid ascending order of the
     ORACLE's squared distances up to `dist_tol` (relative), and given that order the Shapley values are the oracle's
-    closed form.  (Features agree to ~1e-6; two candidates whose distances differ by less than that may legitimately
-    swap, which moves their SVs by a discrete 1/j-sized step — so SVs are compared under the kernel's own order.)"""
+    closed form.  (Features agree to ~1e-5 relative, test_eval_forward_features_vs_oracle; two candidates whose
+    distances differ by less than the induced distance error may legitimately swap, which moves their SVs by a discrete
+    1/j-sized step — so SVs are compared under the kernel's own order and the order is checked with a tolerance.)"""
     f_e, y_e, f_c, y_c = aux
     d = O.sq_dist_matrix(f_e, f_c)
     ds = np.take_along_axis(d, order, axis=1)
