@@ -51,7 +51,7 @@ class ScrAugment(object):
         return p
 
     def __call__(self, x):
-        params = self.sample_params(x.shape[0]).to(x.device)
+        params = ops.upload(self.sample_params(x.shape[0]), x.device)
         return ops.scr_augment(x, params)
 
 

@@ -94,6 +94,8 @@ struct WgradArgs {
     int tdy[9], tdx[9];
     int min_dy, min_dx, max_dy, max_dx;
     int KC, nchunks;            // channel chunking of Cin
+    int d_c4, d_pc, d_row;      // patch-prefetch walk (as ConvArgs)
+    float inv_PR;
     int CP, PC, PR, DP;         // LDS strides
     int KP;                     // pixels per tile (multiple of 4)
     int ppi, imgs, tiles_per_img, total_tiles;

@@ -628,13 +628,22 @@ int launch_conv(const ConvPlan& p, hipStream_t s) {
 // =====================================================================================================
 // weight gradient
 // =====================================================================================================
-template <int MTW, int NTW>
+// Weight gradient: (tap, ci) x co GEMM reduced over pixels.  A workgroup owns one (channel chunk, row block, column
+// block) output tile and a strided subset of the pixel tiles; like the forward kernel it is software-pipelined: the dy
+// tile and the input patch of the NEXT pixel tile are fetched into registers while the MFMAs of the current one run.
+struct WTile {
+    int img0, p0, oy0, nrows;
+};
+
+template <int MTW, int NTW, int PF>
 __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     int* pixoff = (int*)lds_raw;                    // [KP]
     float* dyt = (float*)(pixoff + a.KP);           // [KP][DP]
     float* patch = dyt + (size_t)a.KP * a.DP;       // [imgs][PR][PC][CP]
     constexpr int BNW = 16 * NTW;
+    constexpr int Q = BNW / 4;
+    constexpr int DPF = (128 * Q + 255) / 256;      // dy prefetch registers (KP <= 128)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, g = lane >> 4;
@@ -661,81 +670,114 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int kc4 = a.KC >> 2;
-    constexpr int Q = BNW / 4;
-    const float inv_kc4 = 1.0f / (float)kc4, inv_pc = 1.0f / (float)a.PC, inv_ppi = 1.0f / (float)a.ppi, inv_wo = 1.0f / (float)a.Wo;
-    for (int tile = blockIdx.x; tile < a.total_tiles; tile += a.S) {
+    auto geom = [&](int tile) __attribute__((always_inline)) -> WTile {
+        WTile t;
         const int ti = tile / a.tiles_per_img;
-        const int img0 = ti * a.imgs;
-        const int p0 = (tile - ti * a.tiles_per_img) * a.ppi;
-        const int oy0 = p0 / a.Wo;
-        const int pend = min(p0 + a.ppi, LP);
+        t.img0 = ti * a.imgs;
+        t.p0 = (tile - ti * a.tiles_per_img) * a.ppi;
+        t.oy0 = t.p0 / a.Wo;
+        const int pend = min(t.p0 + a.ppi, LP);
         const int oy1 = (pend - 1) / a.Wo;
-        const int pr_use = (oy1 - oy0) * a.stride + (a.max_dy - a.min_dy) + 1;
+        t.nrows = a.imgs > 1 ? min(a.imgs, a.N - t.img0) * a.PR : (oy1 - t.oy0) * a.stride + (a.max_dy - a.min_dy) + 1;
+        return t;
+    };
+
+    // ---- per-thread unit bookkeeping (identical for every tile) ----------------------------------------------------
+    // dy units: u = tid + i*256 -> (pixel slot q, float4 column c4); packed q << 8 | c4, -1 past the tile
+    const int kc4 = a.KC >> 2;
+    const float inv_ppi = 1.0f / (float)a.ppi, inv_wo = 1.0f / (float)a.Wo;
+    int du_pos[DPF];
+#pragma unroll
+    for (int i = 0; i < DPF; ++i) {
+        const int u = tid + i * 256;
+        int c4;
+        const int q = fdiv(u, Q, 1.0f / (float)Q, c4);
+        du_pos[i] = q < a.KP ? (q << 8) | c4 : -1;
+    }
+    // patch units: flat [row][pc][c4], packed il << 24 | pr << 16 | pc << 8 | c4
+    int pu_pos[PF];
+    {
+        int c4, pc;
+        const int pix = fdiv(tid, kc4, 1.0f / (float)kc4, c4);
+        int row = fdiv(pix, a.PC, 1.0f / (float)a.PC, pc);
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            int il = 0, pr = row;
+            if (a.imgs > 1) il = fdiv(row, a.PR, a.inv_PR, pr);
+            pu_pos[i] = (il << 24) | (pr << 16) | (pc << 8) | c4;
+            if (il >= 128 || pr >= 256) pu_pos[i] = 0x7fff0000;   // past any tile's last row
+            c4 += a.d_c4;
+            pc += a.d_pc;
+            if (c4 >= kc4) { c4 -= kc4; pc += 1; }
+            row += a.d_row;
+            if (pc >= a.PC) { pc -= a.PC; row += 1; }
+        }
+    }
+    float4 dv[DPF], pv[PF];
+    int dpo[DPF];   // LDS patch offset of the pixel (units with c4 == 0 publish it), -1: unit not in this tile
+    auto load_tile = [&](const WTile& t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < DPF; ++i) {
+            const int q = du_pos[i] >> 8, c4 = du_pos[i] & 255;
+            int pl, ox;
+            const int il = fdiv(q, a.ppi, inv_ppi, pl);
+            const int p = t.p0 + pl, n = t.img0 + il;
+            const int oy = fdiv(p, a.Wo, inv_wo, ox);
+            const bool in_tile = du_pos[i] >= 0;
+            const bool v = in_tile && (il < a.imgs) && (n < a.N) && (p < LP);
+            const int co = n0 + c4 * 4;
+            const bool ok = v && co < a.Cout;
+            const float* ptr = ok ? a.dy + ((int64_t)(n * a.Ho + oy) * a.Wo + ox) * a.Cout + co : a.dy;   // unconditional load
+            const float4 val = *(const float4*)ptr;
+            dv[i] = ok ? val : make_float4(0.f, 0.f, 0.f, 0.f);
+            dpo[i] = in_tile ? (v ? ((il * a.PR + (oy - t.oy0) * a.stride) * a.PC + ox * a.stride) * a.CP : 0) : -1;
+        }
+        const int iy0 = t.oy0 * a.stride + a.min_dy;
+        const float* base = a.x + ((int64_t)(t.img0 * a.Hin + iy0) * a.Win + a.min_dx) * a.Cin + c0;
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int il = pu_pos[i] >> 24, pr = (pu_pos[i] >> 16) & 255, pc = (pu_pos[i] >> 8) & 255, c4 = pu_pos[i] & 255;
+            const int iy = iy0 + pr, ix = a.min_dx + pc;
+            const bool ok = il * a.PR + pr < t.nrows && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
+            const float* ptr = ok ? base + ((il * a.Hin + pr) * a.Win + pc) * a.Cin + c4 * 4 : a.x;
+            const float4 val = *(const float4*)ptr;
+            pv[i] = ok ? val : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_tile = [&](const WTile& t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < DPF; ++i)
+            if (dpo[i] >= 0) {
+                const int q = du_pos[i] >> 8, c4 = du_pos[i] & 255;
+                if (c4 == 0) pixoff[q] = dpo[i];
+                *(float4*)(dyt + (size_t)q * a.DP + c4 * 4) = dv[i];
+            }
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int il = pu_pos[i] >> 24, pr = (pu_pos[i] >> 16) & 255, pc = (pu_pos[i] >> 8) & 255, c4 = pu_pos[i] & 255;
+            const int row = il * a.PR + pr;
+            if (row < t.nrows) {
+                float* d = patch + (row * a.PC + pc) * a.CP + c4 * 4;
+                *(float2*)d = make_float2(pv[i].x, pv[i].y);
+                *(float2*)(d + 2) = make_float2(pv[i].z, pv[i].w);
+            }
+        }
+    };
+
+    int tile = blockIdx.x;
+    WTile cur = geom(tile);
+    if (tile < a.total_tiles) load_tile(cur);
+    for (; tile < a.total_tiles; tile += a.S) {
         __syncthreads();  // previous tile consumed
-        // pixel table + dy tile (batches of 4 independent 16-B loads per thread)
-        const int dunits = a.KP * Q;
-        for (int u0 = tid; u0 < dunits; u0 += 1024) {
-            float4 d[4];
-            int q_[4], c4_[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int u = u0 + i * 256;
-                q_[i] = -1;
-                d[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (u < dunits) {
-                    int c4, pl;
-                    const int q = fdiv(u, Q, 1.0f / (float)Q, c4);
-                    const int il = fdiv(q, a.ppi, inv_ppi, pl);
-                    const int p = p0 + pl, n = img0 + il;
-                    const bool v = (il < a.imgs) && (n < a.N) && (p < LP);
-                    int ox;
-                    const int oy = fdiv(p, a.Wo, inv_wo, ox);
-                    if (c4 == 0) pixoff[q] = v ? ((il * a.PR + (oy - oy0) * a.stride) * a.PC + ox * a.stride) * a.CP : 0;
-                    const int co = n0 + c4 * 4;
-                    if (v && co < a.Cout) d[i] = *(const float4*)(a.dy + ((int64_t)(n * a.Ho + oy) * a.Wo + ox) * a.Cout + co);
-                    q_[i] = q; c4_[i] = c4;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (q_[i] >= 0) *(float4*)(dyt + (size_t)q_[i] * a.DP + c4_[i] * 4) = d[i];
-        }
-        // input patch, channels [c0, c0+KC)
-        const int units = a.imgs * pr_use * a.PC * kc4;
-        const float inv_pr = 1.0f / (float)pr_use;
-        for (int u0 = tid; u0 < units; u0 += 1024) {
-            float4 v[4];
-            int doff[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int u = u0 + i * 256;
-                doff[i] = -1;
-                v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (u < units) {
-                    int c4, pc, pr;
-                    const int u1 = fdiv(u, kc4, inv_kc4, c4);
-                    const int u2 = fdiv(u1, a.PC, inv_pc, pc);
-                    const int il = fdiv(u2, pr_use, inv_pr, pr);
-                    const int iy = oy0 * a.stride + a.min_dy + pr;
-                    const int ix = a.min_dx + pc;
-                    const int n = img0 + il;
-                    doff[i] = ((il * a.PR + pr) * a.PC + pc) * a.CP + c4 * 4;
-                    if (n < a.N && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win)
-                        v[i] = *(const float4*)(a.x + ((int64_t)(n * a.Hin + iy) * a.Win + ix) * a.Cin + c0 + c4 * 4);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-                if (doff[i] >= 0) {
-                    float* d = patch + doff[i];
-                    *(float2*)d = make_float2(v[i].x, v[i].y);
-                    *(float2*)(d + 2) = make_float2(v[i].z, v[i].w);
-                }
-        }
+        store_tile(cur);
         __syncthreads();
+        const int next = tile + a.S;
+        if (next < a.total_tiles) {
+            cur = geom(next);
+            load_tile(cur);
+        }
         const float* pb = dyt + (size_t)g * a.DP + r16;
-        auto ksteps = [&](int s, auto UC) {
+        auto ksteps = [&](int s, auto UC) __attribute__((always_inline)) {
             constexpr int U = decltype(UC)::value;
             int po[U];
             float av[U][MTW], bv[U][NTW];
@@ -774,9 +816,12 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
 }
 
 typedef void (*wgrad_fn_t)(const WgradArgs);
-static wgrad_fn_t wgrad_fn(int M, int N) {
-#define OCL_CASE(A, B) \
-    if (M == A && N == B) return conv_wgrad_kernel<A, B>;
+static wgrad_fn_t wgrad_fn(int M, int N, int PF) {
+#define OCL_CASE(A, B)                                               \
+    if (M == A && N == B) {                                          \
+        if (PF == 4) return conv_wgrad_kernel<A, B, 4>;              \
+        if (PF == 8) return conv_wgrad_kernel<A, B, 8>;              \
+    }
     OCL_CASE(1, 1) OCL_CASE(1, 2) OCL_CASE(1, 3) OCL_CASE(1, 4) OCL_CASE(1, 5)
     OCL_CASE(2, 1) OCL_CASE(2, 2) OCL_CASE(2, 3) OCL_CASE(2, 4) OCL_CASE(2, 5)
     OCL_CASE(3, 1) OCL_CASE(3, 2) OCL_CASE(3, 3) OCL_CASE(3, 4) OCL_CASE(3, 5)
@@ -784,6 +829,7 @@ static wgrad_fn_t wgrad_fn(int M, int N) {
 #undef OCL_CASE
     return nullptr;
 }
+static int wgrad_pf_for(int units) { return units <= 1024 ? 4 : 8; }
 
 // sums the split-K partials into the OIHW gradient: grad[co][ci][t] (+)= sum_s partial[s][(chunk,t,cc)][co].
 // 32 consecutive outputs (co fastest: coalesced partial reads) x 8 split lanes per block; the 8 lane sums are combined
@@ -849,7 +895,7 @@ int plan_wgrad(int N, int Hin, int Win, int Cin, int Ho, int Wo, int Cout, int k
     a.min_dy = a.min_dx = -pad;
     a.max_dy = a.max_dx = ksize - 1 - pad;
     const int ntile = cdiv(Cout, 16);
-    int NTW = ntile <= 5 ? ntile : 5;
+    int NTW = ntile <= 3 ? ntile : 3;   // 48 output channels per workgroup (register budget of the dy prefetch)
     a.nblocks = cdiv(ntile, NTW);
     if (a.nblocks > 1) NTW = cdiv(ntile, a.nblocks);
     a.CoutP = a.nblocks * NTW * 16;
@@ -857,34 +903,45 @@ int plan_wgrad(int N, int Hin, int Win, int Cin, int Ho, int Wo, int Cout, int k
     while ((dp & 31) != 16) dp += 16;
     a.DP = dp;
     const int LP = Ho * Wo;
-    int KPmax = 128;
-    for (;;) {
-        if (LP >= KPmax) {
-            a.imgs = 1; a.ppi = KPmax; a.tiles_per_img = cdiv(LP, KPmax); a.KP = KPmax;
-        } else {
-            a.imgs = std::min(KPmax / LP, N); a.ppi = LP; a.tiles_per_img = 1; a.KP = (int)round_up((int64_t)a.imgs * LP, 4);
+    // pixel tile (KP output pixels, 128 / 64 / 32) and channel chunk KC: the largest tile whose patch + dy fit the LDS
+    // target and the prefetch registers with a chunk of at least min(20, Cin) channels; else the best that fits at all.
+    bool found = false;
+    for (int pass = 0; pass < 2 && !found; ++pass) {
+        for (int KPmax = 128; KPmax >= 32 && !found; KPmax /= 2) {
+            if (LP >= KPmax) {
+                a.imgs = 1; a.ppi = KPmax; a.tiles_per_img = cdiv(LP, KPmax); a.KP = KPmax;
+            } else {
+                a.imgs = std::min(KPmax / LP, N); a.ppi = LP; a.tiles_per_img = 1; a.KP = (int)round_up((int64_t)a.imgs * LP, 4);
+            }
+            a.PC = (Wo - 1) * stride + (a.max_dx - a.min_dx) + 1;
+            const int rows_l = (a.imgs == 1 && LP >= KPmax) ? std::min(Ho, (KPmax + Wo - 2) / Wo + 1) : Ho;
+            a.PR = (rows_l - 1) * stride + (a.max_dy - a.min_dy) + 1;
+            if (a.imgs > 127 || a.PR >= 256 || a.PC >= 256) continue;
+            for (int KC = Cin; KC >= 4; KC -= 4) {
+                if (Cin % KC) continue;
+                if (pass == 0 && KC < std::min(20, Cin)) break;
+                a.KC = KC; a.CP = wg_cp(KC, stride);
+                const size_t bytes = (size_t)a.KP * 4 + (size_t)a.KP * a.DP * 4 + (size_t)a.imgs * a.PR * a.PC * a.CP * 4;
+                const bool fits = (pass == 0 ? bytes <= kLdsTarget : bytes <= kLdsLimit - 1024) &&
+                                  a.imgs * a.PR * a.PC * (KC / 4) <= 256 * kPatchPF;
+                if (fits) { p->lds_bytes = bytes; found = true; break; }
+            }
         }
-        a.PC = (Wo - 1) * stride + (a.max_dx - a.min_dx) + 1;
-        int rows_l = (a.imgs == 1 && LP >= KPmax) ? std::min(Ho, (KPmax + Wo - 2) / Wo + 1) : Ho;
-        a.PR = (rows_l - 1) * stride + (a.max_dy - a.min_dy) + 1;
-        int KC = Cin;
-        size_t bytes = 0;
-        for (;;) {
-            a.KC = KC; a.CP = wg_cp(KC, stride);
-            bytes = (size_t)a.KP * 4 + (size_t)a.KP * a.DP * 4 + (size_t)a.imgs * a.PR * a.PC * a.CP * 4;
-            if (bytes <= kLdsTarget) break;
-            if (KC % 8 == 0 && Cin % (KC / 2) == 0 && KC / 2 >= 4) KC /= 2; else break;
-        }
-        if (bytes > kLdsLimit - 1024) {
-            if (KPmax > 32) { KPmax /= 2; continue; }
-            set_error("plan_wgrad: tile needs %zu B of LDS", bytes);
-            return OCL_ERR_ARG;
-        }
-        p->lds_bytes = bytes;
-        break;
+    }
+    if (!found) {
+        set_error("plan_wgrad: no pixel tile fits the LDS (Hin=%d Win=%d Cin=%d Cout=%d)", Hin, Win, Cin, Cout);
+        return OCL_ERR_ARG;
     }
     a.nchunks = Cin / a.KC;
     a.Mchunk = a.ntaps * a.KC;
+    {   // patch prefetch walk: 256 units = d_row rows + d_pc pixels + d_c4 float4s
+        const int kc4 = a.KC / 4;
+        a.d_c4 = 256 % kc4;
+        const int d_pix = 256 / kc4;
+        a.d_pc = d_pix % a.PC;
+        a.d_row = d_pix / a.PC;
+        a.inv_PR = 1.0f / (float)a.PR;
+    }
     const int mtiles = cdiv(a.Mchunk, 16);
     a.total_tiles = cdiv(N, a.imgs) * a.tiles_per_img;
     // Block tile (64*MTW rows) and pixel split S: aim at >= 384 workgroups (1.5 per CU) with the largest tile that
@@ -916,7 +973,7 @@ int plan_wgrad(int N, int Hin, int Win, int Cin, int Ho, int Wo, int Cout, int k
 }
 
 int launch_wgrad(const WgradPlan& p, hipStream_t s) {
-    wgrad_fn_t fn = wgrad_fn(p.MTW, p.NTW);
+    wgrad_fn_t fn = wgrad_fn(p.MTW, p.NTW, wgrad_pf_for(p.a.imgs * p.a.PR * p.a.PC * (p.a.KC / 4)));
     if (!fn) {
         set_error("launch_wgrad: no kernel for MTW=%d NTW=%d", p.MTW, p.NTW);
         return OCL_ERR_STATE;
@@ -1361,7 +1418,8 @@ int conv_kernels_init() {
                     OCL_HIP(hipFuncSetAttribute((const void*)conv_fn(m, n, pf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     for (int m = 1; m <= 4; ++m)
         for (int n = 1; n <= 5; ++n)
-            OCL_HIP(hipFuncSetAttribute((const void*)wgrad_fn(m, n), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+            for (int pf = 4; pf <= 8; pf += 4)
+                OCL_HIP(hipFuncSetAttribute((const void*)wgrad_fn(m, n, pf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     done = true;
     return OCL_OK;
 }

@@ -8,6 +8,47 @@ import torch
 from . import ffi
 
 
+class _PinnedRing(object):
+    """Small host->device uploads (index vectors, augmentation parameters) without stalling the host: a pageable-memory
+    `.to(device)` blocks until the stream has drained, which serialises the host bookkeeping of step i+1 behind the GPU
+    work of step i.  Each upload goes through one slot of a ring of pinned buffers and an asynchronous copy; a slot is
+    reused only after the event recorded behind its copy has completed."""
+
+    def __init__(self, slots=64, slot_bytes=1 << 16):
+        self.slots, self.slot_bytes = slots, slot_bytes
+        self.bufs, self.events, self.i = None, [None] * slots, 0
+
+    def upload(self, t, device):
+        nbytes = t.numel() * t.element_size()
+        if nbytes == 0 or nbytes > self.slot_bytes:
+            return t.to(device)
+        if self.bufs is None:
+            self.bufs = [torch.empty(self.slot_bytes, dtype=torch.uint8).pin_memory() for _ in range(self.slots)]
+        k = self.i
+        self.i = (k + 1) % self.slots
+        if self.events[k] is not None:
+            self.events[k].synchronize()
+        stage = self.bufs[k][:nbytes].view(t.dtype).view(t.shape)
+        stage.copy_(t)
+        d = stage.to(device, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[k] = ev
+        return d
+
+
+_ring = _PinnedRing()
+
+
+def upload(t, device):
+    """Asynchronous upload of a small CPU tensor (or numpy array) to `device`."""
+    if not torch.is_tensor(t):
+        t = torch.from_numpy(t)
+    if t.is_cuda:
+        return t
+    return _ring.upload(t.contiguous(), device)
+
+
 def _f32(t):
     if t.dtype != torch.float32 or not t.is_cuda:
         raise RuntimeError("expected a float32 tensor on the GPU, got %s on %s" % (t.dtype, t.device))

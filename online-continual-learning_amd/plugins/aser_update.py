@@ -113,8 +113,8 @@ class ASER_update(object):
                                                  new_y=y_upt_host, ind=ind_buffer.tolist(), device=self.device)
         if ind_buffer.numel():
             dev = buffer.buffer_img.device
-            ind_cur_dev = ind_cur.to(dev)
-            ind_buffer_dev = ind_buffer.to(dev)
+            ind_cur_dev = ops.upload(ind_cur, dev)
+            ind_buffer_dev = ops.upload(ind_buffer, dev)
             ops.scatter_rows(buffer.buffer_img, ind_buffer_dev, ops.gather_rows(cur_x, ind_cur_dev))
             ops.scatter_rows(buffer.buffer_label, ind_buffer_dev, ops.gather_rows(cur_y, ind_cur_dev))
             buffer.label_host[ind_buffer.numpy()] = y_upt_host

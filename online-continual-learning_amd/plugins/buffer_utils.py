@@ -28,7 +28,7 @@ def random_retrieve(buffer, num_retrieve, excl_indices=None, return_indices=Fals
     indices = torch.from_numpy(np.random.choice(valid_indices, num_retrieve, replace=False)).long()
 
     debug.emit("random_retrieve", indices=indices.numpy().copy())
-    idx_dev = indices.to(buffer.buffer_img.device)
+    idx_dev = ops.upload(indices, buffer.buffer_img.device)
     x = ops.gather_rows(buffer.buffer_img, idx_dev)
     y = ops.gather_rows(buffer.buffer_label, idx_dev)
     y.host = buffer.label_host[indices.numpy()] if num_retrieve else np.zeros(0, dtype=np.int64)
@@ -73,7 +73,7 @@ class ClassBalancedRandomSampling:
                 ind = torch.tensor(list(valid_ind), dtype=torch.long)[perm_ind][:n_smp_cls]
                 sample_ind = torch.cat((sample_ind, ind))
 
-        idx_dev = sample_ind.to(buffer_x.device)
+        idx_dev = ops.upload(sample_ind, buffer_x.device)
         x = ops.gather_rows(buffer_x, idx_dev)
         y = ops.gather_rows(buffer_y, idx_dev)
         if label_host is not None:

@@ -61,8 +61,8 @@ class Reservoir_update(object):
         keys = list(idx_map.keys())
         vals = list(idx_map.values())
         dev = buffer.buffer_img.device
-        keys_dev = torch.tensor(keys, dtype=torch.long).to(dev)
-        vals_dev = torch.tensor(vals, dtype=torch.long).to(dev)
+        keys_dev = ops.upload(torch.tensor(keys, dtype=torch.long), dev)
+        vals_dev = ops.upload(torch.tensor(vals, dtype=torch.long), dev)
         # perform overwrite op
         ops.scatter_rows(buffer.buffer_img, keys_dev, ops.gather_rows(x.contiguous(), vals_dev))
         ops.scatter_rows(buffer.buffer_label, keys_dev, ops.gather_rows(y.contiguous(), vals_dev))
