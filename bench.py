@@ -75,6 +75,18 @@ def flops_per_step(workload, hw, n_classes_in_buffer=100):
     return gemm, wgrad
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r1_scr_pmc_traffic.json: FETCH_SIZE
+    and WRITE_SIZE collected in separate --pmc runs of this same command, gfx950 FETCH_SIZE correction applied there);
+    null when the profile is not shipped.  Counters cannot be read live from inside the process."""
+    path = os.path.join(ROOT, "profiles", "r1_scr_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def build_agent(workload, seed, device):
     import ocl_amd  # noqa: F401
     from ocl_amd import name_match
@@ -149,7 +161,7 @@ def gpu_leg(args, rank, world, local):
             achieved=(gemm_fl * n_prof / (g["ms"] * 1e-3) / 1e12) if g["ms"] > 0 else None,
             peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
             frac=(gemm_fl * n_prof / (g["ms"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if g["ms"] > 0 else None,
-            traffic=None,
+            traffic=pmc_traffic("conv_gemm_kernel"),
             avg_launch_us=(g["ms"] * 1e3 / g["launches"]) if g["launches"] else None, launches_per_step=g["launches"] / n_prof,
             algorithmic_gflop_per_step=gemm_fl / 1e9,
             wgrad=dict(achieved=(wgrad_fl * n_prof / (wg["ms"] * 1e-3) / 1e12) if wg["ms"] > 0 else None,

@@ -499,7 +499,11 @@ int plan_conv(const ConvGeomDesc& g, ConvPlan* p) {
         const int LPx = g.LH * g.LW;
         const int64_t tiles64 = (int64_t)g.groups * (LPx >= 64 ? (int64_t)(g.N / g.groups) * cdiv(LPx, 64)
                                                                 : cdiv(g.N / g.groups, std::max(1, 64 / LPx)));
-        const int pref_nt = std::min(3, ntiles16), pref_mt = tiles64 >= 512 ? 2 : 1;
+        // small problems (replay batches of 10-20 images): latency-bound, the serial MFMA chain of a wave is what counts:
+        // narrower column blocks until there are >= 128 workgroups
+        int pref_nt = std::min(3, ntiles16);
+        while (pref_nt > 1 && tiles64 * cdiv(ntiles16, pref_nt) < 128) --pref_nt;
+        const int pref_mt = tiles64 >= 512 ? 2 : 1;
         double best = 1e30;
         const int MTs[3] = {1, 2, 4};
         for (int mi = 0; mi < 3; ++mi)

@@ -77,6 +77,23 @@ class _EngineMixin:
         self._slot_gen = {}
         self._anchor = None
 
+    # ---- train()/eval(): the engine only looks at the root module's flag; nn.Module.train() walks all ~60 container
+    # modules through __setattr__ (~1 ms per toggle, and ASER toggles six times per step: utils/utils.py:45-90).  The
+    # flags of the children are still kept in step (state is observable), through their __dict__.
+    def train(self, mode=True):
+        if not isinstance(mode, bool):
+            raise ValueError("training mode is expected to be boolean")
+        mods = self.__dict__.get("_all_modules_cache")
+        if mods is None:
+            mods = list(self.modules())
+            self.__dict__["_all_modules_cache"] = mods
+        for m in mods:
+            m.__dict__["training"] = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
     # ---- lazy binding --------------------------------------------------------------------------------------
     def _ensure_bound(self, device=None):
         if self._net is not None:
@@ -358,3 +375,9 @@ class SupConResNet(nn.Module, _EngineMixin):
 
     def features(self, x):
         return self._features(x)
+
+
+# nn.Module precedes the mixin in the MRO: install the fast train()/eval() explicitly
+for _cls in (ResNet, SupConResNet):
+    _cls.train = _EngineMixin.train
+    _cls.eval = _EngineMixin.eval
