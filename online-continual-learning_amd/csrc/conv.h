@@ -53,7 +53,7 @@ struct ConvArgs {
 
 struct ConvPlan {
     ConvArgs a;
-    int MT, NT;
+    int W, MT, NT;              // MFMA tile width (16: 16x16x4, 32: 32x32x2) and tiles per wave
     int grid_x, grid_y;
     size_t lds_bytes;
 };
@@ -67,7 +67,7 @@ struct ConvGeomDesc {
     int ntaps;
     int tdy[9], tdx[9], tw[9];
     int WP;                     // weight pack row stride (0: the plan's own CoutP)
-    int force_MT, force_NT, force_bpc;   // 0 = planner's choice (benchmarks / tests)
+    int force_W, force_MT, force_NT, force_bpc;   // 0 = planner's choice (benchmarks / tests)
 };
 
 int plan_conv(const ConvGeomDesc& g, ConvPlan* p);

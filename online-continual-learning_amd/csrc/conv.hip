@@ -56,17 +56,25 @@ __device__ __forceinline__ int tap_sel(const int (&tab)[9], int t) {
 //   patch stage  = (tile, channel chunk): the input patch is fetched into REGISTERS one patch stage ahead and written
 //                  to LDS after the consumers of the previous patch have passed a barrier;
 //   weight stage = TG taps of a chunk: double-buffered in LDS, fetched into registers one weight stage ahead.
-constexpr int kPatchPF = 8;     // max float4 patch-prefetch registers per thread (planner: patch units <= 256*kPatchPF)
+constexpr int kPatchPF = 8;     // max float4 patch-prefetch registers per thread of the wgrad kernels
+constexpr int kConvPatchPF = 8;  // ... of the conv kernels (planner: patch units <= 256*kConvPatchPF)
 
 struct TileGeom {
     int grp, img0, p0, ly0, nrows, grp_end;
 };
 
-template <int MT, int NT, int PF>   // PF: float4 patch-prefetch registers per thread (patch units <= 256*PF)
+// W = 16: v_mfma_f32_16x16x4_f32 (wave tile 16*MT x 16*NT, 4 channels per MFMA);
+// W = 32: v_mfma_f32_32x32x2_f32 (wave tile 32*MT x 32*NT, 2 channels per MFMA).  On MI355X the 32x32x2 form issues at
+// its nominal 64 cycles (146-155 TF/s in kbench's register-only stream) while 16x16x4 sustains only ~40-50 cycles per
+// instruction instead of 32 (99-134 TF/s): profiles/r1_mfma_peak_calibration.txt.  W = 32 is used wherever the output
+// channel count pads well to 32 and there are enough pixels for 128-row tiles.
+template <int W, int MT, int NT, int PF>   // PF: float4 patch-prefetch registers per thread (patch units <= 256*PF)
 __global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    constexpr int BM = 64 * MT;
-    constexpr int BN = 16 * NT;
+    constexpr int BM = 4 * W * MT;
+    constexpr int BN = W * NT;
+    constexpr int NR = W == 16 ? 4 : 16;            // accumulator registers per MFMA tile
+    typedef float accv __attribute__((ext_vector_type(NR)));
     constexpr int Q = BN / 4;                       // float4 per weight row
     constexpr int CS = BN + 4;                      // row stride of the epilogue tile: 4*CS = 16 (mod 32) -> conflict-free
     int* tapw = (int*)lds_raw;                      // [16] weight-pack index of each tap
@@ -76,7 +84,7 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs a) {
     float* ct = wl;                                 // epilogue alias: output tile [BM][CS] (+ fp64 stat scratch)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r16 = lane & 15, g = lane >> 4;
+    const int r16 = lane & (W - 1), g = lane / W;   // row/column inside the MFMA tile, k slot (0..3 / 0..1)
     const int n0 = blockIdx.y * BN;
     const int LP = a.LH * a.LW;
     const int ntiles = a.groups * a.tiles_per_group;
@@ -191,7 +199,7 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs a) {
     };
 
     const float inv_ppi = 1.0f / (float)a.ppi, inv_lw = 1.0f / (float)a.LW;
-    const int bbase = g * a.BNP + r16;
+    const int bbase = (W == 16 ? g : 2 * g) * a.BNP + r16;
     const int nchunks = a.Cin / a.KC;
     const int flags = a.flags;
     double run1 = 0.0, run2 = 0.0;   // threads < BN: running BatchNorm sums of channel n0+tid over this block's tiles
@@ -234,14 +242,16 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             int po, oo;
-            decode(wave * 16 * MT + mt * 16 + r16, po, oo);
-            abase[mt] = po + g;
+            decode(wave * W * MT + mt * W + r16, po, oo);
+            abase[mt] = po + (W == 16 ? g : 2 * g);   // W = 32: lane half g owns channels {2g, 2g+1} of each group of 4
         }
-        f32x4 acc[MT][NT];
+        accv acc[MT][NT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int r = 0; r < NR; ++r) acc[mt][nt][r] = 0.f;
 
         for (int chunk = 0; chunk < nchunks; ++chunk) {
             const int c0 = chunk * a.KC;
@@ -259,28 +269,54 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs a) {
                 for (int tt = 0; tt < tcnt; ++tt) {
                     const float* pa = patch + tap_sel(a.tpo, t0 + tt);
                     const float* pb = wbase + tt * a.KC * a.BNP;
-                    auto ksteps = [&](int s, auto UC) __attribute__((always_inline)) {
+                    // one group = 4 input channels: W = 16 one MFMA (k = lane>>4), W = 32 two MFMAs (lane half g
+                    // multiplies channels 2g then 2g+1; the A pair is one 8-byte LDS read, conflict-free for CP = 2 mod 4)
+                    auto kgroups = [&](int s, auto UC) __attribute__((always_inline)) {
                         constexpr int U = decltype(UC)::value;
-                        float av[U][MT], bv[U][NT];
+                        if constexpr (W == 16) {
+                            float av[U][MT], bv[U][NT];
 #pragma unroll
-                        for (int u = 0; u < U; ++u) {
+                            for (int u = 0; u < U; ++u) {
 #pragma unroll
-                            for (int mt = 0; mt < MT; ++mt) av[u][mt] = pa[abase[mt] + s + 4 * u];
+                                for (int mt = 0; mt < MT; ++mt) av[u][mt] = pa[abase[mt] + s + 4 * u];
 #pragma unroll
-                            for (int nt = 0; nt < NT; ++nt) bv[u][nt] = pb[(s + 4 * u) * a.BNP + nt * 16];
+                                for (int nt = 0; nt < NT; ++nt) bv[u][nt] = pb[(s + 4 * u) * a.BNP + nt * 16];
+                            }
+#pragma unroll
+                            for (int u = 0; u < U; ++u)
+#pragma unroll
+                                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                                    for (int nt = 0; nt < NT; ++nt)
+                                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][mt], bv[u][nt], acc[mt][nt], 0, 0, 0);
+                        } else {
+                            float2 av[U][MT];
+                            float bv[U][NT][2];
+#pragma unroll
+                            for (int u = 0; u < U; ++u) {
+#pragma unroll
+                                for (int mt = 0; mt < MT; ++mt) av[u][mt] = *(const float2*)(pa + abase[mt] + s + 4 * u);
+#pragma unroll
+                                for (int nt = 0; nt < NT; ++nt) {
+                                    bv[u][nt][0] = pb[(s + 4 * u) * a.BNP + nt * 32];
+                                    bv[u][nt][1] = pb[(s + 4 * u + 1) * a.BNP + nt * 32];
+                                }
+                            }
+#pragma unroll
+                            for (int u = 0; u < U; ++u)
+#pragma unroll
+                                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                                    for (int nt = 0; nt < NT; ++nt) {
+                                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][mt].x, bv[u][nt][0], acc[mt][nt], 0, 0, 0);
+                                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][mt].y, bv[u][nt][1], acc[mt][nt], 0, 0, 0);
+                                    }
                         }
-#pragma unroll
-                        for (int u = 0; u < U; ++u)
-#pragma unroll
-                            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                                for (int nt = 0; nt < NT; ++nt)
-                                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][mt], bv[u][nt], acc[mt][nt], 0, 0, 0);
                     };
-                    if (a.KU == 5) {
-                        for (int s = 0; s < a.KC; s += 20) ksteps(s, std::integral_constant<int, 5>());
+                    if (W == 16 && a.KU == 5) {   // 16x16x4: five groups in flight; 32x32x2 (64-cycle MFMAs): one is enough
+                        for (int s = 0; s < a.KC; s += 20) kgroups(s, std::integral_constant<int, 5>());
                     } else {
-                        for (int s = 0; s < a.KC; s += 4) ksteps(s, std::integral_constant<int, 1>());
+                        for (int s = 0; s < a.KC; s += 4) kgroups(s, std::integral_constant<int, 1>());
                     }
                 }
             };
@@ -308,13 +344,14 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int reg = 0; reg < 4; ++reg) {
-                const int row = wave * 16 * MT + mt * 16 + g * 4 + reg;
+            for (int reg = 0; reg < NR; ++reg) {
+                // D layout: column = lane % W; row = 4*(lane / W) + reg (16x16), 8*(reg/4) + 4*(lane / 32) + reg%4 (32x32)
+                const int row = wave * W * MT + mt * W + (W == 16 ? g * 4 + reg : (reg >> 2) * 8 + g * 4 + (reg & 3));
                 const bool valid = rowoff[row] >= 0;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const float v = acc[mt][nt][reg];
-                    ct[row * CS + nt * 16 + r16] = v;
+                    ct[row * CS + nt * W + r16] = v;
                     if (valid) {
                         s1[nt] += v;
                         s2[nt] = fmaf(v, v, s2[nt]);
@@ -326,13 +363,15 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs a) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 double x = (double)s1[nt], y = (double)s2[nt];
-                x += __shfl_xor(x, 16, 64);
+                if (W == 16) {
+                    x += __shfl_xor(x, 16, 64);
+                    y += __shfl_xor(y, 16, 64);
+                }
                 x += __shfl_xor(x, 32, 64);
-                y += __shfl_xor(y, 16, 64);
                 y += __shfl_xor(y, 32, 64);
                 if (g == 0) {
-                    red[(wave * 2 + 0) * BN + nt * 16 + r16] = x;
-                    red[(wave * 2 + 1) * BN + nt * 16 + r16] = y;
+                    red[(wave * 2 + 0) * BN + nt * W + r16] = x;
+                    red[(wave * 2 + 1) * BN + nt * W + r16] = y;
                 }
             }
         }
@@ -390,20 +429,21 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs a) {
 }
 
 typedef void (*conv_fn_t)(const ConvArgs);
-// instantiated tilings (chosen from the kbench sweeps, profiles/): (MT, NT) x patch-prefetch depth {4, 8}
-#define OCL_CONV_TILINGS(X) X(1, 1) X(1, 2) X(1, 3) X(1, 5) X(2, 1) X(2, 2) X(2, 3) X(4, 2)
-static conv_fn_t conv_fn(int MT, int NT, int PF) {
-#define OCL_CASE(M, N)                                                  \
-    if (MT == M && NT == N) {                                           \
-        if (PF == 4) return conv_gemm_kernel<M, N, 4>;                  \
-        if (PF == 6) return conv_gemm_kernel<M, N, 6>;                  \
-        if (PF == 8) return conv_gemm_kernel<M, N, 8>;                  \
+// instantiated tilings (chosen from the kbench sweeps, profiles/): MFMA width x (MT, NT) x patch-prefetch depth
+#define OCL_CONV_TILINGS16(X) X(16, 1, 1) X(16, 1, 2) X(16, 1, 3) X(16, 1, 5) X(16, 2, 1) X(16, 2, 2) X(16, 2, 3) X(16, 4, 2)
+#define OCL_CONV_TILINGS32(X) X(32, 1, 1) X(32, 1, 2) X(32, 1, 3) X(32, 2, 1) X(32, 2, 2)
+static conv_fn_t conv_fn(int W, int MT, int NT, int PF) {
+#define OCL_CASE(WW, M, N)                                                  \
+    if (W == WW && MT == M && NT == N) {                                    \
+        if (PF == 4) return conv_gemm_kernel<WW, M, N, 4>;                  \
+        if (PF == 8) return conv_gemm_kernel<WW, M, N, 8>;                  \
     }
-    OCL_CONV_TILINGS(OCL_CASE)
+    OCL_CONV_TILINGS16(OCL_CASE)
+    OCL_CONV_TILINGS32(OCL_CASE)
 #undef OCL_CASE
     return nullptr;
 }
-static int conv_pf_for(int units) { return units <= 1024 ? 4 : units <= 1536 ? 6 : 8; }
+static int conv_pf_for(int units) { return units <= 1024 ? 4 : 8; }
 
 static int bnp_for(int bn) {  // LDS weight row stride with (stride mod 32) == 16: B reads conflict-free
     int p = bn;
@@ -412,23 +452,24 @@ static int bnp_for(int bn) {  // LDS weight row stride with (stride mod 32) == 1
 }
 
 // LDS bytes of a tile: row table + max(main loop: 2 weight stages + patch, epilogue: output tile + fp64 stat scratch)
-static size_t conv_lds_bytes(const ConvArgs& a, int BM, int NT) {
+static size_t conv_lds_bytes(const ConvArgs& a, int BM, int BN) {
     const size_t w_b = (size_t)2 * a.WS * 4;
     const size_t main_b = w_b + (size_t)a.imgs * a.PR * a.PC * a.CP * 4;
-    const size_t epi_b = (size_t)BM * (16 * NT + 4) * 4 + (size_t)8 * 16 * NT * 8;
+    const size_t epi_b = (size_t)BM * (BN + 4) * 4 + (size_t)8 * BN * 8;
     return (size_t)64 + (size_t)BM * 4 + std::max(main_b, epi_b);
 }
 
 // Fills the tile-dependent fields of `a` for a given (MT, NT); returns the LDS bytes (0 = does not fit).
-static size_t conv_tile_layout(const ConvGeomDesc& g, ConvArgs& a, int MT, int NT) {
-    const int ntiles16 = cdiv(g.Cout, 16);
-    const int splits = cdiv(ntiles16, NT);
+static size_t conv_tile_layout(const ConvGeomDesc& g, ConvArgs& a, int W, int MT, int NT) {
+    const int ntilesW = cdiv(g.Cout, W);
+    const int splits = cdiv(ntilesW, NT);
+    const int BN = W * NT;
     a.n_splits = splits;
-    a.CoutP = splits * NT * 16;
-    a.BNP = bnp_for(NT * 16);
+    a.CoutP = splits * BN;
+    a.BNP = W == 16 ? bnp_for(BN) : BN;     // 32-wide B reads: 32 consecutive floats per lane half, any row stride
     a.group_size = g.N / g.groups;
     const int LP = g.LH * g.LW;
-    const int BM = 64 * MT;
+    const int BM = 4 * W * MT;
     if (LP >= BM) {
         a.imgs = 1; a.ppi = BM; a.tiles_per_img = cdiv(LP, BM);
     } else {
@@ -442,29 +483,37 @@ static size_t conv_tile_layout(const ConvGeomDesc& g, ConvArgs& a, int MT, int N
     size_t bytes = 0;
     for (;;) {
         a.KC = KC; a.CP = KC + 2;
-        int TG = std::max(1, std::min(g.ntaps, kMaxStageFloats / (KC * a.BNP)));
-        if (KC * a.BNP > kMaxStageFloats) TG = 0;   // a single tap does not fit one stage: shrink the chunk
-        if (TG > 0) {
-            a.TG = TG;
-            a.gpc = cdiv(g.ntaps, TG);
-            a.TG = cdiv(g.ntaps, a.gpc);            // balance the groups (9 taps: 5+4, 3x3, ...)
-            a.WS = (int)round_up(a.TG * KC * a.BNP, 4);
-            bytes = conv_lds_bytes(a, BM, NT);
-            if (bytes <= kLdsTarget && a.imgs * a.PR * a.PC * (KC / 4) <= 256 * kPatchPF) break;
+        bool ok = false;
+        if (KC * a.BNP <= kMaxStageFloats) {
+            // largest balanced tap group (fewest weight stages per chunk) that fits: 9 taps as 9, 5+4, 3x3, ..., 1x9
+            for (int gpc = 1; gpc <= g.ntaps; ++gpc) {
+                const int TG = cdiv(g.ntaps, gpc);
+                if (TG * KC * a.BNP > kMaxStageFloats) continue;
+                a.TG = TG;
+                a.gpc = cdiv(g.ntaps, TG);
+                a.WS = (int)round_up(TG * KC * a.BNP, 4);
+                bytes = conv_lds_bytes(a, BM, BN);
+                if (bytes <= kLdsTarget && a.imgs * a.PR * a.PC * (KC / 4) <= 256 * kConvPatchPF) { ok = true; break; }
+            }
         }
+        if (ok) break;
         // next smaller channel chunk: the largest divisor of Cin below KC that is a multiple of 4
         int nk = 0;
         for (int d = KC - 4; d >= 4; d -= 4)
             if (g.Cin % d == 0) { nk = d; break; }
-        if (nk) KC = nk;
-        else if (TG > 0) break;
-        else return 0;
+        if (nk) { KC = nk; continue; }
+        if (KC * a.BNP <= kMaxStageFloats) {   // nothing meets the 2-workgroups-per-CU target: single-tap stages, full LDS
+            a.TG = 1; a.gpc = g.ntaps; a.WS = (int)round_up(KC * a.BNP, 4);
+            bytes = conv_lds_bytes(a, BM, BN);
+            break;
+        }
+        return 0;
     }
-    while ((bytes > kLdsLimit - 1024 || a.imgs * a.PR * a.PC * (a.KC / 4) > 256 * kPatchPF) && a.imgs > 1) {
+    while ((bytes > kLdsLimit - 1024 || a.imgs * a.PR * a.PC * (a.KC / 4) > 256 * kConvPatchPF) && a.imgs > 1) {
         a.imgs -= 1;   // shrink the tile (fewer images per block)
-        bytes = conv_lds_bytes(a, BM, NT);
+        bytes = conv_lds_bytes(a, BM, BN);
     }
-    if (bytes > kLdsLimit - 1024 || a.imgs * a.PR * a.PC * (a.KC / 4) > 256 * kPatchPF) return 0;
+    if (bytes > kLdsLimit - 1024 || a.imgs * a.PR * a.PC * (a.KC / 4) > 256 * kConvPatchPF) return 0;
     if (a.imgs > 127 || a.PR >= 256 || a.PC >= 256 || a.KC / 4 >= 256) return 0;   // packed (il, pr, pc, c4) prefetch bookkeeping
     a.tiles_per_group = cdiv(a.group_size, a.imgs) * a.tiles_per_img;
     return bytes;
@@ -489,41 +538,52 @@ int plan_conv(const ConvGeomDesc& g, ConvPlan* p) {
         a.min_dx = std::min(a.min_dx, g.tdx[t]); a.max_dx = std::max(a.max_dx, g.tdx[t]);
     }
     // ---- tile choice ---------------------------------------------------------------------------------------------
-    // Rule distilled from the kbench sweeps on MI355X (profiles/r1_kbench_conv_sweep.txt): 48 output channels per
-    // workgroup (NT = 3, or all of them when Cout <= 32), 128-pixel tiles (MT = 2) once there are >= 512 64-pixel
-    // tiles, else 64; persistent grid of two workgroups per CU (their barrier bubbles overlap).  Anything that does
-    // not fit the LDS / prefetch-register budget falls back to the nearest tiling that does.
-    const int ntiles16 = cdiv(g.Cout, 16);
-    int bestMT = 0, bestNT = 0, bestG = 0;
+    // Rules distilled from the kbench sweeps on MI355X (profiles/r1_kbench_conv_sweep*.txt):
+    //  * enough pixels for 128-row tiles -> 32x32x2 MFMA (W = 32), all output channels of a 32/64/96-wide block per
+    //    workgroup; else 16x16x4 with 48-channel blocks (NT = 3), 128-pixel tiles once there are >= 512 64-pixel tiles;
+    //  * small problems (replay batches of 10-20 images) are latency-bound on a wave's serial MFMA chain: narrower
+    //    column blocks until there are >= 128 workgroups;
+    //  * persistent grid of two workgroups per CU.  Whatever does not fit the LDS / prefetch-register budget falls back
+    //    to the nearest tiling that does.
+    int bestW = 0, bestMT = 0, bestNT = 0, bestG = 0;
     {
         const int LPx = g.LH * g.LW;
         const int64_t tiles64 = (int64_t)g.groups * (LPx >= 64 ? (int64_t)(g.N / g.groups) * cdiv(LPx, 64)
                                                                 : cdiv(g.N / g.groups, std::max(1, 64 / LPx)));
-        // small problems (replay batches of 10-20 images): latency-bound, the serial MFMA chain of a wave is what counts:
-        // narrower column blocks until there are >= 128 workgroups
-        int pref_nt = std::min(3, ntiles16);
-        while (pref_nt > 1 && tiles64 * cdiv(ntiles16, pref_nt) < 128) --pref_nt;
-        const int pref_mt = tiles64 >= 512 ? 2 : 1;
+        const int nt16 = cdiv(g.Cout, 16), nt32 = cdiv(g.Cout, 32);
+        int pref_w = (g.Cout <= 32 && tiles64 >= 1024) ? 32 : 16;   // sweep: 32x32x2 wins only where 20 channels pad to 32 anyway
+        if (g.force_W) pref_w = g.force_W;
+        int pref_nt, pref_mi;
+        if (pref_w == 32) {
+            pref_nt = nt32 <= 3 ? nt32 : (nt32 % 2 == 0 ? 2 : 1);     // 160 channels: five 32-wide blocks
+            pref_mi = 0;
+        } else {
+            pref_nt = std::min(3, nt16);
+            while (pref_nt > 1 && tiles64 * cdiv(nt16, pref_nt) < 128) --pref_nt;
+            pref_mi = tiles64 >= 512 ? 1 : 0;
+        }
         double best = 1e30;
         const int MTs[3] = {1, 2, 4};
-        for (int mi = 0; mi < 3; ++mi)
-            for (int NT = 1; NT <= 5; ++NT) {
-                const int MT = MTs[mi];
-                if (g.force_MT && MT != g.force_MT) continue;
-                if (g.force_NT && NT != g.force_NT) continue;
-                if (!conv_fn(MT, NT, 8)) continue;
-                if (NT > ntiles16) continue;
-                ConvArgs t = a;
-                const size_t lds = conv_tile_layout(g, t, MT, NT);
-                if (!lds) continue;
-                // distance from the preferred tiling; shallow channel chunks (many patch stages) are penalised
-                const double cost = std::abs(NT - pref_nt) * 1.0 + std::abs(mi - (pref_mt == 2 ? 1 : 0)) * 1.5 +
-                                    (g.Cin / t.KC - 1) * 0.4 + (t.KC < std::min(20, g.Cin) ? 3.0 : 0.0);
-                if (cost < best) { best = cost; bestMT = MT; bestNT = NT; }
-            }
+        for (int W = 16; W <= 32; W += 16)
+            for (int mi = 0; mi < 3; ++mi)
+                for (int NT = 1; NT <= 5; ++NT) {
+                    const int MT = MTs[mi];
+                    if (g.force_W && W != g.force_W) continue;
+                    if (g.force_MT && MT != g.force_MT) continue;
+                    if (g.force_NT && NT != g.force_NT) continue;
+                    if (!conv_fn(W, MT, NT, 8)) continue;
+                    if (NT > cdiv(g.Cout, W)) continue;
+                    ConvArgs t = a;
+                    const size_t lds = conv_tile_layout(g, t, W, MT, NT);
+                    if (!lds) continue;
+                    // distance from the preferred tiling; shallow channel chunks (many patch stages) are penalised
+                    const double cost = (W != pref_w ? 10.0 : 0.0) + std::abs(NT - pref_nt) * 1.0 + std::abs(mi - pref_mi) * 1.5 +
+                                        (g.Cin / t.KC - 1) * 0.4 + (t.KC < std::min(20, g.Cin) ? 3.0 : 0.0);
+                    if (cost < best) { best = cost; bestW = W; bestMT = MT; bestNT = NT; }
+                }
         if (bestMT) {
             ConvArgs t = a;
-            const size_t lds = conv_tile_layout(g, t, bestMT, bestNT);
+            const size_t lds = conv_tile_layout(g, t, bestW, bestMT, bestNT);
             const int ntiles = g.groups * t.tiles_per_group;
             int bpc = (int)std::min<size_t>(2, kLdsLimit / (lds + 512));
             if (g.force_bpc) bpc = g.force_bpc;
@@ -531,7 +591,8 @@ int plan_conv(const ConvGeomDesc& g, ConvPlan* p) {
         }
     }
     OCL_REQUIRE(bestMT > 0, "plan_conv: no tile fits the LDS (Hin=%d Win=%d Cin=%d Cout=%d)", g.Hin, g.Win, g.Cin, g.Cout);
-    p->lds_bytes = conv_tile_layout(g, a, bestMT, bestNT);
+    p->lds_bytes = conv_tile_layout(g, a, bestW, bestMT, bestNT);
+    p->W = bestW;
     a.WP = g.WP > 0 ? g.WP : a.CoutP;
     a.KU = ((a.KC / 4) % 5 == 0) ? 5 : 1;
     for (int t = 0; t < 9; ++t) a.tpo[t] = t < a.ntaps ? ((a.tdy[t] - a.min_dy) * a.PC + (a.tdx[t] - a.min_dx)) * a.CP : 0;
@@ -618,9 +679,9 @@ void geom_dgrad(const ConvShape& c, int N, std::vector<ConvGeomDesc>* out) {
 }
 
 int launch_conv(const ConvPlan& p, hipStream_t s) {
-    conv_fn_t fn = conv_fn(p.MT, p.NT, conv_pf_for(p.a.imgs * p.a.PR * p.a.PC * (p.a.KC / 4)));
+    conv_fn_t fn = conv_fn(p.W, p.MT, p.NT, conv_pf_for(p.a.imgs * p.a.PR * p.a.PC * (p.a.KC / 4)));
     if (!fn) {
-        set_error("launch_conv: no kernel for MT=%d NT=%d", p.MT, p.NT);
+        set_error("launch_conv: no kernel for W=%d MT=%d NT=%d", p.W, p.MT, p.NT);
         return OCL_ERR_STATE;
     }
     ProfScope ps(PROF_CONV, s);
@@ -1415,11 +1476,13 @@ int launch_fill(float* p, int64_t n, float v, hipStream_t s) {
 int conv_kernels_init() {
     static bool done = false;
     if (done) return OCL_OK;
-    for (int m = 1; m <= 4; ++m)
-        for (int n = 1; n <= 5; ++n)
-            for (int pf = 4; pf <= 8; pf += 2)
-                if (conv_fn(m, n, pf))
-                    OCL_HIP(hipFuncSetAttribute((const void*)conv_fn(m, n, pf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+    for (int w = 16; w <= 32; w += 16)
+        for (int m = 1; m <= 4; ++m)
+            for (int n = 1; n <= 5; ++n)
+                for (int pf = 4; pf <= 8; pf += 4)
+                    if (conv_fn(w, m, n, pf))
+                        OCL_HIP(hipFuncSetAttribute((const void*)conv_fn(w, m, n, pf), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                    (int)kLdsLimit));
     for (int m = 1; m <= 4; ++m)
         for (int n = 1; n <= 5; ++n)
             for (int pf = 4; pf <= 8; pf += 4)

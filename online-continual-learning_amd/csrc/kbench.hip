@@ -120,16 +120,18 @@ static void bench_geom(const char* lname, const char* kind, ConvGeomDesc g, cons
     CK(hipMemset(out_ref, 0, out_elems * 4));
     run(p0, out_ref);
     const double t0 = time_us([&] { run(p0, out_ref); });
-    printf("%-20s %-7s M=%7d N=%3d K=%4d  auto MT=%d NT=%d grid=%5dx%d lds=%6zu KC=%3d TG=%d  %7.1f us %6.1f TF/s\n", lname, kind,
-           g.N * g.LH * g.LW, g.Cout, g.ntaps * g.Cin, p0.MT, p0.NT, p0.grid_x, p0.grid_y, p0.lds_bytes, p0.a.KC, p0.a.TG, t0,
+    printf("%-20s %-7s M=%7d N=%3d K=%4d  auto W=%d MT=%d NT=%d grid=%5dx%d lds=%6zu KC=%3d TG=%d  %7.1f us %6.1f TF/s\n", lname, kind,
+           g.N * g.LH * g.LW, g.Cout, g.ntaps * g.Cin, p0.W, p0.MT, p0.NT, p0.grid_x, p0.grid_y, p0.lds_bytes, p0.a.KC, p0.a.TG, t0,
            flops / t0 * 1e-6);
     if (!sweep) return;
     const int MTs[3] = {1, 2, 4};
     const int ntile16 = (g.Cout + 15) / 16;
+    for (int W = 16; W <= 32; W += 16)
     for (int mi = 0; mi < 3; ++mi)
         for (int NT = 1; NT <= std::min(5, ntile16); ++NT)
-          for (int bpc = 1; bpc <= 3; ++bpc) {
+          for (int bpc = 1; bpc <= 2; ++bpc) {
             ConvGeomDesc gf = g;
+            gf.force_W = W;
             gf.force_MT = MTs[mi];
             gf.force_NT = NT;
             gf.force_bpc = bpc;
@@ -139,7 +141,8 @@ static void bench_geom(const char* lname, const char* kind, ConvGeomDesc g, cons
             run(p, out);
             const double d = max_diff(out, out_ref, out_elems);
             const double t = time_us([&] { run(p, out); });
-            printf("    MT=%d NT=%d grid=%5dx%d lds=%6zu KC=%3d TG=%d  %7.1f us %6.1f TF/s  maxdiff=%.2e%s\n", p.MT, p.NT, p.grid_x,
+            if (p.W != W || p.MT != MTs[mi] || p.NT != NT) continue;
+            printf("    W=%d MT=%d NT=%d grid=%5dx%d lds=%6zu KC=%3d TG=%d  %7.1f us %6.1f TF/s  maxdiff=%.2e%s\n", p.W, p.MT, p.NT, p.grid_x,
                    p.grid_y, p.lds_bytes, p.a.KC, p.a.TG, t, flops / t * 1e-6, d, d > 1e-3 ? "  <-- MISMATCH" : "");
         }
 }
@@ -175,6 +178,50 @@ __global__ void __launch_bounds__(256) mfma_peak_kernel(float* out, int iters) {
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+// 32x32x2 variant: lane l holds A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]
+template <int NACC, bool LDS>
+__global__ void __launch_bounds__(256) mfma_peak32_kernel(float* out, int iters) {
+    __shared__ float sm[4096];
+    for (int i = threadIdx.x; i < 4096; i += 256) sm[i] = (float)(i & 7) * 0.125f;
+    __syncthreads();
+    f32x16 acc[NACC];
+#pragma unroll
+    for (int j = 0; j < NACC; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    float a = (float)(threadIdx.x & 3) * 0.25f, b = 1.0f;
+    const int lane = threadIdx.x & 63;
+    for (int i = 0; i < iters; ++i) {
+        if (LDS) {
+            float av[NACC], bv;
+#pragma unroll
+            for (int j = 0; j < NACC; ++j) av[j] = sm[((lane & 31) * 22 + (lane >> 5) + j * 704 + i * 2) & 4095];
+            bv = sm[((lane >> 5) * 48 + (lane & 31) + i * 96) & 4095];
+#pragma unroll
+            for (int j = 0; j < NACC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv, acc[j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NACC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+        }
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NACC; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) s += acc[j][e];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+template <int NACC, bool LDS>
+static void peak32_case(const char* name, int blocks_per_cu, float* out) {
+    const int iters = 2000;
+    const int blocks = 256 * blocks_per_cu;
+    const double t = time_us([&] { hipLaunchKernelGGL((mfma_peak32_kernel<NACC, LDS>), dim3(blocks), dim3(256), 0, 0, out, iters); }, 5, 1);
+    const double flops = (double)blocks * 4 * iters * NACC * 4096.0;
+    printf("peak32x32x2 %-26s acc=%d blocks/CU=%d  %8.1f us  %6.1f TF/s  (%.1f cycles/MFMA/SIMD at 2.4 GHz)\n", name, NACC, blocks_per_cu, t,
+           flops / t * 1e-6, t * 1e-6 * 2.4e9 / ((double)blocks_per_cu * iters * NACC));
+}
+
 template <int NACC, bool LDS>
 static void peak_case(const char* name, int blocks_per_cu, float* out) {
     const int iters = 4000;
@@ -203,9 +250,9 @@ int main(int argc, char** argv) {
             for (size_t i = 0; i < all.size(); ++i) {
                 ConvPlan p;
                 OK(plan_conv(all[i], &p));
-                printf("%-20s %-6s M=%7d N=%3d K=%4d  MT=%d NT=%d grid=%5dx%d lds=%6zu KC=%3d CP=%3d TG=%d gpc=%d WS=%d imgs=%d ppi=%d PR=%d PC=%d\n",
+                printf("%-20s %-6s M=%7d N=%3d K=%4d  W=%d MT=%d NT=%d grid=%5dx%d lds=%6zu KC=%3d CP=%3d TG=%d gpc=%d WS=%d imgs=%d ppi=%d PR=%d PC=%d\n",
                        l.name.c_str(), i == 0 ? "fwd" : "dgrad", all[i].N * all[i].LH * all[i].LW, all[i].Cout, all[i].ntaps * all[i].Cin,
-                       p.MT, p.NT, p.grid_x, p.grid_y, p.lds_bytes, p.a.KC, p.a.CP, p.a.TG, p.a.gpc, p.a.WS, p.a.imgs, p.a.ppi, p.a.PR, p.a.PC);
+                       p.W, p.MT, p.NT, p.grid_x, p.grid_y, p.lds_bytes, p.a.KC, p.a.CP, p.a.TG, p.a.gpc, p.a.WS, p.a.imgs, p.a.ppi, p.a.PR, p.a.PC);
             }
             WgradPlan wp;
             OK(plan_wgrad(N, c.Hin, c.Win, c.CinT, c.Ho, c.Wo, c.Cout, c.k, c.stride, &wp));
@@ -241,6 +288,18 @@ int main(int argc, char** argv) {
         peak_case<4, true>("with ds_read_b32 operands", 2, bufB);
         peak_case<4, true>("with ds_read_b32 operands", 3, bufB);
         peak_case<8, true>("with ds_read_b32 operands", 2, bufB);
+        peak_case<4, true>("with ds_read_b32 operands", 4, bufB);
+        peak_case<6, true>("with ds_read_b32 operands", 3, bufB);
+        peak_case<6, true>("with ds_read_b32 operands", 4, bufB);
+        peak_case<4, false>("regs only", 4, bufB);
+        peak32_case<1, false>("regs only", 1, bufB);
+        peak32_case<2, false>("regs only", 1, bufB);
+        peak32_case<2, false>("regs only", 2, bufB);
+        peak32_case<2, false>("regs only", 3, bufB);
+        peak32_case<2, true>("with ds_read_b32 operands", 1, bufB);
+        peak32_case<2, true>("with ds_read_b32 operands", 2, bufB);
+        peak32_case<2, true>("with ds_read_b32 operands", 3, bufB);
+        peak32_case<3, true>("with ds_read_b32 operands", 2, bufB);
     }
 
     if (mode == "all" || mode == "conv") {
