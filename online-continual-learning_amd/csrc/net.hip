@@ -271,7 +271,8 @@ static int build_layout(ocl_net* n) {
         if (rc != OCL_OK) return rc;
         pmax = std::max<int64_t>(pmax, (int64_t)wp.partial_floats);
     }
-    n->partial_floats = pmax + 1024;
+    // plan_wgrad caps the split-K slabs at 12 MB for every batch size (the split differs per batch): size for the cap
+    n->partial_floats = std::max<int64_t>(pmax, (int64_t)(12ll << 20) / 4 + (1ll << 20)) + 1024;
     n->off_partial = takeb(n->partial_floats * 4);
     int64_t so = 0;
     for (auto& b : n->bns) {
