@@ -40,6 +40,18 @@ __device__ __forceinline__ int fdiv(int u, int d, float inv, int& rem) {
     return q;
 }
 
+// 16-byte buffer load with a 32-bit byte offset; an offset of kOob (>= num_records of every descriptor made by
+// make_rsrc) returns zeros in hardware: no exec-mask branch, no 64-bit address arithmetic, no select on the result.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kOob = 0x7fffffff;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7ffffff0, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, int byte_off) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
 constexpr int kMaxStageFloats = 4096;   // 16 KiB per weight stage buffer -> <= 4 float4 prefetch registers per thread
 
 // value of a small per-tap table at a block-uniform index, without dynamic indexing of the kernel-argument struct
@@ -92,63 +104,24 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs a) {
     if (tid < 9) tapw[tid] = tap_sel(a.tw, tid);
     __syncthreads();
 
+    // tile -> (group, first image, first lattice pixel, ...): divisions by block-uniform plan constants through float
+    // reciprocals (a 32-bit integer division costs ~40 instructions and this runs twice per tile)
+    const float inv_tpg = 1.0f / (float)a.tiles_per_group, inv_tpi = 1.0f / (float)a.tiles_per_img, inv_lw0 = 1.0f / (float)a.LW;
     auto geom = [&](int tile) __attribute__((always_inline)) -> TileGeom {
         TileGeom t;
-        t.grp = tile / a.tiles_per_group;
-        const int tg_ = tile - t.grp * a.tiles_per_group;
-        const int ti = tg_ / a.tiles_per_img;
+        int tg_, tp, rem;
+        t.grp = fdiv(tile, a.tiles_per_group, inv_tpg, tg_);
+        const int ti = fdiv(tg_, a.tiles_per_img, inv_tpi, tp);
         t.img0 = t.grp * a.group_size + ti * a.imgs;
-        t.p0 = (tg_ - ti * a.tiles_per_img) * a.ppi;
+        t.p0 = tp * a.ppi;
         t.grp_end = min(a.N, (t.grp + 1) * a.group_size);
-        t.ly0 = t.p0 / a.LW;
+        t.ly0 = fdiv(t.p0, a.LW, inv_lw0, rem);
         const int pend = min(t.p0 + a.ppi, LP);
-        const int ly1 = (pend - 1) / a.LW;
+        const int ly1 = fdiv(pend - 1, a.LW, inv_lw0, rem);
         // patch rows to stage: one image's used rows, or (imgs > 1: whole images of PR rows) the images inside the group
         t.nrows = a.imgs > 1 ? min(a.imgs, t.grp_end - t.img0) * a.PR : (ly1 - t.ly0) * a.is + (a.max_dy - a.min_dy) + 1;
         return t;
     };
-
-    // ---- weight-stage prefetch bookkeeping: unit u = tid + q*256 -> (tap-in-group, kc, float4 column) -------------
-    const int rows_full = a.TG * a.KC;              // weight rows of a full stage
-    int pf_tg[4], pf_src[4], pf_dst[4];
-    {
-        const float inv_q = 1.0f / (float)Q, inv_kc = 1.0f / (float)a.KC;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int u = tid + q * 256;
-            int q4, kc;
-            const int row = fdiv(u, Q, inv_q, q4);
-            const int tgi = fdiv(row, a.KC, inv_kc, kc);
-            pf_tg[q] = (row < rows_full && n0 + q4 * 4 < a.WP) ? tgi : -1;   // columns past the pack's row stride: never stored
-            pf_src[q] = kc * a.WP + q4 * 4;
-            pf_dst[q] = row * a.BNP + q4 * 4;
-        }
-    }
-    // The four prefetch registers are named variables (not an array): with the nested select chain the array form is
-    // left in scratch memory by the compiler, which serialises every load behind an s_waitcnt.
-    float4 pf0, pf1, pf2, pf3;
-#define OCL_PF_LOAD(Q, REG)                                                                               \
-    {                                                                                                     \
-        const int t = t0_ + pf_tg[Q];                                                                     \
-        const bool ok = pf_tg[Q] >= 0 && t < a.ntaps;                                                     \
-        const int wt = tapw[ok ? t : 0];                                                                  \
-        const float* p = ok ? a.w + ((int64_t)wt * a.Cin + c0_) * a.WP + n0 + pf_src[Q] : a.w;           \
-        REG = *(const float4*)p; /* unconditional (clamped address): no exec-mask branch around the load */ \
-    }
-#define OCL_PF_STORE(Q, REG)                                                           \
-    {                                                                                  \
-        const int t = t0_ + pf_tg[Q];                                                  \
-        if (pf_tg[Q] >= 0 && t < a.ntaps) *(float4*)(dst_ + pf_dst[Q]) = REG;          \
-    }
-    auto prefetch = [&](int t0_, int c0_) __attribute__((always_inline)) {
-        OCL_PF_LOAD(0, pf0) OCL_PF_LOAD(1, pf1) OCL_PF_LOAD(2, pf2) OCL_PF_LOAD(3, pf3)
-    };
-    auto commit = [&](int t0_, int buf) __attribute__((always_inline)) {
-        float* dst_ = wl + buf * a.WS;
-        OCL_PF_STORE(0, pf0) OCL_PF_STORE(1, pf1) OCL_PF_STORE(2, pf2) OCL_PF_STORE(3, pf3)
-    };
-#undef OCL_PF_LOAD
-#undef OCL_PF_STORE
 
     // ---- patch prefetch bookkeeping: this thread's units tid + i*256 of the flat [row][pc][c4] space are the same for
     // every tile; their (il, pr, pc, c4) coordinates are packed into one register each.
@@ -172,17 +145,16 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs a) {
         }
     }
     float4 pv[PF];
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in), rs_w = make_rsrc(a.w);
     auto load_patch = [&](const TileGeom& t, int c0) __attribute__((always_inline)) {
         const int iy0 = t.ly0 * a.is + a.min_dy;
-        const float* base = a.in + ((int64_t)(t.img0 * a.Hin + iy0) * a.Win + a.min_dx) * a.Cin + c0;
+        const int base = (((t.img0 * a.Hin + iy0) * a.Win + a.min_dx) * a.Cin + c0) * 4;   // bytes; may be negative (halo)
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
             const int il = pu_pos[i] >> 24, pr = (pu_pos[i] >> 16) & 255, pc = (pu_pos[i] >> 8) & 255, c4 = pu_pos[i] & 255;
             const int iy = iy0 + pr, ix = a.min_dx + pc;
-            const bool ok = il * a.PR + pr < t.nrows && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-            const float* p = ok ? base + ((il * a.Hin + pr) * a.Win + pc) * a.Cin + c4 * 4 : a.in;   // unconditional load
-            const float4 v = *(const float4*)p;
-            pv[i] = ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = (il * a.PR + pr < t.nrows) & (iy >= 0) & (iy < a.Hin) & (ix >= 0) & (ix < a.Win);   // no short-circuit branches
+            pv[i] = buf_load16(rs_in, ok ? base + (((il * a.Hin + pr) * a.Win + pc) * a.Cin + c4 * 4) * 4 : kOob);
         }
     };
     auto store_patch = [&](const TileGeom& t) __attribute__((always_inline)) {
@@ -197,6 +169,51 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs a) {
             }
         }
     };
+
+    // the first tile's patch is requested before anything else: its latency overlaps the rest of the set-up
+    TileGeom cur = geom(blockIdx.x);
+    load_patch(cur, 0);
+
+    // ---- weight-stage prefetch bookkeeping: unit u = tid + q*256 -> (tap-in-group, kc, float4 column) -------------
+    const int rows_full = a.TG * a.KC;              // weight rows of a full stage
+    int pf_tg[4], pf_src[4], pf_dst[4];
+    {
+        const float inv_q = 1.0f / (float)Q, inv_kc = 1.0f / (float)a.KC;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int u = tid + q * 256;
+            int q4, kc;
+            const int row = fdiv(u, Q, inv_q, q4);
+            const int tgi = fdiv(row, a.KC, inv_kc, kc);
+            pf_tg[q] = (row < rows_full && n0 + q4 * 4 < a.WP) ? tgi : -1;   // columns past the pack's row stride: never stored
+            pf_src[q] = kc * a.WP + q4 * 4;
+            pf_dst[q] = row * a.BNP + q4 * 4;
+        }
+    }
+    // The four prefetch registers are named variables (not an array): with the nested select chain the array form is
+    // left in scratch memory by the compiler, which serialises every load behind an s_waitcnt.
+    float4 pf0, pf1, pf2, pf3;
+#define OCL_PF_LOAD(Q, REG)                                                                               \
+    {                                                                                                     \
+        const int t = t0_ + pf_tg[Q];                                                                     \
+        const bool ok = (pf_tg[Q] >= 0) & (t < a.ntaps);                                                  \
+        const int wt = tapw[ok ? t : 0];                                                                  \
+        REG = buf_load16(rs_w, ok ? ((wt * a.Cin + c0_) * a.WP + n0 + pf_src[Q]) * 4 : kOob);             \
+    }
+#define OCL_PF_STORE(Q, REG)                                                           \
+    {                                                                                  \
+        const int t = t0_ + pf_tg[Q];                                                  \
+        if (pf_tg[Q] >= 0 && t < a.ntaps) *(float4*)(dst_ + pf_dst[Q]) = REG;          \
+    }
+    auto prefetch = [&](int t0_, int c0_) __attribute__((always_inline)) {
+        OCL_PF_LOAD(0, pf0) OCL_PF_LOAD(1, pf1) OCL_PF_LOAD(2, pf2) OCL_PF_LOAD(3, pf3)
+    };
+    auto commit = [&](int t0_, int buf) __attribute__((always_inline)) {
+        float* dst_ = wl + buf * a.WS;
+        OCL_PF_STORE(0, pf0) OCL_PF_STORE(1, pf1) OCL_PF_STORE(2, pf2) OCL_PF_STORE(3, pf3)
+    };
+#undef OCL_PF_LOAD
+#undef OCL_PF_STORE
 
     const float inv_ppi = 1.0f / (float)a.ppi, inv_lw = 1.0f / (float)a.LW;
     const int bbase = (W == 16 ? g : 2 * g) * a.BNP + r16;
@@ -218,8 +235,6 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs a) {
     };
 
     int st = 0;
-    TileGeom cur = geom(blockIdx.x);
-    load_patch(cur, 0);
     prefetch(0, 0);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int next_tile = tile + gridDim.x;
@@ -232,7 +247,7 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs a) {
             const int il = fdiv(r, a.ppi, inv_ppi, pl);
             const int p = cur.p0 + pl;
             const int n = cur.img0 + il;
-            const bool v = (il < a.imgs) && (n < cur.grp_end) && (p < LP);
+            const bool v = (il < a.imgs) & (n < cur.grp_end) & (p < LP);
             const int ly = fdiv(p, a.LW, inv_lw, lx);
             poff = v ? ((il * a.PR + (ly - cur.ly0) * a.is) * a.PC + lx * a.is) * a.CP : 0;
             ooff = ((n * a.Hout + ly * a.os + a.oy0) * a.Wout + lx * a.os + a.ox0) * a.Cout;
@@ -436,6 +451,7 @@ static conv_fn_t conv_fn(int W, int MT, int NT, int PF) {
 #define OCL_CASE(WW, M, N)                                                  \
     if (W == WW && MT == M && NT == N) {                                    \
         if (PF == 4) return conv_gemm_kernel<WW, M, N, 4>;                  \
+        if (PF == 6) return conv_gemm_kernel<WW, M, N, 6>;                  \
         if (PF == 8) return conv_gemm_kernel<WW, M, N, 8>;                  \
     }
     OCL_CONV_TILINGS16(OCL_CASE)
@@ -443,7 +459,7 @@ static conv_fn_t conv_fn(int W, int MT, int NT, int PF) {
 #undef OCL_CASE
     return nullptr;
 }
-static int conv_pf_for(int units) { return units <= 1024 ? 4 : 8; }
+static int conv_pf_for(int units) { return units <= 1024 ? 4 : units <= 1536 ? 6 : 8; }
 
 static int bnp_for(int bn) {  // LDS weight row stride with (stride mod 32) == 16: B reads conflict-free
     int p = bn;
@@ -1479,7 +1495,7 @@ int conv_kernels_init() {
     for (int w = 16; w <= 32; w += 16)
         for (int m = 1; m <= 4; ++m)
             for (int n = 1; n <= 5; ++n)
-                for (int pf = 4; pf <= 8; pf += 4)
+                for (int pf = 4; pf <= 8; pf += 2)
                     if (conv_fn(w, m, n, pf))
                         OCL_HIP(hipFuncSetAttribute((const void*)conv_fn(w, m, n, pf), hipFuncAttributeMaxDynamicSharedMemorySize,
                                                     (int)kLdsLimit));
