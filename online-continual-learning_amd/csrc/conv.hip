@@ -751,14 +751,16 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    const float inv_tpi = 1.0f / (float)a.tiles_per_img, inv_wo0 = 1.0f / (float)a.Wo;
     auto geom = [&](int tile) __attribute__((always_inline)) -> WTile {
         WTile t;
-        const int ti = tile / a.tiles_per_img;
+        int tp, rem;
+        const int ti = fdiv(tile, a.tiles_per_img, inv_tpi, tp);
         t.img0 = ti * a.imgs;
-        t.p0 = (tile - ti * a.tiles_per_img) * a.ppi;
-        t.oy0 = t.p0 / a.Wo;
+        t.p0 = tp * a.ppi;
+        t.oy0 = fdiv(t.p0, a.Wo, inv_wo0, rem);
         const int pend = min(t.p0 + a.ppi, LP);
-        const int oy1 = (pend - 1) / a.Wo;
+        const int oy1 = fdiv(pend - 1, a.Wo, inv_wo0, rem);
         t.nrows = a.imgs > 1 ? min(a.imgs, a.N - t.img0) * a.PR : (oy1 - t.oy0) * a.stride + (a.max_dy - a.min_dy) + 1;
         return t;
     };
@@ -796,6 +798,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
     }
     float4 dv[DPF], pv[PF];
     int dpo[DPF];   // LDS patch offset of the pixel (units with c4 == 0 publish it), -1: unit not in this tile
+    const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(a.x), rs_dy = make_rsrc(a.dy);
     auto load_tile = [&](const WTile& t) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < DPF; ++i) {
@@ -805,24 +808,20 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
             const int p = t.p0 + pl, n = t.img0 + il;
             const int oy = fdiv(p, a.Wo, inv_wo, ox);
             const bool in_tile = du_pos[i] >= 0;
-            const bool v = in_tile && (il < a.imgs) && (n < a.N) && (p < LP);
+            const bool v = in_tile & (il < a.imgs) & (n < a.N) & (p < LP);
             const int co = n0 + c4 * 4;
-            const bool ok = v && co < a.Cout;
-            const float* ptr = ok ? a.dy + ((int64_t)(n * a.Ho + oy) * a.Wo + ox) * a.Cout + co : a.dy;   // unconditional load
-            const float4 val = *(const float4*)ptr;
-            dv[i] = ok ? val : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = v & (co < a.Cout);
+            dv[i] = buf_load16(rs_dy, ok ? (((n * a.Ho + oy) * a.Wo + ox) * a.Cout + co) * 4 : kOob);   // zeros when masked
             dpo[i] = in_tile ? (v ? ((il * a.PR + (oy - t.oy0) * a.stride) * a.PC + ox * a.stride) * a.CP : 0) : -1;
         }
         const int iy0 = t.oy0 * a.stride + a.min_dy;
-        const float* base = a.x + ((int64_t)(t.img0 * a.Hin + iy0) * a.Win + a.min_dx) * a.Cin + c0;
+        const int base = (((t.img0 * a.Hin + iy0) * a.Win + a.min_dx) * a.Cin + c0) * 4;   // bytes; may be negative (halo)
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
             const int il = pu_pos[i] >> 24, pr = (pu_pos[i] >> 16) & 255, pc = (pu_pos[i] >> 8) & 255, c4 = pu_pos[i] & 255;
             const int iy = iy0 + pr, ix = a.min_dx + pc;
-            const bool ok = il * a.PR + pr < t.nrows && iy >= 0 && iy < a.Hin && ix >= 0 && ix < a.Win;
-            const float* ptr = ok ? base + ((il * a.Hin + pr) * a.Win + pc) * a.Cin + c4 * 4 : a.x;
-            const float4 val = *(const float4*)ptr;
-            pv[i] = ok ? val : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = (il * a.PR + pr < t.nrows) & (iy >= 0) & (iy < a.Hin) & (ix >= 0) & (ix < a.Win);
+            pv[i] = buf_load16(rs_x, ok ? base + (((il * a.Hin + pr) * a.Win + pc) * a.Cin + c4 * 4) * 4 : kOob);
         }
     };
     auto store_tile = [&](const WTile& t) __attribute__((always_inline)) {
