@@ -45,6 +45,7 @@ struct ConvArgs {
     int ppi, imgs, tiles_per_img;
     int groups, group_size, tiles_per_group;
     int BNP;                    // LDS weight row stride (floats)
+    int wreg;                   // 1: register-resident weights variant (conv_gemm_kernel<32,1,1,PF,true>)
     int KU;                     // k-steps issued per unrolled group (5 when KC/4 is a multiple of 5)
     int TG, gpc, WS;            // taps per weight stage, stages per channel chunk, floats per stage buffer
     int flags;
@@ -67,6 +68,7 @@ struct ConvGeomDesc {
     int ntaps;
     int tdy[9], tdx[9], tw[9];
     int WP;                     // weight pack row stride (0: the plan's own CoutP)
+    int no_wreg;                // benchmarks: disable the register-resident-weights variant
     int force_W, force_MT, force_NT, force_bpc;   // 0 = planner's choice (benchmarks / tests)
 };
 

@@ -80,7 +80,10 @@ struct TileGeom {
 // its nominal 64 cycles (146-155 TF/s in kbench's register-only stream) while 16x16x4 sustains only ~40-50 cycles per
 // instruction instead of 32 (99-134 TF/s): profiles/r1_mfma_peak_calibration.txt.  W = 32 is used wherever the output
 // channel count pads well to 32 and there are enough pixels for 128-row tiles.
-template <int W, int MT, int NT, int PF>   // PF: float4 patch-prefetch registers per thread (patch units <= 256*PF)
+// WREG (only <32,1,1>: 3x3 stride-1 convolutions of the 20-channel layers, one channel chunk of 20): every weight the lane
+// ever multiplies by (9 taps x 5 channel groups x 2 = 90 values of B[k][lane & 31]) lives in registers for the lifetime of the
+// persistent workgroup: no weight stages, no B reads, two barriers less per tile, and the 90-MFMA tap loop is straight-line.
+template <int W, int MT, int NT, int PF, bool WREG = false>   // PF: float4 patch-prefetch registers per thread
 __global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     constexpr int BM = 4 * W * MT;
@@ -103,6 +106,20 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs a) {
     if ((int)blockIdx.x >= ntiles) return;
     if (tid < 9) tapw[tid] = tap_sel(a.tw, tid);
     __syncthreads();
+    float breg[WREG ? 9 : 1][WREG ? 5 : 1][2];
+    if constexpr (WREG) {
+        const int col = n0 + r16;                       // this lane's output channel (the pack is zero beyond Cout)
+        const bool colok = col < a.WP;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int gq = 0; gq < 5; ++gq)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int c = 4 * gq + 2 * g + e;   // lane half g multiplies channels 2g, 2g+1 of each group of 4
+                    breg[t][gq][e] = colok ? a.w[((int64_t)a.tw[t] * a.Cin + c) * a.WP + col] : 0.f;
+                }
+    }
 
     // tile -> (group, first image, first lattice pixel, ...): divisions by block-uniform plan constants through float
     // reciprocals (a 32-bit integer division costs ~40 instructions and this runs twice per tile)
@@ -235,7 +252,7 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs a) {
     };
 
     int st = 0;
-    prefetch(0, 0);
+    if constexpr (!WREG) prefetch(0, 0);
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int next_tile = tile + gridDim.x;
         TileGeom nxt = cur;
@@ -335,6 +352,19 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs a) {
                     }
                 }
             };
+            if constexpr (WREG) {
+                __syncthreads();      // patch visible
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const float* pa = patch + a.tpo[t];
+#pragma unroll
+                    for (int gq = 0; gq < 5; ++gq) {
+                        const float2 av = *(const float2*)(pa + abase[0] + 4 * gq);
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, breg[t][gq][0], acc[0][0], 0, 0, 0);
+                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, breg[t][gq][1], acc[0][0], 0, 0, 0);
+                    }
+                }
+            } else
             for (int t0 = 0; t0 < a.ntaps; t0 += a.TG, ++st) {
                 commit(t0, st & 1);
                 __syncthreads();      // stage st's weights (and the patch) visible; everyone is done with stage st-1
@@ -447,6 +477,12 @@ typedef void (*conv_fn_t)(const ConvArgs);
 // instantiated tilings (chosen from the kbench sweeps, profiles/): MFMA width x (MT, NT) x patch-prefetch depth
 #define OCL_CONV_TILINGS16(X) X(16, 1, 1) X(16, 1, 2) X(16, 1, 3) X(16, 1, 5) X(16, 2, 1) X(16, 2, 2) X(16, 2, 3) X(16, 4, 2)
 #define OCL_CONV_TILINGS32(X) X(32, 1, 1) X(32, 1, 2) X(32, 1, 3) X(32, 2, 1) X(32, 2, 2)
+static conv_fn_t conv_fn_wreg(int PF) {
+    if (PF == 4) return conv_gemm_kernel<32, 1, 1, 4, true>;
+    if (PF == 6) return conv_gemm_kernel<32, 1, 1, 6, true>;
+    if (PF == 8) return conv_gemm_kernel<32, 1, 1, 8, true>;
+    return nullptr;
+}
 static conv_fn_t conv_fn(int W, int MT, int NT, int PF) {
 #define OCL_CASE(WW, M, N)                                                  \
     if (W == WW && MT == M && NT == N) {                                    \
@@ -609,6 +645,8 @@ int plan_conv(const ConvGeomDesc& g, ConvPlan* p) {
     OCL_REQUIRE(bestMT > 0, "plan_conv: no tile fits the LDS (Hin=%d Win=%d Cin=%d Cout=%d)", g.Hin, g.Win, g.Cin, g.Cout);
     p->lds_bytes = conv_tile_layout(g, a, bestW, bestMT, bestNT);
     p->W = bestW;
+    // register-resident weights: 3x3 (9 taps), 20 input channels in one chunk, <= 32 output channels, 32x32x2 tiles
+    a.wreg = (bestW == 32 && bestMT == 1 && bestNT == 1 && g.ntaps == 9 && g.Cin == 20 && a.KC == 20 && g.Cout <= 32 && !g.no_wreg) ? 1 : 0;
     a.WP = g.WP > 0 ? g.WP : a.CoutP;
     a.KU = ((a.KC / 4) % 5 == 0) ? 5 : 1;
     for (int t = 0; t < 9; ++t) a.tpo[t] = t < a.ntaps ? ((a.tdy[t] - a.min_dy) * a.PC + (a.tdx[t] - a.min_dx)) * a.CP : 0;
@@ -695,7 +733,8 @@ void geom_dgrad(const ConvShape& c, int N, std::vector<ConvGeomDesc>* out) {
 }
 
 int launch_conv(const ConvPlan& p, hipStream_t s) {
-    conv_fn_t fn = conv_fn(p.W, p.MT, p.NT, conv_pf_for(p.a.imgs * p.a.PR * p.a.PC * (p.a.KC / 4)));
+    const int pfu = conv_pf_for(p.a.imgs * p.a.PR * p.a.PC * (p.a.KC / 4));
+    conv_fn_t fn = p.a.wreg ? conv_fn_wreg(pfu) : conv_fn(p.W, p.MT, p.NT, pfu);
     if (!fn) {
         set_error("launch_conv: no kernel for W=%d MT=%d NT=%d", p.W, p.MT, p.NT);
         return OCL_ERR_STATE;
@@ -1502,6 +1541,8 @@ int conv_kernels_init() {
         for (int n = 1; n <= 5; ++n)
             for (int pf = 4; pf <= 8; pf += 4)
                 OCL_HIP(hipFuncSetAttribute((const void*)wgrad_fn(m, n, pf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+    for (int pf = 4; pf <= 8; pf += 2)
+        OCL_HIP(hipFuncSetAttribute((const void*)conv_fn_wreg(pf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     done = true;
     return OCL_OK;
 }

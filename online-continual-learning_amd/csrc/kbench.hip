@@ -123,6 +123,17 @@ static void bench_geom(const char* lname, const char* kind, ConvGeomDesc g, cons
     printf("%-20s %-7s M=%7d N=%3d K=%4d  auto W=%d MT=%d NT=%d grid=%5dx%d lds=%6zu KC=%3d TG=%d  %7.1f us %6.1f TF/s\n", lname, kind,
            g.N * g.LH * g.LW, g.Cout, g.ntaps * g.Cin, p0.W, p0.MT, p0.NT, p0.grid_x, p0.grid_y, p0.lds_bytes, p0.a.KC, p0.a.TG, t0,
            flops / t0 * 1e-6);
+    if (p0.a.wreg) {   // A/B: the same tiling with staged (LDS) weights
+        ConvGeomDesc gn = g;
+        gn.no_wreg = 1;
+        ConvPlan pn;
+        OK(plan_conv(gn, &pn));
+        CK(hipMemset(out, 0, out_elems * 4));
+        run(pn, out);
+        const double d = max_diff(out, out_ref, out_elems);
+        const double t = time_us([&] { run(pn, out); });
+        printf("    (weights staged through LDS instead of registers: %7.1f us, maxdiff vs register variant %.2e)\n", t, d);
+    }
     if (!sweep) return;
     const int MTs[3] = {1, 2, 4};
     const int ntile16 = (g.Cout + 15) / 16;
