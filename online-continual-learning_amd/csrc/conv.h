@@ -184,7 +184,7 @@ int launch_avgpool_fwd(const float* z, float* feat, int N, int H, int W, int C, 
 int launch_avgpool_bwd(const float* dfeat, float* dz, int N, int H, int W, int C, hipStream_t s);
 
 // F.normalize(dim=1) forward/backward
-int launch_l2norm_fwd(const float* v, float* out, float* norms, int n, int d, hipStream_t s);
+int launch_l2norm_fwd(const float* v, float* out, float* norms, int n, int d, hipStream_t s, float* out2 = nullptr);
 int launch_l2norm_bwd(const float* out, const float* norms, const float* dout, float* dv, int n, int d, hipStream_t s);
 // dx = dy * (a > 0)
 int launch_relu_bwd(const float* dy, const float* a, float* dx, int64_t n, hipStream_t s);

@@ -1446,7 +1446,7 @@ int launch_avgpool_bwd(const float* dfeat, float* dz, int N, int H, int W, int C
 }
 
 __global__ void __launch_bounds__(64) l2norm_fwd_kernel(const float* __restrict__ v, float* __restrict__ out, float* __restrict__ norms,
-                                                        int d) {
+                                                        int d, float* __restrict__ out2) {
     const int n = blockIdx.x, lane = threadIdx.x;
     const float* p = v + (int64_t)n * d;
     float ss = 0.f;
@@ -1454,7 +1454,11 @@ __global__ void __launch_bounds__(64) l2norm_fwd_kernel(const float* __restrict_
     ss = wave_sum(ss);
     const float nrm = fmaxf(sqrtf(ss), 1e-12f);  // F.normalize eps
     if (lane == 0) norms[n] = nrm;
-    for (int j = lane; j < d; j += 64) out[(int64_t)n * d + j] = p[j] / nrm;
+    for (int j = lane; j < d; j += 64) {
+        const float q = p[j] / nrm;
+        out[(int64_t)n * d + j] = q;
+        if (out2) out2[(int64_t)n * d + j] = q;   // the caller's tensor (saves a device-to-device copy launch)
+    }
 }
 __global__ void __launch_bounds__(64) l2norm_bwd_kernel(const float* __restrict__ out, const float* __restrict__ norms,
                                                         const float* __restrict__ dout, float* __restrict__ dv, int d) {
@@ -1467,9 +1471,9 @@ __global__ void __launch_bounds__(64) l2norm_bwd_kernel(const float* __restrict_
     const float inv = 1.0f / norms[n];
     for (int j = lane; j < d; j += 64) dv[(int64_t)n * d + j] = (g[j] - o[j] * dot) * inv;
 }
-int launch_l2norm_fwd(const float* v, float* out, float* norms, int n, int d, hipStream_t s) {
+int launch_l2norm_fwd(const float* v, float* out, float* norms, int n, int d, hipStream_t s, float* out2) {
     ProfScope ps(PROF_HEAD, s);
-    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(n), dim3(64), 0, s, v, out, norms, d);
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(n), dim3(64), 0, s, v, out, norms, d, out2);
     OCL_LAUNCH_CHECK();
     return OCL_OK;
 }

@@ -393,7 +393,7 @@ static int run_conv(ocl_net* n, ConvPlan p, const float* in, const float* w, flo
 }
 
 static int head_forward(ocl_net* n, const float* P, float* feat, float* h1, float* h2, float* norms, float* out, int N,
-                        hipStream_t s) {
+                        hipStream_t s, float* out2, bool* wrote_out2) {
     const int FD = n->feat_dim;
     auto T = [&](int t) { return P + n->tensors[t].off; };
     int rc = OCL_OK;
@@ -406,15 +406,18 @@ static int head_forward(ocl_net* n, const float* P, float* feat, float* h1, floa
             if (rc) return rc;
             rc = ocl_gemm_small(h1, FD, 1, T(n->t_h2_w), 1, FD, h2, n->out_dim, N, n->out_dim, FD, T(n->t_h2_b), 0, 0, s);
             if (rc) return rc;
-            rc = launch_l2norm_fwd(h2, out, norms, N, n->out_dim, s);
+            rc = launch_l2norm_fwd(h2, out, norms, N, n->out_dim, s, out2);
+            *wrote_out2 = true;
             break;
         case 2:
             rc = ocl_gemm_small(feat, FD, 1, T(n->t_h2_w), 1, FD, h2, n->out_dim, N, n->out_dim, FD, T(n->t_h2_b), 0, 0, s);
             if (rc) return rc;
-            rc = launch_l2norm_fwd(h2, out, norms, N, n->out_dim, s);
+            rc = launch_l2norm_fwd(h2, out, norms, N, n->out_dim, s, out2);
+            *wrote_out2 = true;
             break;
         default:
-            rc = launch_l2norm_fwd(feat, out, norms, N, FD, s);
+            rc = launch_l2norm_fwd(feat, out, norms, N, FD, s, out2);
+            *wrote_out2 = true;
             break;
     }
     return rc;
@@ -525,7 +528,8 @@ int ocl_net_forward(ocl_net* n, const float* x, int N, int groups, uint32_t flag
     if (rc != OCL_OK) return rc;
     n->slot_valid[slot] = false;
 
-    float* feat = S + n->feat_off;
+    const bool feat_direct = feat_out && !out && !(flags & OCL_FWD_SAVE_TAPE);   // features only (ASER scoring, NCM): no copy
+    float* feat = feat_direct ? feat_out : S + n->feat_off;
     if (train) {
         double* stats = (double*)(n->ws + n->off_stats);
         OCL_HIP(hipMemsetAsync(stats, 0, n->stats_doubles * 8, s));
@@ -606,11 +610,12 @@ int ocl_net_forward(ocl_net* n, const float* x, int N, int groups, uint32_t flag
         }
         if ((rc = launch_avgpool_fwd(cur, feat, N, n->Hf, n->Wf, n->convs[n->blocks.back().conv2].Cout, s))) return rc;
     }
-    if (feat_out) OCL_HIP(hipMemcpyAsync(feat_out, feat, (size_t)N * n->feat_dim * 4, hipMemcpyDeviceToDevice, s));
+    if (feat_out && !feat_direct) OCL_HIP(hipMemcpyAsync(feat_out, feat, (size_t)N * n->feat_dim * 4, hipMemcpyDeviceToDevice, s));
     if (out || (flags & OCL_FWD_SAVE_TAPE)) {
         float* o = S + n->out_off;
-        if ((rc = head_forward(n, P, feat, S + n->h1_off, S + n->h2_off, S + n->norms_off, o, N, s))) return rc;
-        if (out) OCL_HIP(hipMemcpyAsync(out, o, (size_t)N * n->out_dim * 4, hipMemcpyDeviceToDevice, s));
+        bool wrote = false;
+        if ((rc = head_forward(n, P, feat, S + n->h1_off, S + n->h2_off, S + n->norms_off, o, N, s, out, &wrote))) return rc;
+        if (out && !wrote) OCL_HIP(hipMemcpyAsync(out, o, (size_t)N * n->out_dim * 4, hipMemcpyDeviceToDevice, s));
     }
     if (train && (flags & OCL_FWD_SAVE_TAPE) && !params_override) {
         n->slot_valid[slot] = true;

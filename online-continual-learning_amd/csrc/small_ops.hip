@@ -321,44 +321,69 @@ __global__ void __launch_bounds__(256) knn_sv_kernel(const float* __restrict__ e
     }
 }
 
-// column reductions over evaluation rows
+// column reductions over evaluation rows: 32 columns x 8 row lanes per workgroup; the fp64 lane sums are combined in a
+// fixed order (deterministic)
 __global__ void __launch_bounds__(256) col_reduce_kernel(const float* __restrict__ m, int rows, int cols, int mode,
                                                          float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
-    if (mode <= 1) {
-        double s = 0.0;
-        for (int r = 0; r < rows; ++r) s += (double)m[(int64_t)r * cols + c];
-        out[c] = mode == 1 ? (float)(s / (double)rows) : (float)s;
-    } else {
-        float v = m[c];
-        for (int r = 1; r < rows; ++r) {
+    __shared__ double red[8][33];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double s = 0.0;
+    float v = mode == 2 ? -INFINITY : INFINITY;
+    if (c < cols)
+        for (int r = rl; r < rows; r += 8) {
             const float t = m[(int64_t)r * cols + c];
+            s += (double)t;
             v = mode == 2 ? fmaxf(v, t) : fminf(v, t);
         }
-        out[c] = v;
+    red[rl][cl] = mode <= 1 ? s : (double)v;
+    __syncthreads();
+    if (rl == 0 && c < cols) {
+        if (mode <= 1) {
+            const double t = ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])) + ((red[4][cl] + red[5][cl]) + (red[6][cl] + red[7][cl]));
+            out[c] = mode == 1 ? (float)(t / (double)rows) : (float)t;
+        } else {
+            double t = red[0][cl];
+            for (int k = 1; k < 8; ++k) t = mode == 2 ? fmax(t, red[k][cl]) : fmin(t, red[k][cl]);
+            out[c] = (float)t;
+        }
     }
 }
 
 __global__ void __launch_bounds__(256) aser_score_kernel(const float* __restrict__ adv, int n_adv, const float* __restrict__ coop,
                                                          int n_coop, int n_cand, int type, float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_cand) return;
-    if (type == 0) {
-        double sa = 0.0, sc = 0.0;
-        for (int r = 0; r < n_adv; ++r) sa += (double)adv[(int64_t)r * n_cand + c];
-        for (int r = 0; r < n_coop; ++r) sc += (double)coop[(int64_t)r * n_cand + c];
-        const float ma = (float)(sa / (double)n_adv), mc = (float)(sc / (double)n_coop);
-        out[c] = mc - ma;
-    } else if (type == 1) {
-        float mn = adv[c], mx = coop[c];
-        for (int r = 1; r < n_adv; ++r) mn = fminf(mn, adv[(int64_t)r * n_cand + c]);
-        for (int r = 1; r < n_coop; ++r) mx = fmaxf(mx, coop[(int64_t)r * n_cand + c]);
-        out[c] = mx - mn;
-    } else {
-        double sa = 0.0;
-        for (int r = 0; r < n_adv; ++r) sa += (double)adv[(int64_t)r * n_cand + c];
-        out[c] = (float)sa * -1.0f;
+    __shared__ double ra[8][33], rc[8][33];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
+    double sa = 0.0, sc = 0.0;
+    float mn = INFINITY, mx = -INFINITY;
+    if (c < n_cand) {
+        for (int r = rl; r < n_adv; r += 8) {
+            const float t = adv[(int64_t)r * n_cand + c];
+            sa += (double)t;
+            mn = fminf(mn, t);
+        }
+        if (type != 2)
+            for (int r = rl; r < n_coop; r += 8) {
+                const float t = coop[(int64_t)r * n_cand + c];
+                sc += (double)t;
+                mx = fmaxf(mx, t);
+            }
+    }
+    ra[rl][cl] = type == 1 ? (double)mn : sa;
+    rc[rl][cl] = type == 1 ? (double)mx : sc;
+    __syncthreads();
+    if (rl == 0 && c < n_cand) {
+        if (type == 1) {
+            double a = ra[0][cl], b = rc[0][cl];
+            for (int k = 1; k < 8; ++k) { a = fmin(a, ra[k][cl]); b = fmax(b, rc[k][cl]); }
+            out[c] = (float)b - (float)a;
+        } else {
+            const double ta = ((ra[0][cl] + ra[1][cl]) + (ra[2][cl] + ra[3][cl])) + ((ra[4][cl] + ra[5][cl]) + (ra[6][cl] + ra[7][cl]));
+            const double tc = ((rc[0][cl] + rc[1][cl]) + (rc[2][cl] + rc[3][cl])) + ((rc[4][cl] + rc[5][cl]) + (rc[6][cl] + rc[7][cl]));
+            if (type == 0) out[c] = (float)(tc / (double)n_coop) - (float)(ta / (double)n_adv);
+            else out[c] = (float)ta * -1.0f;
+        }
     }
 }
 
@@ -718,7 +743,7 @@ int ocl_col_reduce(const float* m, int rows, int cols, int mode, float* out, voi
     OCL_REQUIRE(m && out && rows > 0 && cols > 0 && mode >= 0 && mode <= 3, "col_reduce: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(PROF_KNN, s);
-    hipLaunchKernelGGL(col_reduce_kernel, dim3(cdiv(cols, 256)), dim3(256), 0, s, m, rows, cols, mode, out);
+    hipLaunchKernelGGL(col_reduce_kernel, dim3(cdiv(cols, 32)), dim3(256), 0, s, m, rows, cols, mode, out);
     OCL_LAUNCH_CHECK();
     return OCL_OK;
 }
@@ -729,7 +754,7 @@ int ocl_aser_score(const float* sv_adv, int n_adv, const float* sv_coop, int n_c
     OCL_REQUIRE(type == 2 || (sv_coop && n_coop > 0), "aser_score: cooperative matrix required for type %d", type);
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(PROF_KNN, s);
-    hipLaunchKernelGGL(aser_score_kernel, dim3(cdiv(n_cand, 256)), dim3(256), 0, s, sv_adv, n_adv, sv_coop, n_coop, n_cand, type,
+    hipLaunchKernelGGL(aser_score_kernel, dim3(cdiv(n_cand, 32)), dim3(256), 0, s, sv_adv, n_adv, sv_coop, n_coop, n_cand, type,
                        out);
     OCL_LAUNCH_CHECK();
     return OCL_OK;

@@ -304,3 +304,34 @@ def test_backward_without_tape_fails_loudly(cuda):
         m.forward(torch.rand(4, 3, 16, 16, device=cuda))
     with pytest.raises(RuntimeError):
         m.forward(torch.rand(4, 3, 32, 32))     # CPU tensor: no CPU path
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 129, 300])
+def test_edge_batch_sizes_train_and_eval_forward(cuda, n):
+    """Batch sizes the tilings do not divide: a single image, odd counts, more than one 128-pixel tile's worth of 4x4
+    images, and a batch above max_batch (eval features are chunked; a train forward above max_batch must fail loudly)."""
+    m, sd = build("ER", "cifar100", cuda=cuda, max_batch=160)
+    rng = np.random.default_rng(100 + n)
+    x = rng.random((n, 3, 32, 32)).astype(np.float32)
+    xd = torch.from_numpy(x).to(cuda)
+    m.eval()
+    with torch.no_grad():
+        f = m.features_batched(xd).cpu().numpy()
+    net = O.OracleNet(O.clone_state(sd, requires_grad=False), head=None, training=False)
+    with torch.no_grad():
+        f_ref = net.features(torch.from_numpy(x)).numpy()
+    assert f.shape == f_ref.shape and relmax(f, f_ref) < 1e-4
+    m.train()
+    if n > 160:
+        with pytest.raises(RuntimeError):
+            m.forward(xd)
+        return
+    out = m.forward(xd)
+    net_t = O.OracleNet(O.clone_state(sd, requires_grad=False), head=None, training=True)
+    with torch.no_grad():
+        out_ref = net_t.forward(torch.from_numpy(x)).numpy()
+    if n > 1:      # n = 1: BatchNorm of a 1x1 feature map over one sample is degenerate at layer 4 (var of 16 values only)
+        assert np.abs(out.detach().cpu().numpy() - out_ref).max() < 2e-3 * (1 + np.abs(out_ref).max())
+    out.sum().backward()
+    g = m.flat_grads().cpu().numpy()
+    assert np.isfinite(g).all() and np.abs(g).max() > 0
