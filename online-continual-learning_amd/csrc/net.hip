@@ -65,6 +65,8 @@ struct ocl_net {
     int64_t slot_floats = 0;
     int64_t gbuf_floats = 0;
     int64_t off_g[5] = {0, 0, 0, 0, 0};
+    static const int kDyRing = 6;        // dL/dy buffers handed to the weight-gradient stream (see ocl_net_backward)
+    int64_t off_dy[6] = {0, 0, 0, 0, 0, 0};
     int64_t off_partial = 0, partial_floats = 0;
     int64_t off_stats = 0, stats_doubles = 0, stats_rep_stride = 0;
     int64_t off_bsums = 0, bsums_doubles = 0;
@@ -92,6 +94,15 @@ struct ocl_net {
 
     float* slotf(int slot) const { return (float*)(ws + slot_base + (int64_t)slot * slot_bytes); }
     float* gbuf(int i) const { return (float*)(ws + off_g[i]); }
+    float* dybuf(int i) const { return (float*)(ws + off_dy[i]); }
+
+    // second stream for the weight gradients + events (created on first backward)
+    hipStream_t s2 = nullptr;
+    std::vector<hipEvent_t> ev_ready;      // main -> s2: a dL/dy buffer has been written
+    hipEvent_t ev_done[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // s2 -> main: ring slot no longer read
+    bool ev_done_pending[6] = {false, false, false, false, false, false};
+    hipEvent_t ev_join = nullptr;
+    int dy_next = 0;
 };
 
 // -----------------------------------------------------------------------------------------------------
@@ -263,6 +274,7 @@ static int build_layout(ocl_net* n) {
     };
     n->gbuf_floats = max_act;
     for (int i = 0; i < 5; ++i) n->off_g[i] = takeb(max_act * 4);
+    for (int i = 0; i < ocl_net::kDyRing; ++i) n->off_dy[i] = takeb(max_act * 4);
     // wgrad partial: worst case over layers for the largest batch
     int64_t pmax = 0;
     for (auto& cv : n->convs) {
@@ -445,7 +457,15 @@ int ocl_net_create(const ocl_net_desc* desc, ocl_net** out) {
     return OCL_OK;
 }
 
-void ocl_net_destroy(ocl_net* net) { delete net; }
+void ocl_net_destroy(ocl_net* net) {
+    if (!net) return;
+    for (auto e : net->ev_ready) (void)hipEventDestroy(e);
+    for (int i = 0; i < ocl_net::kDyRing; ++i)
+        if (net->ev_done[i]) (void)hipEventDestroy(net->ev_done[i]);
+    if (net->ev_join) (void)hipEventDestroy(net->ev_join);
+    if (net->s2) (void)hipStreamDestroy(net->s2);
+    delete net;
+}
 
 int64_t ocl_net_param_count(const ocl_net* net) { return net ? net->n_params : -1; }
 int32_t ocl_net_num_tensors(const ocl_net* net) { return net ? (int32_t)net->tensors.size() : -1; }
@@ -690,13 +710,57 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
         }
     }
     // ---- trunk ------------------------------------------------------------------------------------
+    // Two HIP streams: the caller's stream carries the dependent chain (BatchNorm backward -> data gradient -> ...), the
+    // weight gradients (conv_wgrad_kernel + reduce: a third of the step's MFMA work, needed by nobody until the
+    // optimiser step) run on a second stream as soon as their dL/dy exists.  Most launches of either chain are a single
+    // round of 220-512 workgroups or HBM-bound BatchNorm passes, so the two streams fill each other's idle CUs.
+    // dL/dy buffers come from a ring; a slot is rewritten only after the event behind its last weight-gradient reader.
     float* gA = n->gbuf(0);  // grad wrt current block output
-    float* gB = n->gbuf(1);
-    float* gC = n->gbuf(2);
     float* gD = n->gbuf(3);
     float* gE = n->gbuf(4);
+    float* gB = nullptr;     // dL/dy of the main-path BatchNorm being processed (ring slot)
+    float* gC = nullptr;     // dL/dy of the projection-shortcut BatchNorm
     const int Clast = n->convs[n->blocks.back().conv2].Cout;
     if ((rc = launch_avgpool_bwd(dfeat, gA, N, n->Hf, n->Wf, Clast, s))) return rc;
+
+    // replay batches of 10-20 images are launch-latency-bound: the event traffic costs more than the overlap returns there;
+    // the debug stops expose intermediate buffers: single stream as well
+    const bool two_streams = n->dbg_stop < 0 && N >= 48;
+    if (two_streams && !n->s2) {
+        OCL_HIP(hipStreamCreateWithFlags(&n->s2, hipStreamNonBlocking));
+        for (int i = 0; i < ocl_net::kDyRing; ++i) OCL_HIP(hipEventCreateWithFlags(&n->ev_done[i], hipEventDisableTiming));
+        OCL_HIP(hipEventCreateWithFlags(&n->ev_join, hipEventDisableTiming));
+    }
+    hipStream_t sw = two_streams ? n->s2 : s;   // stream of the weight gradients
+    size_t ready_used = 0;
+    auto take_dy = [&](int* slot_out) -> float* {   // next ring slot; the main stream waits for its previous readers
+        const int r = n->dy_next;
+        n->dy_next = (r + 1) % ocl_net::kDyRing;
+        if (two_streams && n->ev_done_pending[r]) {
+            (void)hipStreamWaitEvent(s, n->ev_done[r], 0);
+            n->ev_done_pending[r] = false;
+        }
+        *slot_out = r;
+        return n->dybuf(r);
+    };
+    auto publish = [&]() -> int {   // everything the main stream has written so far is visible to the wgrad stream
+        if (!two_streams) return OCL_OK;
+        if (ready_used == n->ev_ready.size()) {
+            hipEvent_t e;
+            OCL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            n->ev_ready.push_back(e);
+        }
+        hipEvent_t e = n->ev_ready[ready_used++];
+        OCL_HIP(hipEventRecord(e, s));
+        OCL_HIP(hipStreamWaitEvent(sw, e, 0));
+        return OCL_OK;
+    };
+    auto release = [&](int r) -> int {   // the wgrad stream is done reading ring slot r
+        if (!two_streams) return OCL_OK;
+        OCL_HIP(hipEventRecord(n->ev_done[r], sw));
+        n->ev_done_pending[r] = true;
+        return OCL_OK;
+    };
 
     auto bn_bwd = [&](const float* dz, const float* zmask, int conv_a, float* dya, int conv_b, float* dyb) -> int {
         BnBwdArgs a;
@@ -719,28 +783,23 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
             a.dgamma[k] = GT(b.gamma_t);
             a.dbeta[k] = GT(b.beta_t);
         }
-        // both sets live in conv_a's BN arena region followed by conv_b's: use separate regions per BN
+        // sums are addressed [set][G][2][C] inside conv_a's arena of kGmax*2*C doubles: two sets need 2*G <= kGmax
         a.sums = bsums + n->bns[ca.bn].arena_off;
-        if (conv_b >= 0) {
-            // the kernel addresses sums as [set][G][2][C]; both BNs have the same C and their arenas are
-            // kGmax*2*C doubles each, so set 1 would alias set 0's tail when G < kGmax.  Use a private layout:
-            // set k at offset k*G*2*C inside conv_a's region is only valid if 2*G <= kGmax.
-            if (2 * G > kGmax) {
-                set_error("bn_bwd: groups=%d too large for a shared reduction arena", G);
-                return OCL_ERR_ARG;
-            }
+        if (conv_b >= 0 && 2 * G > kGmax) {
+            set_error("bn_bwd: groups=%d too large for a shared reduction arena", G);
+            return OCL_ERR_ARG;
         }
         a.accumulate = accumulate;
         return launch_bn_bwd(a, s);
     };
-    auto wgrad = [&](int conv_i, const float* xin, const float* dy) -> int {
+    auto wgrad = [&](int conv_i, const float* xin, const float* dy) -> int {   // on the weight-gradient stream
         WgradPlan wp = ps->wgrad[conv_i];
         wp.a.x = xin;
         wp.a.dy = dy;
         wp.a.partial = partial;
-        int r = launch_wgrad(wp, s);
+        int r = launch_wgrad(wp, sw);
         if (r) return r;
-        return launch_wgrad_reduce(wp, GT(n->convs[conv_i].w_t), accumulate, s);
+        return launch_wgrad_reduce(wp, GT(n->convs[conv_i].w_t), accumulate, sw);
     };
     auto dgrad = [&](int conv_i, const float* dy, float* dx, const float* res, const float* resmask, int extra_flags) -> int {
         const ConvInfo& c = n->convs[conv_i];
@@ -764,29 +823,50 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
         const float* a1 = S + b.a1_off;
         const float* z = S + b.z_off;
         // gA = dL/dz.  bn2 (and the projection BN) share the ReLU-masked gradient.
+        int rB, rC = -1;
+        gB = take_dy(&rB);
+        if (b.convs >= 0) gC = take_dy(&rC);
         if ((rc = bn_bwd(gA, z, b.conv2, gB, b.convs, gC))) return rc;
         if (stop_here(bi, 1)) return OCL_OK;                                 // gB = dL/dy2, gC = dL/dys
-        if (b.convs >= 0)
+        if ((rc = publish())) return rc;
+        if (b.convs >= 0) {
             if ((rc = wgrad(b.convs, xin, gC))) return rc;
+            if ((rc = release(rC))) return rc;                               // (the shortcut's dgrad below reads gC on `s`)
+        }
         if ((rc = wgrad(b.conv2, a1, gB))) return rc;
+        if ((rc = release(rB))) return rc;
         if ((rc = dgrad(b.conv2, gB, gD, nullptr, nullptr, 0))) return rc;   // gD = dL/da1 (pre-mask)
         if (stop_here(bi, 2)) return OCL_OK;
-        if ((rc = bn_bwd(gD, a1, b.conv1, gB, -1, nullptr))) return rc;      // gB = dL/dy1
+        int rB1;
+        float* gB1 = take_dy(&rB1);
+        if ((rc = bn_bwd(gD, a1, b.conv1, gB1, -1, nullptr))) return rc;     // gB1 = dL/dy1
+        gB = gB1;
         if (stop_here(bi, 3)) return OCL_OK;
-        if ((rc = wgrad(b.conv1, xin, gB))) return rc;
+        if ((rc = publish())) return rc;
+        if ((rc = wgrad(b.conv1, xin, gB1))) return rc;
+        if ((rc = release(rB1))) return rc;
         if (b.convs >= 0) {
-            if ((rc = dgrad(b.conv1, gB, gE, nullptr, nullptr, 0))) return rc;
+            if ((rc = dgrad(b.conv1, gB1, gE, nullptr, nullptr, 0))) return rc;
             if (stop_here(bi, 4)) return OCL_OK;
             if ((rc = dgrad(b.convs, gC, gE, nullptr, nullptr, EPI_ACCUM))) return rc;
         } else {
-            if ((rc = dgrad(b.conv1, gB, gE, gA, z, 0))) return rc;         // + identity shortcut: dz * (z>0)
+            if ((rc = dgrad(b.conv1, gB1, gE, gA, z, 0))) return rc;         // + identity shortcut: dz * (z>0)
         }
         if (stop_here(bi, 5)) return OCL_OK;                                 // gE = dL/dx of the block
         std::swap(gA, gE);
     }
     // stem
-    if ((rc = bn_bwd(gA, S + n->zstem_off, 0, gB, -1, nullptr))) return rc;
-    if ((rc = wgrad(0, S + n->x4_off, gB))) return rc;
+    int rS;
+    float* gS = take_dy(&rS);
+    if ((rc = bn_bwd(gA, S + n->zstem_off, 0, gS, -1, nullptr))) return rc;
+    if ((rc = publish())) return rc;
+    if ((rc = wgrad(0, S + n->x4_off, gS))) return rc;
+    if ((rc = release(rS))) return rc;
+    if (two_streams) {   // the caller's stream continues (optimiser step, next forward) only after every weight gradient
+        OCL_HIP(hipEventRecord(n->ev_join, sw));
+        OCL_HIP(hipStreamWaitEvent(s, n->ev_join, 0));
+        for (int i = 0; i < ocl_net::kDyRing; ++i) n->ev_done_pending[i] = false;   // covered by the join
+    }
     return OCL_OK;
 }
 
