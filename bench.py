@@ -139,6 +139,8 @@ def gpu_leg(args, rank, world, local):
     out = dict(elapsed=elapsed, total_steps=total_steps, hw=hw, bs=bs)
 
     # ---- roofline leg: HIP events around every kernel launch, on the stream the kernels run on (rank 0) -----------
+    # With profiling enabled the engine keeps the weight-gradient kernels on the same stream (no overlap), so each duration is
+    # that of the kernel alone; `value` above comes from the overlapped product path.
     if rank == 0 and not args.no_roofline:
         n_prof = min(args.steps, 20)
         xp, yp = synth_u8(n_prof * bs, hw, ncls, 3)
@@ -228,7 +230,12 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=150)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--single-stream", action="store_true",
+                    help="keep the weight-gradient kernels on the main stream (OCL_SINGLE_STREAM=1): the configuration the roofline "
+                         "leg measures kernels in, and the one profiles/*kernel_stats_single_stream* are taken in")
     args = ap.parse_args()
+    if args.single_stream:
+        os.environ["OCL_SINGLE_STREAM"] = "1"
 
     import ocl_amd  # noqa: F401
     from ocl_amd import dist as odist

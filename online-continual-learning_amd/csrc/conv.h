@@ -178,6 +178,7 @@ struct BnBwdArgs {
     int accumulate;       // dgamma/dbeta += (1) or = (0)
 };
 int launch_bn_bwd(const BnBwdArgs& a, hipStream_t s);
+void bn_bwd_tune(int block_cap, int unroll, int phase);   // micro-benchmark overrides; 0 = default (phase 1 reduce only, 2 apply only)
 
 // avg_pool2d(k=4) + flatten in PyTorch's (C,ph,pw) order; and its backward
 int launch_avgpool_fwd(const float* z, float* feat, int N, int H, int W, int C, hipStream_t s);

@@ -1264,6 +1264,9 @@ int launch_bn_fold(const float* params, const float* running, float* out, const 
 // =====================================================================================================
 // BatchNorm backward (+ReLU mask), one or two BNs sharing the incoming gradient
 // =====================================================================================================
+// One block walks a contiguous pixel range: thread t < PT*C4 owns (pixel lane t / C4, channel quad t % C4), so one pass of the block
+// reads PT*C4 consecutive float4s of each tensor.  U passes are loaded before any is consumed (3U 16-byte loads in flight per lane).
+template <int U>
 __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const BnBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int C4 = a.C >> 2;
@@ -1288,25 +1291,44 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const BnBwdArgs a) {
                 mean[k] = *(const float4*)(a.mean[k] + (int64_t)g * a.C + c4 * 4);
                 istd[k] = *(const float4*)(a.invstd[k] + (int64_t)g * a.C + c4 * 4);
             }
-        for (int64_t p = pbeg + pl; p < pend; p += PT) {
-            const int64_t e = ((int64_t)g * M + p) * C4 + c4;
-            float4 d = ((const float4*)a.dz)[e];
-            if (a.z) {
-                const float4 zz = ((const float4*)a.z)[e];
+        const float4* dz4 = (const float4*)a.dz + (int64_t)g * M * C4;
+        const float4* z4 = a.z ? (const float4*)a.z + (int64_t)g * M * C4 : nullptr;
+        const float4* y40 = (const float4*)a.y[0] + (int64_t)g * M * C4;
+        const float4* y41 = a.nsets > 1 ? (const float4*)a.y[1] + (int64_t)g * M * C4 : y40;
+        const int64_t step = (int64_t)PT * C4;
+        const int64_t eend = pend * C4;
+        int64_t e = (pbeg + pl) * C4 + c4;
+        auto consume = [&](float4 d, const float4& zz, const float4& ya, const float4& yb) __attribute__((always_inline)) {
+            if (z4) {
                 d.x = zz.x > 0.f ? d.x : 0.f; d.y = zz.y > 0.f ? d.y : 0.f;
                 d.z = zz.z > 0.f ? d.z : 0.f; d.w = zz.w > 0.f ? d.w : 0.f;
             }
 #pragma unroll
             for (int k = 0; k < 2; ++k)
                 if (k < a.nsets) {
-                    const float4 y = ((const float4*)a.y[k])[e];
+                    const float4& y = k ? yb : ya;
                     sd[k].x += d.x; sd[k].y += d.y; sd[k].z += d.z; sd[k].w += d.w;
                     sx[k].x = fmaf(d.x, (y.x - mean[k].x) * istd[k].x, sx[k].x);
                     sx[k].y = fmaf(d.y, (y.y - mean[k].y) * istd[k].y, sx[k].y);
                     sx[k].z = fmaf(d.z, (y.z - mean[k].z) * istd[k].z, sx[k].z);
                     sx[k].w = fmaf(d.w, (y.w - mean[k].w) * istd[k].w, sx[k].w);
                 }
+        };
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (; e + (U - 1) * step < eend; e += U * step) {
+            float4 d[U], zz[U], ya[U], yb[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                d[u] = dz4[e + u * step];
+                zz[u] = z4 ? z4[e + u * step] : zero4;
+                ya[u] = y40[e + u * step];
+                yb[u] = a.nsets > 1 ? y41[e + u * step] : zero4;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) consume(d[u], zz[u], ya[u], yb[u]);
         }
+        for (; e < eend; e += step)
+            consume(dz4[e], z4 ? z4[e] : zero4, y40[e], a.nsets > 1 ? y41[e] : zero4);
     }
     // LDS layout: [set][2][PT][C]
     float* base = sm;
@@ -1386,15 +1408,28 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const BnBwdArgs a) {
     }
 }
 
+static int g_bn_bwd_cap = 0, g_bn_bwd_unroll = 0, g_bn_bwd_phase = 0;   // micro-benchmark overrides (kbench)
+void bn_bwd_tune(int cap, int unroll, int phase) { g_bn_bwd_cap = cap; g_bn_bwd_unroll = unroll; g_bn_bwd_phase = phase; }
+
 int launch_bn_bwd(const BnBwdArgs& a, hipStream_t s) {
     OCL_REQUIRE(a.nsets == 1 || a.nsets == 2, "bn_bwd: nsets=%d", a.nsets);
     const int C4 = a.C / 4, PT = 256 / C4;
-    const int64_t per_block_pixels = (int64_t)PT * 8;
-    const int bx = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (a.m_per_group + per_block_pixels - 1) / per_block_pixels));
+    const int U = g_bn_bwd_unroll ? g_bn_bwd_unroll : 4;
+    // passes per block: 8 for the large maps, 4 once a group has fewer than 1024 passes in total (more, shorter blocks: the
+    // small layers are latency-bound) -- profiles/r1_kbench_bn_sweep.txt
+    const int passes = g_bn_bwd_cap > 1024 ? (g_bn_bwd_cap > 2048 ? 2 : 4) : (g_bn_bwd_cap == 0 && a.m_per_group / PT < 1024 ? 4 : 8);
+    const int cap = g_bn_bwd_cap ? g_bn_bwd_cap : 1024;
+    const int64_t per_block_pixels = (int64_t)PT * passes;
+    const int bx = (int)std::max<int64_t>(1, std::min<int64_t>(std::max(1, cap / a.G), (a.m_per_group + per_block_pixels - 1) / per_block_pixels));
     ProfScope ps(PROF_BN, s);
     const size_t sm1 = (size_t)a.nsets * 2 * PT * a.C * 4;
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(bx, a.G), dim3(256), sm1, s, a);
-    OCL_LAUNCH_CHECK();
+    if (g_bn_bwd_phase != 2) {
+        if (U == 1) hipLaunchKernelGGL(bn_bwd_reduce_kernel<1>, dim3(bx, a.G), dim3(256), sm1, s, a);
+        else if (U == 2) hipLaunchKernelGGL(bn_bwd_reduce_kernel<2>, dim3(bx, a.G), dim3(256), sm1, s, a);
+        else hipLaunchKernelGGL(bn_bwd_reduce_kernel<4>, dim3(bx, a.G), dim3(256), sm1, s, a);
+        OCL_LAUNCH_CHECK();
+    }
+    if (g_bn_bwd_phase == 1) return OCL_OK;
     const int64_t units = a.m_per_group * C4;
     const int bx2 = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (units + 1023) / 1024));
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bx2, a.G), dim3(256), (size_t)a.nsets * 5 * a.C * 4, s, a);

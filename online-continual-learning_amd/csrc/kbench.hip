@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <math.h>
+#include <time.h>
 #include <string>
 #include <vector>
 
@@ -243,6 +244,103 @@ static void peak_case(const char* name, int blocks_per_cu, float* out) {
            flops / t * 1e-6, t * 1e-6 * 2.4e9 / ((double)blocks_per_cu * iters * NACC));
 }
 
+
+// ---- launch-cost probe: n dependent kernels of ~dur_us each, issued as stream launches or as one captured graph ----------
+__global__ void spin_kernel(float* p, int iters) {
+    float v = p[threadIdx.x];
+    for (int i = 0; i < iters; ++i) v = fmaf(v, 1.0001f, 0.5f);
+    p[threadIdx.x] = v;
+}
+struct FatArgs { float* p; int iters; int pad[90]; };   // ~376 B of kernel arguments, like ConvArgs
+__global__ void spin_kernel_fat(const FatArgs a) {
+    float v = a.p[threadIdx.x];
+    for (int i = 0; i < a.iters; ++i) v = fmaf(v, 1.0001f, 0.5f);
+    a.p[threadIdx.x] = v;
+}
+static double now_us() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+}
+static void launch_probe() {
+    float* p;
+    CK(hipMalloc(&p, 1 << 20));
+    CK(hipMemset(p, 0, 1 << 20));
+    hipStream_t st, s2;
+    CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+    std::vector<hipEvent_t> evs(512);
+    for (auto& e : evs) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    const int n = 200;
+    // variant 0: linear chain; 1: + a memset node every 10 kernels; 2: fork/join to a second stream every 5 kernels (1 kernel on the
+    // side branch, joined at the end only); 3: like 2 but joined back before the next fork
+    for (int variant = 0; variant < 4; ++variant)
+    for (int iters : {0, 2000}) {
+        for (int fat = 1; fat < 2; ++fat) {
+            auto k = [&](hipStream_t s, int off) {
+                FatArgs a; memset(&a, 0, sizeof(a)); a.p = p + off * 256; a.iters = iters;
+                hipLaunchKernelGGL(spin_kernel_fat, dim3(256), dim3(256), 0, s, a);
+            };
+            auto issue = [&](hipStream_t s) {
+                int ne = 0;
+                for (int i = 0; i < n; ++i) {
+                    k(s, 0);
+                    if (variant == 1 && i % 10 == 0) CK(hipMemsetAsync(p + 512 * 256, 0, 4096, s));
+                    if (variant >= 2 && i % 5 == 0) {
+                        CK(hipEventRecord(evs[ne], s));
+                        CK(hipStreamWaitEvent(s2, evs[ne], 0));
+                        ++ne;
+                        k(s2, 1 + i);
+                        if (variant == 3) {
+                            CK(hipEventRecord(evs[ne], s2));
+                            CK(hipStreamWaitEvent(s, evs[ne], 0));
+                            ++ne;
+                        }
+                    }
+                }
+                if (variant >= 2) {
+                    CK(hipEventRecord(evs[ne], s2));
+                    CK(hipStreamWaitEvent(s, evs[ne], 0));
+                }
+            };
+            issue(st);
+            CK(hipStreamSynchronize(st));
+            double h0 = now_us();
+            issue(st);
+            double h1 = now_us();
+            CK(hipStreamSynchronize(st));
+            double h2 = now_us();
+            hipGraph_t g;
+            hipGraphExec_t ge;
+            CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            issue(st);
+            CK(hipStreamEndCapture(st, &g));
+            double i0 = now_us();
+            CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            double i1 = now_us();
+            CK(hipGraphLaunch(ge, st));
+            CK(hipStreamSynchronize(st));
+            double g0 = now_us();
+            CK(hipGraphLaunch(ge, st));
+            double g1 = now_us();
+            CK(hipStreamSynchronize(st));
+            double g2 = now_us();
+            // launched on the legacy default stream, as torch does
+            CK(hipGraphLaunch(ge, 0));
+            CK(hipStreamSynchronize(0));
+            double d0 = now_us();
+            CK(hipGraphLaunch(ge, 0));
+            double d1 = now_us();
+            CK(hipStreamSynchronize(0));
+            double d2 = now_us();
+            printf("launch probe variant %d iters=%5d: stream: host %.2f us/launch, total %.2f | graph: instantiate %.0f us, host %.2f us/node, total %.2f | on stream 0: host %.2f total %.2f\n",
+                   variant, iters, (h1 - h0) / n, (h2 - h0) / n, i1 - i0, (g1 - g0) / n, (g2 - g0) / n, (d1 - d0) / n, (d2 - d0) / n);
+            CK(hipGraphExecDestroy(ge));
+            CK(hipGraphDestroy(g));
+        }
+    }
+}
+
 int main(int argc, char** argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 220;
     const int groups = argc > 2 ? atoi(argv[2]) : 2;
@@ -290,6 +388,7 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&stats, kStatReps * 8 * 2 * 1024 * 8));
     CK(hipMemset(stats, 0, kStatReps * 8 * 2 * 1024 * 8));
     printf("# kbench N=%d groups=%d hw=%d\n", N, groups, hw);
+    if (mode == "launch") { launch_probe(); return 0; }
     if (mode == "all" || mode == "peak") {
         peak_case<4, false>("regs only", 1, bufB);
         peak_case<4, false>("regs only", 2, bufB);
@@ -363,7 +462,7 @@ int main(int argc, char** argv) {
         int lastC = -1, lastH = -1;
         float* small = dev_rand(64 * 1024, 9);
         double* sums;
-        CK(hipMalloc(&sums, 8 * 4 * 1024 * 8));
+        CK(hipMalloc(&sums, 8 * 4 * 1024 * 8 + (size_t)2048 * 4 * 1024 * 8));
         for (auto& l : layers) {
             const ConvShape& c = l.s;
             if (c.Cout == lastC && c.Ho == lastH) continue;
@@ -387,6 +486,47 @@ int main(int argc, char** argv) {
             const double bytes = (double)N * c.Ho * c.Wo * c.Cout * 4;
             printf("bn C=%3d HW=%2d  elems=%9.0f  fwd(3 tensors) %6.1f us %5.2f TB/s   bwd(reduce+apply, 7 tensor passes) %6.1f us %5.2f TB/s\n",
                    c.Cout, c.Ho, bytes / 4, tf, 3 * bytes / tf * 1e-6, tb, 7 * bytes / tb * 1e-6);
+            if (sweep) {
+                bn_bwd_tune(0, 0, 2);
+                const double ta = time_us([&] { OK(launch_bn_bwd(b, 0)); });
+                printf("    apply only %6.1f us %5.2f TB/s;  reduce only (3 tensors) cap x unroll:", ta, 4 * bytes / ta * 1e-6);
+                for (int cap : {128, 256, 512, 1024, 2048})
+                    for (int U : {1, 2, 4}) {
+                        bn_bwd_tune(cap, U, 1);
+                        const double tr = time_us([&] { OK(launch_bn_bwd(b, 0)); });
+                        printf(" %dx%d:%.1f", cap, U, tr);
+                    }
+                printf("\n");
+                bn_bwd_tune(0, 0, 0);
+                // HBM-cold: rotate through R tensor sets whose footprint exceeds the 256 MB MALL (y, z as in the real step: written long ago)
+                {
+                    const int R = 12;
+                    const size_t el = (size_t)N * c.Ho * c.Wo * c.Cout;
+                    static float* pool = nullptr;
+                    if (!pool) pool = dev_rand((size_t)R * 4 * max_act, 77);
+                    int it = 0;
+                    auto setb = [&](bool hot_dz) {
+                        float* base = pool + (size_t)(it % R) * 4 * el;
+                        b.dz = hot_dz ? bufA : base; b.z = base + el; b.y[0] = base + 2 * el; b.dy[0] = base + 3 * el;
+                        f.y = base; f.z = base + el; f.res = base + 2 * el;
+                        ++it;
+                    };
+                    const double tfc = time_us([&] { setb(false); OK(launch_bn_fwd(f, 0)); }, 24, 12);
+                    printf("    cold: fwd %.1f us (%.2f TB/s)", tfc, 3 * bytes / tfc * 1e-6);
+                    bn_bwd_tune(0, 0, 2);
+                    const double tac = time_us([&] { setb(true); OK(launch_bn_bwd(b, 0)); }, 24, 12);
+                    printf("  apply %.1f us (%.2f TB/s)  reduce capxU:", tac, 4 * bytes / tac * 1e-6);
+                    for (int cap : {512, 1024, 2048, 4096})
+                        for (int U : {1, 2, 4}) {
+                            bn_bwd_tune(cap, U, 1);
+                            const double tr = time_us([&] { setb(true); OK(launch_bn_bwd(b, 0)); }, 24, 12);
+                            printf(" %dx%d:%.1f", cap, U, tr);
+                        }
+                    printf("\n");
+                    bn_bwd_tune(0, 0, 0);
+                    b.dz = bufA; b.z = bufB; b.y[0] = bufC; b.dy[0] = bufD; f.y = bufA; f.z = bufB; f.res = bufC;
+                }
+            }
         }
     }
     return 0;

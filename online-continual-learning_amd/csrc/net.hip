@@ -3,10 +3,12 @@
 // :140-168 (SupConResNet) of the reference; parameters stay in PyTorch's named_parameters() order and OIHW layout.
 #include "conv.h"
 #include <string.h>
+#include <stdlib.h>
 #include <string>
 #include <vector>
 #include <map>
 #include <algorithm>
+#include <tuple>
 
 using namespace ocl;
 
@@ -103,6 +105,29 @@ struct ocl_net {
     bool ev_done_pending[6] = {false, false, false, false, false, false};
     hipEvent_t ev_join = nullptr;
     int dy_next = 0;
+
+    // hipGraph cache: the launch sequence of a forward / backward depends only on the key below (all other pointers are
+    // engine-owned or bound once), so from the kGraphWarmCalls-th call with the same key on it is replayed as one graph
+    // launch: ~0.1 us of host time per kernel node instead of 4-5 us per hipLaunchKernel (measured, kbench launch).
+    struct GraphKey {
+        int kind, N, groups, slot, aux;
+        uint32_t flags;
+        const float* P;
+        bool operator<(const GraphKey& o) const {
+            return std::tie(kind, N, groups, slot, aux, flags, P) < std::tie(o.kind, o.N, o.groups, o.slot, o.aux, o.flags, o.P);
+        }
+    };
+    struct GraphEntry {
+        hipGraphExec_t exec = nullptr;
+        int hits = 0;
+        bool failed = false;
+        uint64_t last_use = 0;
+    };
+    std::map<GraphKey, GraphEntry> graphs;
+    uint64_t graph_clock = 0;
+    hipStream_t sc = nullptr;   // capture stream (the caller's stream may be the legacy default stream, which cannot capture)
+    int64_t graph_launches = 0, graph_captures = 0;
+    bool graphs_on = true;
 };
 
 // -----------------------------------------------------------------------------------------------------
@@ -435,6 +460,115 @@ static int head_forward(ocl_net* n, const float* P, float* feat, float* h1, floa
     return rc;
 }
 
+// -----------------------------------------------------------------------------------------------------
+// hipGraph replay of a launch sequence
+// -----------------------------------------------------------------------------------------------------
+static const int kGraphWarmCalls = 2;     // eager calls with a key before it is captured (lazy allocations, plans, rare shapes)
+static const size_t kMaxGraphs = 48;
+
+// OCL_GRAPH_MODE (experiments): 0 = never, 1 = every forward and backward, 2 (default) = forwards, and backwards of batches below
+// kTwoStreamMinBatch (larger ones are GPU-bound and gain more from the eager two-stream schedule than from a single-chain graph)
+static const int kTwoStreamMinBatch = 48;
+static int graph_mode() {
+    static const int m = [] {
+        const char* off = getenv("OCL_NO_GRAPH");
+        if (off && off[0] == '1') return 0;
+        const char* e = getenv("OCL_GRAPH_MODE");
+        return e ? atoi(e) : 2;
+    }();
+    return m;
+}
+static bool graphs_enabled(const ocl_net* n, bool backward = false, int N = 0) {
+    if (!n->graphs_on || prof_on() || n->dbg_stop >= 0) return false;
+    const int m = graph_mode();
+    if (m == 0) return false;
+    if (m == 1 || !backward) return true;
+    return N < kTwoStreamMinBatch;
+}
+
+static int ensure_side_stream(ocl_net* n) {
+    if (n->s2) return OCL_OK;
+    OCL_HIP(hipStreamCreateWithFlags(&n->s2, hipStreamNonBlocking));
+    for (int i = 0; i < ocl_net::kDyRing; ++i) OCL_HIP(hipEventCreateWithFlags(&n->ev_done[i], hipEventDisableTiming));
+    OCL_HIP(hipEventCreateWithFlags(&n->ev_join, hipEventDisableTiming));
+    for (int i = 0; i < 24; ++i) {   // one per publish() of a backward (2 per block + stem); created up front: none during capture
+        hipEvent_t e;
+        OCL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        n->ev_ready.push_back(e);
+    }
+    return OCL_OK;
+}
+
+// body(stream, capturing): issues the launches.  Returns through *replayed whether a graph ran instead of the eager body.
+template <class F>
+static int run_cached(ocl_net* n, const ocl_net::GraphKey& key, hipStream_t s, bool enabled, F&& body) {
+    if (!enabled) return body(s, false);
+    ocl_net::GraphEntry& e = n->graphs[key];
+    e.last_use = ++n->graph_clock;
+    if (e.exec) {
+        OCL_HIP(hipGraphLaunch(e.exec, s));
+        ++n->graph_launches;
+        return OCL_OK;
+    }
+    if (e.failed || ++e.hits <= kGraphWarmCalls) {
+        if (n->graphs.size() > 4 * kMaxGraphs) {   // keys that never repeat (fresh parameter pointers): forget the cold ones
+            for (auto it = n->graphs.begin(); it != n->graphs.end();)
+                it = (!it->second.exec && it->second.last_use + 2 * kMaxGraphs < n->graph_clock) ? n->graphs.erase(it) : std::next(it);
+        }
+        return body(s, false);
+    }
+    int rc = ensure_side_stream(n);
+    if (rc != OCL_OK) return rc;
+    if (!n->sc) OCL_HIP(hipStreamCreateWithFlags(&n->sc, hipStreamNonBlocking));
+    hipError_t he = hipStreamBeginCapture(n->sc, hipStreamCaptureModeThreadLocal);
+    if (he != hipSuccess) {
+        (void)hipGetLastError();
+        e.failed = true;
+        return body(s, false);
+    }
+    rc = body(n->sc, true);
+    hipGraph_t g = nullptr;
+    he = hipStreamEndCapture(n->sc, &g);
+    if (rc != OCL_OK || he != hipSuccess || !g) {
+        (void)hipGetLastError();
+        if (g) (void)hipGraphDestroy(g);
+        e.failed = true;
+        if (rc != OCL_OK) return rc;
+        return body(s, false);
+    }
+    hipGraphExec_t ex = nullptr;
+    he = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (he != hipSuccess || !ex) {
+        (void)hipGetLastError();
+        e.failed = true;
+        return body(s, false);
+    }
+    e.exec = ex;
+    ++n->graph_captures;
+    size_t live = 0;
+    for (auto& kv : n->graphs) live += kv.second.exec != nullptr;
+    if (live > kMaxGraphs) {   // drop the least recently used executable
+        auto victim = n->graphs.end();
+        for (auto it = n->graphs.begin(); it != n->graphs.end(); ++it)
+            if (it->second.exec && it->second.exec != ex && (victim == n->graphs.end() || it->second.last_use < victim->second.last_use))
+                victim = it;
+        if (victim != n->graphs.end()) {
+            (void)hipGraphExecDestroy(victim->second.exec);
+            n->graphs.erase(victim);
+        }
+    }
+    OCL_HIP(hipGraphLaunch(ex, s));
+    ++n->graph_launches;
+    return OCL_OK;
+}
+
+static void drop_graphs(ocl_net* n) {
+    for (auto& kv : n->graphs)
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    n->graphs.clear();
+}
+
 // =====================================================================================================
 // C ABI
 // =====================================================================================================
@@ -463,7 +597,9 @@ void ocl_net_destroy(ocl_net* net) {
     for (int i = 0; i < ocl_net::kDyRing; ++i)
         if (net->ev_done[i]) (void)hipEventDestroy(net->ev_done[i]);
     if (net->ev_join) (void)hipEventDestroy(net->ev_join);
+    drop_graphs(net);
     if (net->s2) (void)hipStreamDestroy(net->s2);
+    if (net->sc) (void)hipStreamDestroy(net->sc);
     delete net;
 }
 
@@ -514,6 +650,7 @@ int ocl_net_bind(ocl_net* net, float* params, float* grads, float* running, int6
     net->bound = true;
     net->descs_uploaded = false;
     net->pack_src = nullptr;
+    drop_graphs(net);   // they hold the previous binding's pointers
     for (size_t i = 0; i < net->slot_valid.size(); ++i) net->slot_valid[i] = false;
     return OCL_OK;
 }
@@ -538,21 +675,26 @@ int ocl_net_forward(ocl_net* n, const float* x, int N, int groups, uint32_t flag
     float* pack = (float*)(n->ws + n->off_pack);
     int max_elems = 0;
     for (auto& c : n->convs) max_elems = std::max(max_elems, c.Cout * c.Cin * c.k * c.k);
-    rc = launch_pack_weights(P, pack, pack_descs(n), (int)n->convs.size(), max_elems, s);   // every forward: the caller
-    if (rc != OCL_OK) return rc;                                                               // may have stepped the weights
-    n->pack_src = P;
 
     float* S = n->slotf(slot);
     float* x4 = S + n->x4_off;
-    rc = launch_nchw3_to_nhwc4(x, x4, N, n->d.in_h, n->d.in_w, s);
+    rc = launch_nchw3_to_nhwc4(x, x4, N, n->d.in_h, n->d.in_w, s);   // the only reader of the caller's input: outside the graph
     if (rc != OCL_OK) return rc;
     n->slot_valid[slot] = false;
 
-    const bool feat_direct = feat_out && !out && !(flags & OCL_FWD_SAVE_TAPE);   // features only (ASER scoring, NCM): no copy
+    // A replayed graph must not hold caller pointers: with graphs on, results land in engine buffers and are copied out below.
+    const bool cached = graphs_enabled(n);
+    const bool want_head = out || (flags & OCL_FWD_SAVE_TAPE);
+    const bool feat_direct = !cached && feat_out && !want_head;   // features only (ASER scoring, NCM): no copy
     float* feat = feat_direct ? feat_out : S + n->feat_off;
+    float* o = S + n->out_off;
+    bool wrote = false;
+    auto body = [&](hipStream_t st, bool) -> int {
+    int rc = launch_pack_weights(P, pack, pack_descs(n), (int)n->convs.size(), max_elems, st);   // every forward: the caller
+    if (rc != OCL_OK) return rc;                                                                    // may have stepped the weights
     if (train) {
         double* stats = (double*)(n->ws + n->off_stats);
-        OCL_HIP(hipMemsetAsync(stats, 0, n->stats_doubles * 8, s));
+        OCL_HIP(hipMemsetAsync(stats, 0, n->stats_doubles * 8, st));
         const bool upd = (flags & OCL_FWD_UPDATE_RUNNING) != 0;
         auto bn_fwd = [&](int conv_i, const float* y, float* z, const float* res, int relu) -> int {
             const ConvInfo& c = n->convs[conv_i];
@@ -572,12 +714,12 @@ int ocl_net_forward(ocl_net* n, const float* x, int N, int groups, uint32_t flag
             a.m_per_group = (int64_t)(N / groups) * c.Ho * c.Wo;
             a.G = groups; a.C = b.C; a.relu = relu;
             a.momentum = 0.1f; a.eps = 1e-5f;
-            return launch_bn_fwd(a, s);
+            return launch_bn_fwd(a, st);
         };
         auto conv_stats = [&](int conv_i, const float* in) -> int {
             const ConvInfo& c = n->convs[conv_i];
             return run_conv(n, ps->fwd[conv_i], in, pack + c.f_off, S + c.y_off, EPI_STATS, stats + n->bns[c.bn].arena_off, nullptr,
-                            nullptr, nullptr, nullptr, s);
+                            nullptr, nullptr, nullptr, st);
         };
         // stem
         if ((rc = conv_stats(0, x4))) return rc;
@@ -599,16 +741,16 @@ int ocl_net_forward(ocl_net* n, const float* x, int N, int groups, uint32_t flag
             if ((rc = bn_fwd(b.conv2, S + n->convs[b.conv2].y_off, z, res, 1))) return rc;
             cur = z;
         }
-        if ((rc = launch_avgpool_fwd(cur, feat, N, n->Hf, n->Wf, n->convs[n->blocks.back().conv2].Cout, s))) return rc;
+        if ((rc = launch_avgpool_fwd(cur, feat, N, n->Hf, n->Wf, n->convs[n->blocks.back().conv2].Cout, st))) return rc;
     } else {
         float* fold = (float*)(n->ws + n->off_fold);
-        if ((rc = launch_bn_fold(P, n->running, fold, fold_descs(n), (int)n->bns.size(), 1e-5f, s))) return rc;
+        if ((rc = launch_bn_fold(P, n->running, fold, fold_descs(n), (int)n->bns.size(), 1e-5f, st))) return rc;
         auto conv_eval = [&](int conv_i, const float* in, float* o, const float* res, int relu) -> int {
             const ConvInfo& c = n->convs[conv_i];
             const BnInfo& b = n->bns[c.bn];
             int fl = EPI_AFFINE | (res ? EPI_RES : 0) | (relu ? EPI_RELU : 0);
             return run_conv(n, ps->fwd[conv_i], in, pack + c.f_off, o, fl, nullptr, fold + b.stat_off, fold + b.stat_off + b.C, res,
-                            nullptr, s);
+                            nullptr, st);
         };
         float* bufs[4] = {n->gbuf(0), n->gbuf(1), n->gbuf(2), n->gbuf(3)};
         float* cur = bufs[0];
@@ -628,15 +770,20 @@ int ocl_net_forward(ocl_net* n, const float* x, int N, int groups, uint32_t flag
             cur = z;
             ci = (ci + 3) & 3;
         }
-        if ((rc = launch_avgpool_fwd(cur, feat, N, n->Hf, n->Wf, n->convs[n->blocks.back().conv2].Cout, s))) return rc;
+        if ((rc = launch_avgpool_fwd(cur, feat, N, n->Hf, n->Wf, n->convs[n->blocks.back().conv2].Cout, st))) return rc;
     }
+    if (want_head) {
+        bool w2 = false;
+        if ((rc = head_forward(n, P, feat, S + n->h1_off, S + n->h2_off, S + n->norms_off, o, N, st, cached ? nullptr : out, &w2))) return rc;
+        wrote = w2 && !cached;
+    }
+    return OCL_OK;
+    };
+    ocl_net::GraphKey key{0, N, groups, slot, (want_head ? 1 : 0) | (feat_out ? 2 : 0), flags, P};
+    if ((rc = run_cached(n, key, s, cached, body))) return rc;
+    n->pack_src = P;
     if (feat_out && !feat_direct) OCL_HIP(hipMemcpyAsync(feat_out, feat, (size_t)N * n->feat_dim * 4, hipMemcpyDeviceToDevice, s));
-    if (out || (flags & OCL_FWD_SAVE_TAPE)) {
-        float* o = S + n->out_off;
-        bool wrote = false;
-        if ((rc = head_forward(n, P, feat, S + n->h1_off, S + n->h2_off, S + n->norms_off, o, N, s, out, &wrote))) return rc;
-        if (out && !wrote) OCL_HIP(hipMemcpyAsync(out, o, (size_t)N * n->out_dim * 4, hipMemcpyDeviceToDevice, s));
-    }
+    if (out && !wrote) OCL_HIP(hipMemcpyAsync(out, o, (size_t)N * n->out_dim * 4, hipMemcpyDeviceToDevice, s));
     if (train && (flags & OCL_FWD_SAVE_TAPE) && !params_override) {
         n->slot_valid[slot] = true;
         n->slot_n[slot] = N;
@@ -650,7 +797,7 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
     OCL_REQUIRE(slot >= 0 && slot < n->d.n_slots && n->slot_valid[slot],
                 "net_backward: slot %d holds no train-mode forward tape (forward with OCL_FWD_TRAIN|OCL_FWD_SAVE_TAPE first)", slot);
     OCL_REQUIRE(dout, "net_backward: null dout");
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t s0 = (hipStream_t)stream;
     const int N = n->slot_n[slot], G = n->slot_groups[slot];
     PlanSet* ps = nullptr;
     int rc = get_plans(n, N, G, &ps);
@@ -662,17 +809,26 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
     float* pack = (float*)(n->ws + n->off_pack);
     float* partial = (float*)(n->ws + n->off_partial);
     double* bsums = (double*)(n->ws + n->off_bsums);
+    const bool repack = n->pack_src != P;   // the arena was rewritten by a forward of MIR's virtual model since the taped forward
+    const int FD = n->feat_dim, OD = n->out_dim;
+    float* hb = (float*)(n->ws + n->off_head);
+    // A replayed graph must not hold the caller's pointer: with graphs on, dL/dout is staged in an engine buffer first.
+    const bool cached = graphs_enabled(n, true, N);
+    if (cached) {
+        float* stage = hb + (int64_t)n->d.max_batch * FD * 3;
+        OCL_HIP(hipMemcpyAsync(stage, dout, (size_t)N * (n->d.head == 3 ? FD : OD) * 4, hipMemcpyDeviceToDevice, s0));
+        dout = stage;
+    }
+    auto body = [&](hipStream_t s, bool capturing) -> int {
+    int rc = OCL_OK;
     OCL_HIP(hipMemsetAsync(bsums, 0, n->bsums_doubles * 8, s));
-    if (n->pack_src != P) {   // the arena was rewritten by a forward of MIR's virtual model since the taped forward
+    if (repack) {
         int max_elems = 0;
         for (auto& c : n->convs) max_elems = std::max(max_elems, c.Cout * c.Cin * c.k * c.k);
         if ((rc = launch_pack_weights(P, pack, pack_descs(n), (int)n->convs.size(), max_elems, s))) return rc;
-        n->pack_src = P;
     }
     auto T = [&](int t) { return P + n->tensors[t].off; };
     auto GT = [&](int t) { return Gr + n->tensors[t].off; };
-    const int FD = n->feat_dim, OD = n->out_dim;
-    float* hb = (float*)(n->ws + n->off_head);
     float* dfeat = hb;
     float* dh1 = hb + (int64_t)N * FD;
     float* dh2 = dh1 + (int64_t)N * FD;
@@ -725,12 +881,15 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
 
     // replay batches of 10-20 images are launch-latency-bound: the event traffic costs more than the overlap returns there;
     // the debug stops expose intermediate buffers: single stream as well
-    const bool two_streams = n->dbg_stop < 0 && N >= 48;
-    if (two_streams && !n->s2) {
-        OCL_HIP(hipStreamCreateWithFlags(&n->s2, hipStreamNonBlocking));
-        for (int i = 0; i < ocl_net::kDyRing; ++i) OCL_HIP(hipEventCreateWithFlags(&n->ev_done[i], hipEventDisableTiming));
-        OCL_HIP(hipEventCreateWithFlags(&n->ev_join, hipEventDisableTiming));
-    }
+    // measurement runs (ocl_prof_enable, OCL_SINGLE_STREAM=1) keep everything on the caller's stream so that per-kernel durations
+    // are those of the kernel alone, not of the kernel sharing the CUs with a weight-gradient kernel
+    // A captured graph stays a single chain: on ROCm 7.2 a graph with a long-lived parallel branch leaves the fast path (measured
+    // with kbench launch: 4 us of host time per node and 10-17 ms to instantiate, against 0.07 us per node for a chain).
+    static const bool env_single = [] { const char* e = getenv("OCL_SINGLE_STREAM"); return e && e[0] == '1'; }();
+    const bool two_streams = n->dbg_stop < 0 && N >= kTwoStreamMinBatch && !capturing && !prof_on() && !env_single;
+    if (two_streams && (rc = ensure_side_stream(n))) return rc;
+    n->dy_next = 0;
+    for (int i = 0; i < ocl_net::kDyRing; ++i) n->ev_done_pending[i] = false;
     hipStream_t sw = two_streams ? n->s2 : s;   // stream of the weight gradients
     size_t ready_used = 0;
     auto take_dy = [&](int* slot_out) -> float* {   // next ring slot; the main stream waits for its previous readers
@@ -867,6 +1026,24 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
         OCL_HIP(hipStreamWaitEvent(s, n->ev_join, 0));
         for (int i = 0; i < ocl_net::kDyRing; ++i) n->ev_done_pending[i] = false;   // covered by the join
     }
+    return OCL_OK;
+    };
+    ocl_net::GraphKey key{1, N, G, slot, (accumulate ? 1 : 0) | (repack ? 2 : 0), 0u, P};
+    if ((rc = run_cached(n, key, s0, cached, body))) return rc;
+    n->pack_src = P;
+    return OCL_OK;
+}
+
+int ocl_net_graph_enable(ocl_net* n, int on) {
+    OCL_REQUIRE(n, "graph_enable: null net");
+    n->graphs_on = on != 0;
+    return OCL_OK;
+}
+
+int ocl_net_graph_stats(const ocl_net* n, int64_t* launches, int64_t* captures) {
+    OCL_REQUIRE(n, "graph_stats: null net");
+    if (launches) *launches = n->graph_launches;
+    if (captures) *captures = n->graph_captures;
     return OCL_OK;
 }
 

@@ -335,3 +335,48 @@ def test_edge_batch_sizes_train_and_eval_forward(cuda, n):
     out.sum().backward()
     g = m.flat_grads().cpu().numpy()
     assert np.isfinite(g).all() and np.abs(g).max() > 0
+
+
+def _graph_stats(m):
+    from ocl_amd import ffi
+    a, b = ffi.i64(0), ffi.i64(0)
+    ffi.check(ffi.lib().ocl_net_graph_stats(m._net, C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
+@pytest.mark.parametrize("agent,head,n,groups", [("ER", None, 10, 1), ("SCR", "mlp", 60, 2), ("SCR", "mlp", 14, 2)])
+def test_graph_replay_matches_eager_launches(cuda, agent, head, n, groups):
+    """The hipGraph replay of a forward/backward (third call with the same shape on) against the same engine with
+    graphs off: outputs, parameter gradients, BatchNorm running statistics over 8 SGD-free steps on fresh inputs
+    (activation slots alternate, so each of the 2 slots captures its forward and backward at its third use).
+    Same kernels, same arguments; the only freedom is the order of the fp64 statistic atomics (1e-6 relative)."""
+    from ocl_amd import ffi
+    results = []
+    for graphs in (1, 0):
+        m, sd = build(agent, "cifar100", head or "mlp", cuda=cuda, max_batch=64)
+        m._ensure_bound()
+        ffi.check(ffi.lib().ocl_net_graph_enable(m._net, graphs))
+        m.train()
+        per = n // groups
+        rng = np.random.default_rng(5)
+        outs = []
+        for step in range(8):
+            xd = torch.from_numpy(rng.random((n, 3, 32, 32)).astype(np.float32)).to(cuda)
+            wd = torch.from_numpy(rng.standard_normal((n // groups if head else n, 1)).astype(np.float32)).to(cuda)
+            out = m.forward(xd) if groups == 1 else m.forward_views([xd[g * per:(g + 1) * per] for g in range(groups)])
+            m.zero_grad()
+            (out.reshape(wd.shape[0], -1) * wd).sum().backward()
+            outs.append((out.detach().cpu().numpy().copy(), m.flat_grads().cpu().numpy().copy()))
+        torch.cuda.synchronize()
+        launches, captures = _graph_stats(m)
+        if graphs:
+            assert captures == 4 and launches == 8, (launches, captures)     # (forward + backward) x 2 slots, steps 5..8 replayed
+        else:
+            assert launches == 0 and captures == 0
+        results.append((outs, {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items() if "running" in k}))
+    (og, rg), (oe, re_) = results
+    for (o1, g1), (o2, g2) in zip(og, oe):
+        assert relmax(o1, o2) < 1e-6
+        assert relmax(g1, g2) < 1e-5
+    for k in rg:
+        assert relmax(rg[k], re_[k]) < 1e-6, k
