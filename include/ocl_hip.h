@@ -200,12 +200,13 @@ int ocl_net_backward(ocl_net* net, int slot, const float* dout, int accumulate, 
  * 2: conv2 data gradient, 3: bn1 backward, 4: conv1 data gradient, 5: block input gradient complete; 990: after the
  * head; -1: off).  debug_copy what: 0 raw conv output (NHWC) of conv `index`; 1 output of block `index`; 2 gradient
  * scratch buffer `index`; 3 gradient buffer by role (0..4 = gA..gE) at the last stop; 4 activation a1 of block `index`; 5 stem output. */
-/* hipGraph replay.  From the third call with the same (batch size, groups, flags, slot, parameter array) on, the launch
- * sequence of ocl_net_forward / ocl_net_backward is captured once and replayed with one hipGraphLaunch on the caller's
- * stream; caller-owned pointers (x, feat_out, out, dout) never enter a graph (they are read / written by eager launches
- * around it).  On by default; off while ocl_prof_enable(1), after ocl_net_debug_stop(>=0), or with OCL_NO_GRAPH=1 in
- * the environment.  Stats: graph launches and captures so far. */
-int ocl_net_graph_enable(ocl_net* net, int on);
+/* Schedule of a two-view (groups == 2) train-mode pass.  mode 0 (default): one chain of launches over both views (weight
+ * gradients of batches >= 48 on a second stream).  mode 1: one chain per view on two streams, each captured at its third use
+ * with the same (batch size, flags, slot, parameter array) and replayed with one hipGraphLaunch; caller-owned pointers never
+ * enter a graph.  mode 2: the same two chains with eager launches.  mode -1: take OCL_DUAL_CHAIN from the environment
+ * (default 0).  Measurement runs (ocl_prof_enable, OCL_SINGLE_STREAM=1) and debug stops always use mode 0.
+ * Stats: graph launches and captures so far. */
+int ocl_net_graph_enable(ocl_net* net, int mode);
 int ocl_net_graph_stats(const ocl_net* net, int64_t* launches, int64_t* captures);
 
 int ocl_net_debug_stop(ocl_net* net, int stage);

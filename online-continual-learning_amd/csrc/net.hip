@@ -94,16 +94,24 @@ struct ocl_net {
     std::vector<bool> slot_valid;
     std::map<std::pair<int, int>, PlanSet> plans;
 
+    // scratch of the second chain (dual-chain passes, see ocl_net_forward) + its gradient staging array
+    int64_t off_g2[5] = {0, 0, 0, 0, 0}, off_dy2[6] = {0, 0, 0, 0, 0, 0};
+    int64_t off_partial2 = 0, off_stats2 = 0, off_bsums2 = 0, off_grad2 = 0;
+    int64_t trunk_params = 0;   // the trunk's tensors occupy [0, trunk_params) of the flat parameter array
+
     float* slotf(int slot) const { return (float*)(ws + slot_base + (int64_t)slot * slot_bytes); }
-    float* gbuf(int i) const { return (float*)(ws + off_g[i]); }
-    float* dybuf(int i) const { return (float*)(ws + off_dy[i]); }
+    float* gbuf(int i, int ch = 0) const { return (float*)(ws + (ch ? off_g2[i] : off_g[i])); }
+    float* dybuf(int i, int ch = 0) const { return (float*)(ws + (ch ? off_dy2[i] : off_dy[i])); }
+    float* partialbuf(int ch) const { return (float*)(ws + (ch ? off_partial2 : off_partial)); }
+    double* statsbuf(int ch) const { return (double*)(ws + (ch ? off_stats2 : off_stats)); }
+    double* bsumsbuf(int ch) const { return (double*)(ws + (ch ? off_bsums2 : off_bsums)); }
 
     // second stream for the weight gradients + events (created on first backward)
     hipStream_t s2 = nullptr;
     std::vector<hipEvent_t> ev_ready;      // main -> s2: a dL/dy buffer has been written
     hipEvent_t ev_done[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // s2 -> main: ring slot no longer read
     bool ev_done_pending[6] = {false, false, false, false, false, false};
-    hipEvent_t ev_join = nullptr;
+    hipEvent_t ev_join = nullptr, ev_fork = nullptr;
     int dy_next = 0;
 
     // hipGraph cache: the launch sequence of a forward / backward depends only on the key below (all other pointers are
@@ -127,7 +135,7 @@ struct ocl_net {
     uint64_t graph_clock = 0;
     hipStream_t sc = nullptr;   // capture stream (the caller's stream may be the legacy default stream, which cannot capture)
     int64_t graph_launches = 0, graph_captures = 0;
-    bool graphs_on = true;
+    int dual_mode = -1;   // -1: default (environment), 0: single chain, 1: dual chain replayed as graphs, 2: dual chain, eager launches
 };
 
 // -----------------------------------------------------------------------------------------------------
@@ -327,6 +335,20 @@ static int build_layout(ocl_net* n) {
     n->off_descs = takeb((int64_t)(n->convs.size() * sizeof(PackDesc) + n->bns.size() * sizeof(BnFoldDesc) + 256));
     n->head_floats = N * ((int64_t)n->feat_dim * 3 + n->out_dim * 2 + 64);
     n->off_head = takeb(n->head_floats * 4);
+    for (int i = 0; i < 5; ++i) n->off_g2[i] = takeb(max_act * 4);
+    for (int i = 0; i < ocl_net::kDyRing; ++i) n->off_dy2[i] = takeb(max_act * 4);
+    n->off_partial2 = takeb(n->partial_floats * 4);
+    n->off_stats2 = takeb(n->stats_doubles * 8);
+    n->off_bsums2 = takeb(so * 8);
+    n->off_grad2 = takeb(n->n_params * 4);
+    {   // conv / BatchNorm tensors were added first: they form a prefix of the flat array
+        int64_t end = 0, sum = 0;
+        for (auto& cv : n->convs) { end = std::max(end, n->tensors[cv.w_t].off + n->tensors[cv.w_t].numel); sum += n->tensors[cv.w_t].numel; }
+        for (auto& b : n->bns) {
+            for (int t : {b.gamma_t, b.beta_t}) { end = std::max(end, n->tensors[t].off + n->tensors[t].numel); sum += n->tensors[t].numel; }
+        }
+        n->trunk_params = end == sum ? end : 0;   // 0 disables the dual-chain backward
+    }
     n->slot_base = w;
     n->slot_bytes = align_up(n->slot_floats * 4, 256);
     w += n->slot_bytes * d.n_slots;
@@ -466,24 +488,21 @@ static int head_forward(ocl_net* n, const float* P, float* feat, float* h1, floa
 static const int kGraphWarmCalls = 2;     // eager calls with a key before it is captured (lazy allocations, plans, rare shapes)
 static const size_t kMaxGraphs = 48;
 
-// OCL_GRAPH_MODE (experiments): 0 = never, 1 = every forward and backward, 2 (default) = forwards, and backwards of batches below
-// kTwoStreamMinBatch (larger ones are GPU-bound and gain more from the eager two-stream schedule than from a single-chain graph)
+// Dual-chain mode (see ocl_net_forward): OCL_DUAL_CHAIN = 0 (default) single chain, 1 two chains replayed as graphs, 2 two chains
+// with eager launches; ocl_net_graph_enable() overrides the environment per net.  Measured on the SCR step (N = 220): 2.70 ms with
+// one chain (+ the weight-gradient stream), 2.93 ms with two chains, graphs or not -- the half-size launches of the two chains slow
+// each other down by more than the interleaving recovers, so this stays an opt-in experiment.
 static const int kTwoStreamMinBatch = 48;
-static int graph_mode() {
-    static const int m = [] {
-        const char* off = getenv("OCL_NO_GRAPH");
-        if (off && off[0] == '1') return 0;
-        const char* e = getenv("OCL_GRAPH_MODE");
-        return e ? atoi(e) : 2;
+static const int kDualMinHalf = 8;
+static int dual_mode(const ocl_net* n) {
+    static const int env = [] {
+        const char* e = getenv("OCL_DUAL_CHAIN");
+        return e ? atoi(e) : 0;
     }();
-    return m;
-}
-static bool graphs_enabled(const ocl_net* n, bool backward = false, int N = 0) {
-    if (!n->graphs_on || prof_on() || n->dbg_stop >= 0) return false;
-    const int m = graph_mode();
-    if (m == 0) return false;
-    if (m == 1 || !backward) return true;
-    return N < kTwoStreamMinBatch;
+    if (prof_on() || n->dbg_stop >= 0 || n->trunk_params == 0) return 0;
+    static const bool env_single = [] { const char* e = getenv("OCL_SINGLE_STREAM"); return e && e[0] == '1'; }();
+    if (env_single) return 0;
+    return n->dual_mode >= 0 ? n->dual_mode : env;
 }
 
 static int ensure_side_stream(ocl_net* n) {
@@ -491,6 +510,7 @@ static int ensure_side_stream(ocl_net* n) {
     OCL_HIP(hipStreamCreateWithFlags(&n->s2, hipStreamNonBlocking));
     for (int i = 0; i < ocl_net::kDyRing; ++i) OCL_HIP(hipEventCreateWithFlags(&n->ev_done[i], hipEventDisableTiming));
     OCL_HIP(hipEventCreateWithFlags(&n->ev_join, hipEventDisableTiming));
+    OCL_HIP(hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming));
     for (int i = 0; i < 24; ++i) {   // one per publish() of a backward (2 per block + stem); created up front: none during capture
         hipEvent_t e;
         OCL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -597,6 +617,7 @@ void ocl_net_destroy(ocl_net* net) {
     for (int i = 0; i < ocl_net::kDyRing; ++i)
         if (net->ev_done[i]) (void)hipEventDestroy(net->ev_done[i]);
     if (net->ev_join) (void)hipEventDestroy(net->ev_join);
+    if (net->ev_fork) (void)hipEventDestroy(net->ev_fork);
     drop_graphs(net);
     if (net->s2) (void)hipStreamDestroy(net->s2);
     if (net->sc) (void)hipStreamDestroy(net->sc);
@@ -655,6 +676,99 @@ int ocl_net_bind(ocl_net* net, float* params, float* grads, float* running, int6
     return OCL_OK;
 }
 
+}  // extern "C"
+
+// -----------------------------------------------------------------------------------------------------
+// Train-mode trunk, one chain: images [img0, img0+Nc) of the batch as G BatchNorm groups (group indices g0..g0+G-1 of the saved
+// statistics), on scratch set `ch`, every launch on `st`.  upd: update the running statistics inside the BatchNorm kernels
+// (single chain); a dual-chain pass updates them afterwards, in group order, from both chains' statistics.
+// -----------------------------------------------------------------------------------------------------
+static int trunk_forward_train(ocl_net* n, PlanSet* ps, const float* P, float* S, int img0, int Nc, int G, int g0, int ch, bool upd,
+                               float* feat, hipStream_t st) {
+    float* pack = (float*)(n->ws + n->off_pack);
+    double* stats = n->statsbuf(ch);
+    int rc = OCL_OK;
+    OCL_HIP(hipMemsetAsync(stats, 0, n->stats_doubles * 8, st));
+    auto at = [&](int64_t off, const ConvInfo& c) { return S + off + (int64_t)img0 * c.Ho * c.Wo * c.Cout; };
+    auto bn_fwd = [&](int conv_i, const float* y, float* z, const float* res, int relu) -> int {
+        const ConvInfo& c = n->convs[conv_i];
+        const BnInfo& b = n->bns[c.bn];
+        BnFwdArgs a;
+        memset(&a, 0, sizeof(a));
+        a.y = y; a.z = z; a.res = res;
+        a.stats = stats + b.arena_off;
+        a.stat_rep_stride = n->stats_rep_stride;
+        a.gamma = P + n->tensors[b.gamma_t].off;
+        a.beta = P + n->tensors[b.beta_t].off;
+        a.running_mean = upd ? n->running + b.stat_off : nullptr;
+        a.running_var = upd ? n->running + b.stat_off + b.C : nullptr;
+        a.nbt = upd ? n->nbt + c.bn : nullptr;
+        a.save_mean = S + b.save_off + (int64_t)g0 * b.C;
+        a.save_invstd = S + b.save_off + (int64_t)kGmax * b.C + (int64_t)g0 * b.C;
+        a.m_per_group = (int64_t)(Nc / G) * c.Ho * c.Wo;
+        a.G = G; a.C = b.C; a.relu = relu;
+        a.momentum = 0.1f; a.eps = 1e-5f;
+        return launch_bn_fwd(a, st);
+    };
+    auto conv_stats = [&](int conv_i, const float* in) -> int {
+        const ConvInfo& c = n->convs[conv_i];
+        return run_conv(n, ps->fwd[conv_i], in, pack + c.f_off, at(c.y_off, c), EPI_STATS, stats + n->bns[c.bn].arena_off, nullptr,
+                        nullptr, nullptr, nullptr, st);
+    };
+    const ConvInfo& c0 = n->convs[0];
+    const float* x4 = S + n->x4_off + (int64_t)img0 * n->d.in_h * n->d.in_w * 4;
+    if ((rc = conv_stats(0, x4))) return rc;
+    float* cur = at(n->zstem_off, c0);
+    if ((rc = bn_fwd(0, at(c0.y_off, c0), cur, nullptr, 1))) return rc;
+    for (auto& b : n->blocks) {
+        const ConvInfo& c1 = n->convs[b.conv1];
+        const ConvInfo& c2 = n->convs[b.conv2];
+        float* a1 = at(b.a1_off, c1);
+        float* z = at(b.z_off, c2);
+        if ((rc = conv_stats(b.conv1, cur))) return rc;
+        if ((rc = bn_fwd(b.conv1, at(c1.y_off, c1), a1, nullptr, 1))) return rc;
+        if ((rc = conv_stats(b.conv2, a1))) return rc;
+        const float* res = cur;
+        if (b.convs >= 0) {
+            const ConvInfo& cs = n->convs[b.convs];
+            if ((rc = conv_stats(b.convs, cur))) return rc;
+            float* sc = n->gbuf(0, ch);
+            if ((rc = bn_fwd(b.convs, at(cs.y_off, cs), sc, nullptr, 0))) return rc;
+            res = sc;
+        }
+        if ((rc = bn_fwd(b.conv2, at(c2.y_off, c2), z, res, 1))) return rc;
+        cur = z;
+    }
+    return launch_avgpool_fwd(cur, feat, Nc, n->Hf, n->Wf, n->convs[n->blocks.back().conv2].Cout, st);
+}
+
+// running_mean / running_var / num_batches_tracked of every BatchNorm after a dual-chain forward: one update per chain, chain 0
+// first (the reference forwards view 1, then view 2)
+static int running_update(ocl_net* n, int Nc, hipStream_t s) {
+    BnRunArgs a;
+    memset(&a, 0, sizeof(a));
+    OCL_REQUIRE((int)n->bns.size() <= kBnRunMax, "running_update: %zu BatchNorms", n->bns.size());
+    a.stats[0] = n->statsbuf(0);
+    a.stats[1] = n->statsbuf(1);
+    a.n_chains = 2;
+    a.rep_stride = n->stats_rep_stride;
+    a.momentum = 0.1f;
+    a.running = n->running;
+    a.nbt = n->nbt;
+    a.n_bn = (int)n->bns.size();
+    for (auto& c : n->convs) {
+        const BnInfo& b = n->bns[c.bn];
+        BnRunDesc& d = a.d[c.bn];
+        d.stat_off = (int)b.stat_off;
+        d.C = b.C;
+        d.arena_off = (int)b.arena_off;
+        d.M = Nc * c.Ho * c.Wo;
+    }
+    return launch_bn_running_update(a, s);
+}
+
+extern "C" {
+
 int ocl_net_forward(ocl_net* n, const float* x, int N, int groups, uint32_t flags, const float* params_override, float* feat_out,
                     float* out, int slot, void* stream) {
     OCL_REQUIRE(n && n->bound, "net_forward: net not bound");
@@ -669,88 +783,61 @@ int ocl_net_forward(ocl_net* n, const float* x, int N, int groups, uint32_t flag
         if (rc != OCL_OK) return rc;
     }
     const float* P = params_override ? params_override : n->params;
+    // Two chains (opt-in, see dual_mode): the two views of an SCR step (groups == 2) share nothing but the weights until the
+    // projection head, and almost every launch of the trunk is a single round of workgroups followed by a full drain.  Each view
+    // can run as its own chain of launches on its own stream and scratch buffers, so that one chain's drains and ramps are
+    // filled by the other's kernels; each chain is a plain sequence, replayed as one hipGraph (graphs with parallel branches
+    // leave the fast path on ROCm 7.2, two single-chain graphs on two streams do not).
+    const int dm = dual_mode(n);
+    const bool dual = train && groups == 2 && dm != 0 && N / 2 >= kDualMinHalf;
     PlanSet* ps = nullptr;
-    int rc = get_plans(n, N, train ? groups : 1, &ps);
+    int rc = get_plans(n, dual ? N / 2 : N, (train && !dual) ? groups : 1, &ps);
     if (rc != OCL_OK) return rc;
     float* pack = (float*)(n->ws + n->off_pack);
     int max_elems = 0;
     for (auto& c : n->convs) max_elems = std::max(max_elems, c.Cout * c.Cin * c.k * c.k);
+    rc = launch_pack_weights(P, pack, pack_descs(n), (int)n->convs.size(), max_elems, s);   // every forward: the caller
+    if (rc != OCL_OK) return rc;                                                               // may have stepped the weights
+    n->pack_src = P;
 
     float* S = n->slotf(slot);
     float* x4 = S + n->x4_off;
-    rc = launch_nchw3_to_nhwc4(x, x4, N, n->d.in_h, n->d.in_w, s);   // the only reader of the caller's input: outside the graph
+    rc = launch_nchw3_to_nhwc4(x, x4, N, n->d.in_h, n->d.in_w, s);
     if (rc != OCL_OK) return rc;
     n->slot_valid[slot] = false;
 
-    // A replayed graph must not hold caller pointers: with graphs on, results land in engine buffers and are copied out below.
-    const bool cached = graphs_enabled(n);
-    const bool want_head = out || (flags & OCL_FWD_SAVE_TAPE);
-    const bool feat_direct = !cached && feat_out && !want_head;   // features only (ASER scoring, NCM): no copy
+    const bool feat_direct = feat_out && !out && !(flags & OCL_FWD_SAVE_TAPE);   // features only (ASER scoring, NCM): no copy
     float* feat = feat_direct ? feat_out : S + n->feat_off;
-    float* o = S + n->out_off;
-    bool wrote = false;
-    auto body = [&](hipStream_t st, bool) -> int {
-    int rc = launch_pack_weights(P, pack, pack_descs(n), (int)n->convs.size(), max_elems, st);   // every forward: the caller
-    if (rc != OCL_OK) return rc;                                                                    // may have stepped the weights
-    if (train) {
-        double* stats = (double*)(n->ws + n->off_stats);
-        OCL_HIP(hipMemsetAsync(stats, 0, n->stats_doubles * 8, st));
-        const bool upd = (flags & OCL_FWD_UPDATE_RUNNING) != 0;
-        auto bn_fwd = [&](int conv_i, const float* y, float* z, const float* res, int relu) -> int {
-            const ConvInfo& c = n->convs[conv_i];
-            const BnInfo& b = n->bns[c.bn];
-            BnFwdArgs a;
-            memset(&a, 0, sizeof(a));
-            a.y = y; a.z = z; a.res = res;
-            a.stats = stats + b.arena_off;
-            a.stat_rep_stride = n->stats_rep_stride;
-            a.gamma = P + n->tensors[b.gamma_t].off;
-            a.beta = P + n->tensors[b.beta_t].off;
-            a.running_mean = upd ? n->running + b.stat_off : nullptr;
-            a.running_var = upd ? n->running + b.stat_off + b.C : nullptr;
-            a.nbt = upd ? n->nbt + c.bn : nullptr;
-            a.save_mean = S + b.save_off;
-            a.save_invstd = S + b.save_off + (int64_t)kGmax * b.C;
-            a.m_per_group = (int64_t)(N / groups) * c.Ho * c.Wo;
-            a.G = groups; a.C = b.C; a.relu = relu;
-            a.momentum = 0.1f; a.eps = 1e-5f;
-            return launch_bn_fwd(a, st);
-        };
-        auto conv_stats = [&](int conv_i, const float* in) -> int {
-            const ConvInfo& c = n->convs[conv_i];
-            return run_conv(n, ps->fwd[conv_i], in, pack + c.f_off, S + c.y_off, EPI_STATS, stats + n->bns[c.bn].arena_off, nullptr,
-                            nullptr, nullptr, nullptr, st);
-        };
-        // stem
-        if ((rc = conv_stats(0, x4))) return rc;
-        float* cur = S + n->zstem_off;
-        if ((rc = bn_fwd(0, S + n->convs[0].y_off, cur, nullptr, 1))) return rc;
-        for (auto& b : n->blocks) {
-            float* a1 = S + b.a1_off;
-            float* z = S + b.z_off;
-            if ((rc = conv_stats(b.conv1, cur))) return rc;
-            if ((rc = bn_fwd(b.conv1, S + n->convs[b.conv1].y_off, a1, nullptr, 1))) return rc;
-            if ((rc = conv_stats(b.conv2, a1))) return rc;
-            const float* res = cur;
-            if (b.convs >= 0) {
-                if ((rc = conv_stats(b.convs, cur))) return rc;
-                float* sc = n->gbuf(0);
-                if ((rc = bn_fwd(b.convs, S + n->convs[b.convs].y_off, sc, nullptr, 0))) return rc;
-                res = sc;
-            }
-            if ((rc = bn_fwd(b.conv2, S + n->convs[b.conv2].y_off, z, res, 1))) return rc;
-            cur = z;
+    const bool upd = (flags & OCL_FWD_UPDATE_RUNNING) != 0;
+    if (train && dual) {
+        if ((rc = ensure_side_stream(n))) return rc;
+        const int Nc = N / 2;
+        float* featS = S + n->feat_off;   // graphs hold engine pointers only
+        OCL_HIP(hipEventRecord(n->ev_fork, s));
+        OCL_HIP(hipStreamWaitEvent(n->s2, n->ev_fork, 0));
+        for (int ch = 0; ch < 2; ++ch) {
+            ocl_net::GraphKey key{2, Nc, 1, slot, ch, flags, P};
+            auto body = [&](hipStream_t st, bool) -> int {
+                return trunk_forward_train(n, ps, P, S, ch * Nc, Nc, 1, ch, ch, false, featS + (int64_t)ch * Nc * n->feat_dim, st);
+            };
+            if ((rc = run_cached(n, key, ch ? n->s2 : s, dm == 1, body))) return rc;
         }
-        if ((rc = launch_avgpool_fwd(cur, feat, N, n->Hf, n->Wf, n->convs[n->blocks.back().conv2].Cout, st))) return rc;
+        OCL_HIP(hipEventRecord(n->ev_join, n->s2));
+        OCL_HIP(hipStreamWaitEvent(s, n->ev_join, 0));
+        if (upd && (rc = running_update(n, Nc, s))) return rc;
+        if (feat_direct) OCL_HIP(hipMemcpyAsync(feat_out, featS, (size_t)N * n->feat_dim * 4, hipMemcpyDeviceToDevice, s));
+        feat = featS;
+    } else if (train) {
+        if ((rc = trunk_forward_train(n, ps, P, S, 0, N, groups, 0, 0, upd, feat, s))) return rc;
     } else {
         float* fold = (float*)(n->ws + n->off_fold);
-        if ((rc = launch_bn_fold(P, n->running, fold, fold_descs(n), (int)n->bns.size(), 1e-5f, st))) return rc;
+        if ((rc = launch_bn_fold(P, n->running, fold, fold_descs(n), (int)n->bns.size(), 1e-5f, s))) return rc;
         auto conv_eval = [&](int conv_i, const float* in, float* o, const float* res, int relu) -> int {
             const ConvInfo& c = n->convs[conv_i];
             const BnInfo& b = n->bns[c.bn];
             int fl = EPI_AFFINE | (res ? EPI_RES : 0) | (relu ? EPI_RELU : 0);
             return run_conv(n, ps->fwd[conv_i], in, pack + c.f_off, o, fl, nullptr, fold + b.stat_off, fold + b.stat_off + b.C, res,
-                            nullptr, st);
+                            nullptr, s);
         };
         float* bufs[4] = {n->gbuf(0), n->gbuf(1), n->gbuf(2), n->gbuf(3)};
         float* cur = bufs[0];
@@ -770,20 +857,15 @@ int ocl_net_forward(ocl_net* n, const float* x, int N, int groups, uint32_t flag
             cur = z;
             ci = (ci + 3) & 3;
         }
-        if ((rc = launch_avgpool_fwd(cur, feat, N, n->Hf, n->Wf, n->convs[n->blocks.back().conv2].Cout, st))) return rc;
+        if ((rc = launch_avgpool_fwd(cur, feat, N, n->Hf, n->Wf, n->convs[n->blocks.back().conv2].Cout, s))) return rc;
     }
-    if (want_head) {
-        bool w2 = false;
-        if ((rc = head_forward(n, P, feat, S + n->h1_off, S + n->h2_off, S + n->norms_off, o, N, st, cached ? nullptr : out, &w2))) return rc;
-        wrote = w2 && !cached;
-    }
-    return OCL_OK;
-    };
-    ocl_net::GraphKey key{0, N, groups, slot, (want_head ? 1 : 0) | (feat_out ? 2 : 0), flags, P};
-    if ((rc = run_cached(n, key, s, cached, body))) return rc;
-    n->pack_src = P;
     if (feat_out && !feat_direct) OCL_HIP(hipMemcpyAsync(feat_out, feat, (size_t)N * n->feat_dim * 4, hipMemcpyDeviceToDevice, s));
-    if (out && !wrote) OCL_HIP(hipMemcpyAsync(out, o, (size_t)N * n->out_dim * 4, hipMemcpyDeviceToDevice, s));
+    if (out || (flags & OCL_FWD_SAVE_TAPE)) {
+        float* o = S + n->out_off;
+        bool wrote = false;
+        if ((rc = head_forward(n, P, feat, S + n->h1_off, S + n->h2_off, S + n->norms_off, o, N, s, out, &wrote))) return rc;
+        if (out && !wrote) OCL_HIP(hipMemcpyAsync(out, o, (size_t)N * n->out_dim * 4, hipMemcpyDeviceToDevice, s));
+    }
     if (train && (flags & OCL_FWD_SAVE_TAPE) && !params_override) {
         n->slot_valid[slot] = true;
         n->slot_n[slot] = N;
@@ -792,105 +874,35 @@ int ocl_net_forward(ocl_net* n, const float* x, int N, int groups, uint32_t flag
     return OCL_OK;
 }
 
-int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, void* stream) {
-    OCL_REQUIRE(n && n->bound, "net_backward: net not bound");
-    OCL_REQUIRE(slot >= 0 && slot < n->d.n_slots && n->slot_valid[slot],
-                "net_backward: slot %d holds no train-mode forward tape (forward with OCL_FWD_TRAIN|OCL_FWD_SAVE_TAPE first)", slot);
-    OCL_REQUIRE(dout, "net_backward: null dout");
-    hipStream_t s0 = (hipStream_t)stream;
-    const int N = n->slot_n[slot], G = n->slot_groups[slot];
-    PlanSet* ps = nullptr;
-    int rc = get_plans(n, N, G, &ps);
-    if (rc != OCL_OK) return rc;
-    n->slot_valid[slot] = false;  // a tape is consumed once (activation buffers are not preserved past this point)
-    float* S = n->slotf(slot);
-    const float* P = n->params;
-    float* Gr = n->grads;
+}  // extern "C"
+
+// -----------------------------------------------------------------------------------------------------
+// Backward of the trunk, one chain: images [img0, img0+Nc) (G groups from group index g0) from dL/dfeat (this chain's rows) to the
+// parameter gradients in Gr (overwritten or accumulated).  side != null: the weight gradients go to that stream behind events
+// (single-chain passes of large batches); null: everything on `s`, in order (dual-chain passes, small batches, measurements).
+// -----------------------------------------------------------------------------------------------------
+static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, float* S, int img0, int Nc, int G, int g0, int ch,
+                          int accumulate, const float* dfeat, hipStream_t s, hipStream_t side) {
     float* pack = (float*)(n->ws + n->off_pack);
-    float* partial = (float*)(n->ws + n->off_partial);
-    double* bsums = (double*)(n->ws + n->off_bsums);
-    const bool repack = n->pack_src != P;   // the arena was rewritten by a forward of MIR's virtual model since the taped forward
-    const int FD = n->feat_dim, OD = n->out_dim;
-    float* hb = (float*)(n->ws + n->off_head);
-    // A replayed graph must not hold the caller's pointer: with graphs on, dL/dout is staged in an engine buffer first.
-    const bool cached = graphs_enabled(n, true, N);
-    if (cached) {
-        float* stage = hb + (int64_t)n->d.max_batch * FD * 3;
-        OCL_HIP(hipMemcpyAsync(stage, dout, (size_t)N * (n->d.head == 3 ? FD : OD) * 4, hipMemcpyDeviceToDevice, s0));
-        dout = stage;
-    }
-    auto body = [&](hipStream_t s, bool capturing) -> int {
+    float* partial = n->partialbuf(ch);
+    double* bsums = n->bsumsbuf(ch);
     int rc = OCL_OK;
     OCL_HIP(hipMemsetAsync(bsums, 0, n->bsums_doubles * 8, s));
-    if (repack) {
-        int max_elems = 0;
-        for (auto& c : n->convs) max_elems = std::max(max_elems, c.Cout * c.Cin * c.k * c.k);
-        if ((rc = launch_pack_weights(P, pack, pack_descs(n), (int)n->convs.size(), max_elems, s))) return rc;
-    }
     auto T = [&](int t) { return P + n->tensors[t].off; };
     auto GT = [&](int t) { return Gr + n->tensors[t].off; };
-    float* dfeat = hb;
-    float* dh1 = hb + (int64_t)N * FD;
-    float* dh2 = dh1 + (int64_t)N * FD;
-    float* feat = S + n->feat_off;
-    float* h1 = S + n->h1_off;
-    float* o = S + n->out_off;
-    float* norms = S + n->norms_off;
-
-    // ---- head -------------------------------------------------------------------------------------
-    auto lin_bwd = [&](const float* dy, int ncol, const float* xin, int kin, int tw, int tb, float* dx) -> int {
-        // y = x W^T + b, W [ncol, kin]
-        int r = ocl_gemm_small(dy, 1, ncol, xin, kin, 1, GT(tw), kin, ncol, kin, N, nullptr, 0, accumulate, s);  // dW = dy^T x
-        if (r) return r;
-        if ((r = launch_colsum(dy, N, ncol, GT(tb), accumulate, s))) return r;
-        if (dx) r = ocl_gemm_small(dy, ncol, 1, T(tw), kin, 1, dx, kin, N, kin, ncol, nullptr, 0, 0, s);  // dx = dy W
-        return r;
-    };
-    if (n->d.head == 0) {
-        if ((rc = lin_bwd(dout, OD, feat, FD, n->t_linear_w, n->t_linear_b, dfeat))) return rc;
-    } else {
-        if (!accumulate) {  // encoder.linear takes no part in SupConResNet.forward: its gradient is zero
-            if ((rc = launch_fill(GT(n->t_linear_w), n->tensors[n->t_linear_w].numel, 0.f, s))) return rc;
-            if ((rc = launch_fill(GT(n->t_linear_b), n->tensors[n->t_linear_b].numel, 0.f, s))) return rc;
-        }
-        if (n->d.head == 1) {
-            if ((rc = launch_l2norm_bwd(o, norms, dout, dh2, N, OD, s))) return rc;
-            if ((rc = lin_bwd(dh2, OD, h1, FD, n->t_h2_w, n->t_h2_b, dh1))) return rc;
-            if ((rc = launch_relu_bwd(dh1, h1, dh1, (int64_t)N * FD, s))) return rc;
-            if ((rc = lin_bwd(dh1, FD, feat, FD, n->t_h0_w, n->t_h0_b, dfeat))) return rc;
-        } else if (n->d.head == 2) {
-            if ((rc = launch_l2norm_bwd(o, norms, dout, dh2, N, OD, s))) return rc;
-            if ((rc = lin_bwd(dh2, OD, feat, FD, n->t_h2_w, n->t_h2_b, dfeat))) return rc;
-        } else {
-            if ((rc = launch_l2norm_bwd(o, norms, dout, dfeat, N, FD, s))) return rc;
-        }
-    }
-    // ---- trunk ------------------------------------------------------------------------------------
-    // Two HIP streams: the caller's stream carries the dependent chain (BatchNorm backward -> data gradient -> ...), the
-    // weight gradients (conv_wgrad_kernel + reduce: a third of the step's MFMA work, needed by nobody until the
-    // optimiser step) run on a second stream as soon as their dL/dy exists.  Most launches of either chain are a single
-    // round of 220-512 workgroups or HBM-bound BatchNorm passes, so the two streams fill each other's idle CUs.
-    // dL/dy buffers come from a ring; a slot is rewritten only after the event behind its last weight-gradient reader.
-    float* gA = n->gbuf(0);  // grad wrt current block output
-    float* gD = n->gbuf(3);
-    float* gE = n->gbuf(4);
-    float* gB = nullptr;     // dL/dy of the main-path BatchNorm being processed (ring slot)
-    float* gC = nullptr;     // dL/dy of the projection-shortcut BatchNorm
+    auto at = [&](int64_t off, const ConvInfo& c) { return S + off + (int64_t)img0 * c.Ho * c.Wo * c.Cout; };
+    float* gA = n->gbuf(0, ch);  // grad wrt current block output
+    float* gD = n->gbuf(3, ch);
+    float* gE = n->gbuf(4, ch);
+    float* gB = nullptr;         // dL/dy of the main-path BatchNorm being processed (ring slot)
+    float* gC = nullptr;         // dL/dy of the projection-shortcut BatchNorm
     const int Clast = n->convs[n->blocks.back().conv2].Cout;
-    if ((rc = launch_avgpool_bwd(dfeat, gA, N, n->Hf, n->Wf, Clast, s))) return rc;
+    if ((rc = launch_avgpool_bwd(dfeat, gA, Nc, n->Hf, n->Wf, Clast, s))) return rc;
 
-    // replay batches of 10-20 images are launch-latency-bound: the event traffic costs more than the overlap returns there;
-    // the debug stops expose intermediate buffers: single stream as well
-    // measurement runs (ocl_prof_enable, OCL_SINGLE_STREAM=1) keep everything on the caller's stream so that per-kernel durations
-    // are those of the kernel alone, not of the kernel sharing the CUs with a weight-gradient kernel
-    // A captured graph stays a single chain: on ROCm 7.2 a graph with a long-lived parallel branch leaves the fast path (measured
-    // with kbench launch: 4 us of host time per node and 10-17 ms to instantiate, against 0.07 us per node for a chain).
-    static const bool env_single = [] { const char* e = getenv("OCL_SINGLE_STREAM"); return e && e[0] == '1'; }();
-    const bool two_streams = n->dbg_stop < 0 && N >= kTwoStreamMinBatch && !capturing && !prof_on() && !env_single;
-    if (two_streams && (rc = ensure_side_stream(n))) return rc;
+    const bool two_streams = side != nullptr;
+    hipStream_t sw = two_streams ? side : s;   // stream of the weight gradients
     n->dy_next = 0;
     for (int i = 0; i < ocl_net::kDyRing; ++i) n->ev_done_pending[i] = false;
-    hipStream_t sw = two_streams ? n->s2 : s;   // stream of the weight gradients
     size_t ready_used = 0;
     auto take_dy = [&](int* slot_out) -> float* {   // next ring slot; the main stream waits for its previous readers
         const int r = n->dy_next;
@@ -900,7 +912,7 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
             n->ev_done_pending[r] = false;
         }
         *slot_out = r;
-        return n->dybuf(r);
+        return n->dybuf(r, ch);
     };
     auto publish = [&]() -> int {   // everything the main stream has written so far is visible to the wgrad stream
         if (!two_streams) return OCL_OK;
@@ -926,7 +938,7 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
         memset(&a, 0, sizeof(a));
         const ConvInfo& ca = n->convs[conv_a];
         a.dz = dz; a.z = zmask;
-        a.m_per_group = (int64_t)(N / G) * ca.Ho * ca.Wo;
+        a.m_per_group = (int64_t)(Nc / G) * ca.Ho * ca.Wo;
         a.G = G; a.C = ca.Cout;
         a.nsets = conv_b >= 0 ? 2 : 1;
         const int cs[2] = {conv_a, conv_b};
@@ -934,9 +946,9 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
         for (int k = 0; k < a.nsets; ++k) {
             const ConvInfo& c = n->convs[cs[k]];
             const BnInfo& b = n->bns[c.bn];
-            a.y[k] = S + c.y_off;
-            a.mean[k] = S + b.save_off;
-            a.invstd[k] = S + b.save_off + (int64_t)kGmax * b.C;
+            a.y[k] = at(c.y_off, c);
+            a.mean[k] = S + b.save_off + (int64_t)g0 * b.C;
+            a.invstd[k] = S + b.save_off + (int64_t)kGmax * b.C + (int64_t)g0 * b.C;
             a.gamma[k] = T(b.gamma_t);
             a.dy[k] = dys[k];
             a.dgamma[k] = GT(b.gamma_t);
@@ -976,11 +988,14 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
         return true;
     };
     if (stop_here(99, 0)) return OCL_OK;   // right after the head: gA = dL/dz of the last block
+    const ConvInfo& c0 = n->convs[0];
     for (int bi = (int)n->blocks.size() - 1; bi >= 0; --bi) {
         const BlockInfo& b = n->blocks[bi];
-        const float* xin = bi == 0 ? S + n->zstem_off : S + n->blocks[bi - 1].z_off;
-        const float* a1 = S + b.a1_off;
-        const float* z = S + b.z_off;
+        const ConvInfo& c1 = n->convs[b.conv1];
+        const ConvInfo& c2 = n->convs[b.conv2];
+        const float* xin = bi == 0 ? at(n->zstem_off, c0) : at(n->blocks[bi - 1].z_off, n->convs[n->blocks[bi - 1].conv2]);
+        const float* a1 = at(b.a1_off, c1);
+        const float* z = at(b.z_off, c2);
         // gA = dL/dz.  bn2 (and the projection BN) share the ReLU-masked gradient.
         int rB, rC = -1;
         gB = take_dy(&rB);
@@ -1017,9 +1032,9 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
     // stem
     int rS;
     float* gS = take_dy(&rS);
-    if ((rc = bn_bwd(gA, S + n->zstem_off, 0, gS, -1, nullptr))) return rc;
+    if ((rc = bn_bwd(gA, at(n->zstem_off, c0), 0, gS, -1, nullptr))) return rc;
     if ((rc = publish())) return rc;
-    if ((rc = wgrad(0, S + n->x4_off, gS))) return rc;
+    if ((rc = wgrad(0, S + n->x4_off + (int64_t)img0 * n->d.in_h * n->d.in_w * 4, gS))) return rc;
     if ((rc = release(rS))) return rc;
     if (two_streams) {   // the caller's stream continues (optimiser step, next forward) only after every weight gradient
         OCL_HIP(hipEventRecord(n->ev_join, sw));
@@ -1027,16 +1042,109 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
         for (int i = 0; i < ocl_net::kDyRing; ++i) n->ev_done_pending[i] = false;   // covered by the join
     }
     return OCL_OK;
-    };
-    ocl_net::GraphKey key{1, N, G, slot, (accumulate ? 1 : 0) | (repack ? 2 : 0), 0u, P};
-    if ((rc = run_cached(n, key, s0, cached, body))) return rc;
-    n->pack_src = P;
-    return OCL_OK;
 }
 
-int ocl_net_graph_enable(ocl_net* n, int on) {
-    OCL_REQUIRE(n, "graph_enable: null net");
-    n->graphs_on = on != 0;
+extern "C" {
+
+int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, void* stream) {
+    OCL_REQUIRE(n && n->bound, "net_backward: net not bound");
+    OCL_REQUIRE(slot >= 0 && slot < n->d.n_slots && n->slot_valid[slot],
+                "net_backward: slot %d holds no train-mode forward tape (forward with OCL_FWD_TRAIN|OCL_FWD_SAVE_TAPE first)", slot);
+    OCL_REQUIRE(dout, "net_backward: null dout");
+    hipStream_t s = (hipStream_t)stream;
+    const int N = n->slot_n[slot], G = n->slot_groups[slot];
+    const int dm = dual_mode(n);
+    const bool dual = G == 2 && dm != 0 && N / 2 >= kDualMinHalf;
+    PlanSet* ps = nullptr;
+    int rc = get_plans(n, dual ? N / 2 : N, dual ? 1 : G, &ps);
+    if (rc != OCL_OK) return rc;
+    n->slot_valid[slot] = false;  // a tape is consumed once (activation buffers are not preserved past this point)
+    float* S = n->slotf(slot);
+    const float* P = n->params;
+    float* Gr = n->grads;
+    float* pack = (float*)(n->ws + n->off_pack);
+    if (n->pack_src != P) {   // the arena was rewritten by a forward of MIR's virtual model since the taped forward
+        int max_elems = 0;
+        for (auto& c : n->convs) max_elems = std::max(max_elems, c.Cout * c.Cin * c.k * c.k);
+        if ((rc = launch_pack_weights(P, pack, pack_descs(n), (int)n->convs.size(), max_elems, s))) return rc;
+        n->pack_src = P;
+    }
+    auto T = [&](int t) { return P + n->tensors[t].off; };
+    auto GT = [&](int t) { return Gr + n->tensors[t].off; };
+    const int FD = n->feat_dim, OD = n->out_dim;
+    float* hb = (float*)(n->ws + n->off_head);
+    float* dfeat = hb;
+    float* dh1 = hb + (int64_t)N * FD;
+    float* dh2 = dh1 + (int64_t)N * FD;
+    float* feat = S + n->feat_off;
+    float* h1 = S + n->h1_off;
+    float* o = S + n->out_off;
+    float* norms = S + n->norms_off;
+
+    // ---- head -------------------------------------------------------------------------------------
+    auto lin_bwd = [&](const float* dy, int ncol, const float* xin, int kin, int tw, int tb, float* dx) -> int {
+        // y = x W^T + b, W [ncol, kin]
+        int r = ocl_gemm_small(dy, 1, ncol, xin, kin, 1, GT(tw), kin, ncol, kin, N, nullptr, 0, accumulate, s);  // dW = dy^T x
+        if (r) return r;
+        if ((r = launch_colsum(dy, N, ncol, GT(tb), accumulate, s))) return r;
+        if (dx) r = ocl_gemm_small(dy, ncol, 1, T(tw), kin, 1, dx, kin, N, kin, ncol, nullptr, 0, 0, s);  // dx = dy W
+        return r;
+    };
+    if (n->d.head == 0) {
+        if ((rc = lin_bwd(dout, OD, feat, FD, n->t_linear_w, n->t_linear_b, dfeat))) return rc;
+    } else {
+        if (!accumulate) {  // encoder.linear takes no part in SupConResNet.forward: its gradient is zero
+            if ((rc = launch_fill(GT(n->t_linear_w), n->tensors[n->t_linear_w].numel, 0.f, s))) return rc;
+            if ((rc = launch_fill(GT(n->t_linear_b), n->tensors[n->t_linear_b].numel, 0.f, s))) return rc;
+        }
+        if (n->d.head == 1) {
+            if ((rc = launch_l2norm_bwd(o, norms, dout, dh2, N, OD, s))) return rc;
+            if ((rc = lin_bwd(dh2, OD, h1, FD, n->t_h2_w, n->t_h2_b, dh1))) return rc;
+            if ((rc = launch_relu_bwd(dh1, h1, dh1, (int64_t)N * FD, s))) return rc;
+            if ((rc = lin_bwd(dh1, FD, feat, FD, n->t_h0_w, n->t_h0_b, dfeat))) return rc;
+        } else if (n->d.head == 2) {
+            if ((rc = launch_l2norm_bwd(o, norms, dout, dh2, N, OD, s))) return rc;
+            if ((rc = lin_bwd(dh2, OD, feat, FD, n->t_h2_w, n->t_h2_b, dfeat))) return rc;
+        } else {
+            if ((rc = launch_l2norm_bwd(o, norms, dout, dfeat, N, FD, s))) return rc;
+        }
+    }
+    // ---- trunk ------------------------------------------------------------------------------------
+    if (dual) {
+        // One chain per view (see ocl_net_forward).  Chain 0 writes the caller's gradient array, chain 1 a staging array that is
+        // added once both are done: no cross-chain ordering inside the chains, and a fixed summation order.
+        if ((rc = ensure_side_stream(n))) return rc;
+        const int Nc = N / 2;
+        float* G2 = (float*)(n->ws + n->off_grad2);
+        OCL_HIP(hipEventRecord(n->ev_fork, s));
+        OCL_HIP(hipStreamWaitEvent(n->s2, n->ev_fork, 0));
+        for (int ch = 0; ch < 2; ++ch) {
+            ocl_net::GraphKey key{3, Nc, 1, slot, ch | (accumulate ? 2 : 0), 0u, P};
+            auto body = [&](hipStream_t st, bool) -> int {
+                return trunk_backward(n, ps, P, ch ? G2 : Gr, S, ch * Nc, Nc, 1, ch, ch, ch ? 0 : accumulate, dfeat + (int64_t)ch * Nc * FD, st,
+                                      nullptr);
+            };
+            if ((rc = run_cached(n, key, ch ? n->s2 : s, dm == 1, body))) return rc;
+        }
+        OCL_HIP(hipEventRecord(n->ev_join, n->s2));
+        OCL_HIP(hipStreamWaitEvent(s, n->ev_join, 0));
+        return launch_add_inplace(Gr, G2, n->trunk_params, s);
+    }
+    // Single chain.  Two HIP streams for the large batches: the caller's stream carries the dependent chain (BatchNorm backward ->
+    // data gradient -> ...), the weight gradients (conv_wgrad_kernel + reduce: a third of the step's MFMA work, needed by nobody
+    // until the optimiser step) run on a second stream as soon as their dL/dy exists; dL/dy buffers come from a ring, a slot is
+    // rewritten only after the event behind its last weight-gradient reader.  Replay batches of 10-20 images are latency-bound:
+    // the event traffic costs more than the overlap returns there.  Debug stops and measurement runs (ocl_prof_enable,
+    // OCL_SINGLE_STREAM=1: per-kernel durations of the kernel alone) stay on one stream as well.
+    static const bool env_single = [] { const char* e = getenv("OCL_SINGLE_STREAM"); return e && e[0] == '1'; }();
+    const bool two_streams = n->dbg_stop < 0 && N >= kTwoStreamMinBatch && !prof_on() && !env_single;
+    if (two_streams && (rc = ensure_side_stream(n))) return rc;
+    return trunk_backward(n, ps, P, Gr, S, 0, N, G, 0, 0, accumulate, dfeat, s, two_streams ? n->s2 : nullptr);
+}
+
+int ocl_net_graph_enable(ocl_net* n, int mode) {
+    OCL_REQUIRE(n && mode >= -1 && mode <= 2, "graph_enable: net / mode %d", mode);
+    n->dual_mode = mode;
     return OCL_OK;
 }
 
