@@ -69,6 +69,14 @@ int ocl_sgd_step(float* params, const float* grads, int64_t n, float lr, float w
 int ocl_ce_fwd_bwd(const float* logits, const int64_t* y, int n, int c, int reduction,
                    float* loss_out, float* dlogits, void* stream);
 
+/* Cross-entropy (mean) over a column segment: the labels trick (agents/base.py:96-101: softmax over the classes present in
+ * the batch) and the separated softmax (:102-108: old and new classes normalised separately) as ONE kernel.  seg[c] assigns
+ * every logit column to a segment id >= 0, or -1 (column takes no part); row r is a softmax over the columns j with
+ * seg[j] == seg[y[r]] (seg[y[r]] must be >= 0: checked by the caller, the labels live on the host).  dlogits (may be NULL)
+ * receives d(mean loss)/d(logits): zero outside the row's segment. */
+int ocl_ce_segmented_fwd_bwd(const float* logits, const int64_t* y, const int32_t* seg, int n, int c, float* loss_out,
+                             float* dlogits, void* stream);
+
 /* ---- K7: supervised contrastive loss ---------------------------------------------------------------
  * SupConLoss.forward with contrast_mode='all' (utils/loss.py:19-96).  feat is VIEW-MAJOR
  * [n_views*bsz, dim] (= torch.cat(torch.unbind(features,1)), loss.py:56).  workspace: at least

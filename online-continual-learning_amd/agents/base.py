@@ -1,7 +1,7 @@
 """agents/base.py:14-227 — ContinualLearner: label bookkeeping, criterion (CE / SupCon), review trick, and
 evaluate() with the nearest-class-mean classifier (NCM) or argmax, on the MI355X.
 
-Only the branches BASELINE.json's configs use are implemented; the labels / separated-softmax / KD tricks raise
+The labels trick and the separated softmax share one segmented cross-entropy kernel; the KD tricks raise
 NotImplementedError instead of silently doing something else."""
 from abc import abstractmethod
 import abc
@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from .. import ops
-from ..loss import SupConLoss, cross_entropy_mean
+from ..loss import SupConLoss, cross_entropy_mean, cross_entropy_segmented_mean
 from ..utils import maybe_cuda, AverageMeter
 
 
@@ -35,7 +35,7 @@ class ContinualLearner(torch.nn.Module, metaclass=abc.ABCMeta):
         self.task_seen = 0
         self.lbl_inv_map = {}
         self.class_task_map = {}
-        for t in ('labels_trick', 'separated_softmax', 'kd_trick', 'kd_trick_star'):
+        for t in ('kd_trick', 'kd_trick_star'):
             if params.trick.get(t, False):
                 raise NotImplementedError("trick %r is outside the HIP hot path (BASELINE configs keep it off)" % t)
         if getattr(params, 'error_analysis', False):
@@ -98,8 +98,27 @@ class ContinualLearner(torch.nn.Module, metaclass=abc.ABCMeta):
                     p.grad.data.mul_(scale)
             self.opt.step()
 
+    def _host_labels(self, labels):
+        h = getattr(labels, 'host', None)
+        return np.asarray(h).astype(np.int64) if h is not None else labels.detach().cpu().numpy().astype(np.int64)
+
     def criterion(self, logits, labels):
-        """agents/base.py:93-113."""
+        """agents/base.py:93-113.  The labels trick (:96-101) and the separated softmax (:102-108) are one kernel: a softmax
+        over the logit columns of the row's label segment (ocl_ce_segmented_fwd_bwd); the segment table is built on the host
+        from the labels' numpy mirror, as the reference builds `unq_lbls` / `lbl_inv_map`."""
+        if self.params.trick['labels_trick']:
+            y_host = self._host_labels(labels)
+            seg = np.full(logits.shape[1], -1, dtype=np.int32)
+            seg[np.unique(y_host)] = 0          # labels.unique().sort()[0]: the heads that appear in the batch
+            return cross_entropy_segmented_mean(logits, labels, ops.upload(torch.from_numpy(seg), logits.device))
+        elif self.params.trick['separated_softmax']:
+            y_host = self._host_labels(labels)
+            for lbl in y_host.tolist():
+                self.lbl_inv_map[lbl]           # KeyError for a label outside old_labels + new_labels, as in the reference (:106)
+            seg = np.full(logits.shape[1], -1, dtype=np.int32)
+            seg[np.asarray(self.old_labels, dtype=np.int64)] = 0
+            seg[np.asarray(self.new_labels, dtype=np.int64)] = 1
+            return cross_entropy_segmented_mean(logits, labels, ops.upload(torch.from_numpy(seg), logits.device))
         labels = labels.clone()
         if self.params.agent in ['SCR', 'SCP']:
             SC = SupConLoss(temperature=self.params.temp)

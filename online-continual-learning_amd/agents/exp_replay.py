@@ -1,4 +1,5 @@
 """agents/exp_replay.py:10-104 — Experience Replay inner loop (also hosts MIR / ASER through the plugins)."""
+import numpy as np
 import torch
 
 from .. import debug
@@ -70,6 +71,8 @@ class ExperienceReplay(ContinualLearner):
                         self.opt.zero_grad()
                         combined_batch = torch.cat((mem_x, batch_x))
                         combined_labels = torch.cat((mem_y, batch_y))
+                        if getattr(mem_y, 'host', None) is not None:
+                            combined_labels.host = np.concatenate((np.asarray(mem_y.host), np.asarray(batch_y_host)))
                         combined_logits = self.model.forward(combined_batch)
                         loss_combined = self.criterion(combined_logits, combined_labels)
                         if debug.on():

@@ -196,10 +196,13 @@ struct BnBwdArgs {
     float* dgamma[2];
     float* dbeta[2];
     double* sums;         // scratch [nsets][G][2][C], zeroed by the caller
+    unsigned* barrier;    // zeroed by the caller, or null: arrival counter of the one-pass kernel (nsets == 1, G <= 2, see launch_bn_bwd)
+    double* fsums;        // one-pass kernel: zeroed accumulators [8 replicas][G][2][C]
     int accumulate;       // dgamma/dbeta += (1) or = (0)
 };
 int launch_bn_bwd(const BnBwdArgs& a, hipStream_t s);
-void bn_bwd_tune(int block_cap, int unroll, int phase);   // micro-benchmark overrides; 0 = default (phase 1 reduce only, 2 apply only)
+void bn_bwd_tune(int block_cap, int unroll, int phase);
+void bn_bwd_fused_enable(int on);   // one-pass kernel on/off (-1: OCL_BN_FUSED from the environment, default on)   // micro-benchmark overrides; 0 = default (phase 1 reduce only, 2 apply only)
 
 // avg_pool2d(k=4) + flatten in PyTorch's (C,ph,pw) order; and its backward
 int launch_avgpool_fwd(const float* z, float* feat, int N, int H, int W, int C, hipStream_t s);

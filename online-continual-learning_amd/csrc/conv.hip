@@ -1458,12 +1458,184 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const BnBwdArgs a) {
     }
 }
 
+// One-pass BatchNorm backward (one BatchNorm, <= 2 groups): every thread keeps its share of the masked gradient and of xhat in
+// registers (<= E float4 each), the workgroups reduce, meet at a grid-wide arrival counter, and apply from registers: dz, z, y are
+// read once and dy written once (4 tensor passes instead of the 7 of reduce + apply).  All workgroups must be resident at once:
+// the grid is one 512-thread workgroup per CU (54-160 VGPRs, 17 KB LDS); workgroups that find their CU full of weight-gradient
+// workgroups of the second stream start when one of those retires; the wait is bounded so that a scheduling surprise shows up as a parity failure, not as a hung GPU.
+constexpr int kBnFusedThreads = 512;
+// accumulator replicas (same-address returning atomics serialise at the coherence point: 256 workgroups on one address cost ~20 us)
+constexpr int kBnFusedReps = 8;
+template <int E>
+__global__ void __launch_bounds__(kBnFusedThreads) bn_bwd_fused_kernel(const BnBwdArgs a) {
+    __shared__ float4 red[2][kBnFusedThreads];
+    __shared__ float kk[2][4 * 40];
+    __shared__ bool timed_out;   // some workgroup never arrived (not all resident at once): the results are poisoned with NaN
+    const int C4 = a.C >> 2;
+    const int tid = threadIdx.x;
+    if (tid == 0) timed_out = false;
+    const int wpg = gridDim.x / a.G;                   // workgroups per group
+    const int g = blockIdx.x / wpg;
+    const int S = (wpg * kBnFusedThreads / C4) * C4;   // unit stride of a thread: a multiple of C4, so its channel quad is fixed
+    const int gt = (blockIdx.x - g * wpg) * kBnFusedThreads + tid;
+    const int c4 = gt % C4;
+    const int64_t M = a.m_per_group;
+    const int64_t units = M * C4;
+    const float4* dz4 = (const float4*)a.dz + (int64_t)g * units;
+    const float4* z4 = a.z ? (const float4*)a.z + (int64_t)g * units : nullptr;
+    const float4* y4 = (const float4*)a.y[0] + (int64_t)g * units;
+    float4* o4 = (float4*)a.dy[0] + (int64_t)g * units;
+    const bool live = g < a.G && gt < S;
+    float4 d[E], xh[E];
+    float4 sd = make_float4(0.f, 0.f, 0.f, 0.f), sx = sd;
+    if (live) {
+        const float4 mean = *(const float4*)(a.mean[0] + (int64_t)g * a.C + c4 * 4);
+        const float4 istd = *(const float4*)(a.invstd[0] + (int64_t)g * a.C + c4 * 4);
+        float4 zz[E];
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int64_t u = (int64_t)gt + (int64_t)e * S;
+            const bool in = u < units;
+            const int64_t uu = in ? u : 0;
+            d[e] = dz4[uu];
+            xh[e] = y4[uu];
+            zz[e] = z4 ? z4[uu] : make_float4(1.f, 1.f, 1.f, 1.f);
+            if (!in) d[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            d[e].x = zz[e].x > 0.f ? d[e].x : 0.f; d[e].y = zz[e].y > 0.f ? d[e].y : 0.f;
+            d[e].z = zz[e].z > 0.f ? d[e].z : 0.f; d[e].w = zz[e].w > 0.f ? d[e].w : 0.f;
+            xh[e].x = (xh[e].x - mean.x) * istd.x; xh[e].y = (xh[e].y - mean.y) * istd.y;
+            xh[e].z = (xh[e].z - mean.z) * istd.z; xh[e].w = (xh[e].w - mean.w) * istd.w;
+            sd.x += d[e].x; sd.y += d[e].y; sd.z += d[e].z; sd.w += d[e].w;
+            sx.x = fmaf(d[e].x, xh[e].x, sx.x); sx.y = fmaf(d[e].y, xh[e].y, sx.y);
+            sx.z = fmaf(d[e].z, xh[e].z, sx.z); sx.w = fmaf(d[e].w, xh[e].w, sx.w);
+        }
+    }
+    red[0][tid] = sd;
+    red[1][tid] = sx;
+    __syncthreads();
+    // threads of this workgroup with channel quad q: tid = first(q) + k*C4
+    if (g < a.G && tid < 2 * C4) {
+        const int which = tid / C4, q = tid - which * C4;
+        const int base = (blockIdx.x - g * wpg) * kBnFusedThreads;
+        int first = (q - base % C4 + C4) % C4;
+        double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
+        for (int t = first; t < kBnFusedThreads; t += C4) {
+            const float4 v = red[which][t];
+            t0 += (double)v.x; t1 += (double)v.y; t2 += (double)v.z; t3 += (double)v.w;
+        }
+        double* dst = a.fsums + ((int64_t)(blockIdx.x % kBnFusedReps) * a.G * 2 + (int64_t)g * 2 + which) * a.C + q * 4;
+        // returning atomics: the wave waits for them to have executed (at the device-wide coherence point) before the barrier below
+        double r = __hip_atomic_fetch_add(dst + 0, t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r += __hip_atomic_fetch_add(dst + 1, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r += __hip_atomic_fetch_add(dst + 2, t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r += __hip_atomic_fetch_add(dst + 3, t3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (r == 1.2345e300) red[0][0].x = 0.f;   // keeps the returns (never true)
+    }
+    // ---- grid-wide arrival ---------------------------------------------------------------------------
+    // Relaxed device-scope atomics only: they execute at the coherence point and bypass the per-XCD L2, so no release / acquire
+    // fence (an L2 write-back + invalidate per fence on this part: ~50 us per launch when the spin loop carried an acquire).
+    __syncthreads();
+    if (tid == 0) {
+        // two-level arrival: 8 sub-counters (same-address atomics serialise: 256 arrivals on one counter cost ~15 us), the last
+        // arrival of each sub-counter reports to the master counter a.barrier[0]
+        const unsigned sub = blockIdx.x % kBnFusedReps;
+        const unsigned members = (gridDim.x - sub + kBnFusedReps - 1) / kBnFusedReps;
+        const unsigned groups_total = gridDim.x < (unsigned)kBnFusedReps ? gridDim.x : (unsigned)kBnFusedReps;
+        if (__hip_atomic_fetch_add(a.barrier + 1 + sub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1)
+            __hip_atomic_fetch_add(a.barrier, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (__hip_atomic_load(a.barrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < groups_total && ++spins < (1 << 22))
+            __builtin_amdgcn_s_sleep(1);
+        timed_out = spins >= (1 << 22);
+    }
+    __syncthreads();
+    const double Md = (double)M;
+    if (g < a.G && tid < 2 * a.C) {
+        const int which = tid / a.C, c = tid - which * a.C;
+        double v = 0.0;
+        for (int r = 0; r < kBnFusedReps; ++r)
+            v += __hip_atomic_load(a.fsums + ((int64_t)r * a.G * 2 + (int64_t)g * 2 + which) * a.C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        kk[which][c] = timed_out ? __builtin_nanf("") : (float)(v / Md);
+    }
+    if (blockIdx.x == 0 && tid < a.C) {   // dgamma / dbeta over all groups
+        double db = 0.0, dg = 0.0;
+        for (int gg = 0; gg < a.G; ++gg)
+            for (int r = 0; r < kBnFusedReps; ++r) {
+                db += __hip_atomic_load(a.fsums + ((int64_t)r * a.G * 2 + (int64_t)gg * 2 + 0) * a.C + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                dg += __hip_atomic_load(a.fsums + ((int64_t)r * a.G * 2 + (int64_t)gg * 2 + 1) * a.C + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        if (a.accumulate) {
+            a.dgamma[0][tid] += (float)dg;
+            a.dbeta[0][tid] += (float)db;
+        } else {
+            a.dgamma[0][tid] = (float)dg;
+            a.dbeta[0][tid] = (float)db;
+        }
+    }
+    __syncthreads();
+    if (live) {
+        const float4 k1 = *(const float4*)&kk[0][c4 * 4];
+        const float4 k2 = *(const float4*)&kk[1][c4 * 4];
+        const float4 gm = *(const float4*)(a.gamma[0] + c4 * 4);
+        const float4 istd = *(const float4*)(a.invstd[0] + (int64_t)g * a.C + c4 * 4);
+        const float4 sc = make_float4(gm.x * istd.x, gm.y * istd.y, gm.z * istd.z, gm.w * istd.w);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int64_t u = (int64_t)gt + (int64_t)e * S;
+            if (u < units) {
+                float4 o;
+                o.x = sc.x * (d[e].x - k1.x - xh[e].x * k2.x);
+                o.y = sc.y * (d[e].y - k1.y - xh[e].y * k2.y);
+                o.z = sc.z * (d[e].z - k1.z - xh[e].z * k2.z);
+                o.w = sc.w * (d[e].w - k1.w - xh[e].w * k2.w);
+                o4[u] = o;
+            }
+        }
+    }
+}
+
 static int g_bn_bwd_cap = 0, g_bn_bwd_unroll = 0, g_bn_bwd_phase = 0;   // micro-benchmark overrides (kbench)
 void bn_bwd_tune(int cap, int unroll, int phase) { g_bn_bwd_cap = cap; g_bn_bwd_unroll = unroll; g_bn_bwd_phase = phase; }
+
+static int g_bn_fused = -1;   // -1: environment (OCL_BN_FUSED, default on)
+static int g_num_cus = 0;
+void bn_bwd_fused_enable(int on) { g_bn_fused = on; }
 
 int launch_bn_bwd(const BnBwdArgs& a, hipStream_t s) {
     OCL_REQUIRE(a.nsets == 1 || a.nsets == 2, "bn_bwd: nsets=%d", a.nsets);
     const int C4 = a.C / 4, PT = 256 / C4;
+    if (g_bn_fused < 0) {
+        const char* e = getenv("OCL_BN_FUSED");
+        g_bn_fused = e ? atoi(e) : 1;
+    }
+    if (g_bn_fused && a.barrier && a.fsums && a.nsets == 1 && a.G <= 2 && a.C <= 160 && g_bn_bwd_phase == 0) {
+        if (!g_num_cus) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            OCL_HIP(hipGetDevice(&dev));
+            OCL_HIP(hipGetDeviceProperties(&prop, dev));
+            g_num_cus = std::max(2, prop.multiProcessorCount);
+        }
+        // about 6 float4 per thread and tensor; never more workgroups than CUs (all must be resident), fewer for the small maps
+        // (the arrival costs grow with the workgroup count, the small maps are latency-bound anyway)
+        const int64_t total_units = a.m_per_group * C4 * a.G;
+        int grid = (int)std::min<int64_t>(g_num_cus, std::max<int64_t>(8, (total_units + kBnFusedThreads * 6 - 1) / (kBnFusedThreads * 6)));
+        grid = std::max(a.G, grid / a.G * a.G);
+        const int wpg = grid / a.G;
+        const int64_t S = (int64_t)(wpg * kBnFusedThreads / C4) * C4;
+        const int64_t need = (a.m_per_group * C4 + S - 1) / S;
+        if (need <= 12) {
+            ProfScope ps(PROF_BN, s);
+            if (need <= 3) hipLaunchKernelGGL(bn_bwd_fused_kernel<3>, dim3(grid), dim3(kBnFusedThreads), 0, s, a);
+            else if (need <= 6) hipLaunchKernelGGL(bn_bwd_fused_kernel<6>, dim3(grid), dim3(kBnFusedThreads), 0, s, a);
+            else hipLaunchKernelGGL(bn_bwd_fused_kernel<12>, dim3(grid), dim3(kBnFusedThreads), 0, s, a);
+            OCL_LAUNCH_CHECK();
+            return OCL_OK;
+        }
+    }
     const int U = g_bn_bwd_unroll ? g_bn_bwd_unroll : 4;
     // passes per block: 8 for the large maps, 4 once a group has fewer than 1024 passes in total (more, shorter blocks: the
     // small layers are latency-bound) -- profiles/r1_kbench_bn_sweep.txt

@@ -483,7 +483,16 @@ int main(int argc, char** argv) {
                 CK(hipMemsetAsync(sums, 0, 8 * 4 * 1024 * 8, 0));
                 OK(launch_bn_bwd(b, 0));
             });
+            b.barrier = (unsigned*)(sums + 4096);
+            b.fsums = sums + 8192;
+            const double tfz = time_us([&] {
+                CK(hipMemsetAsync(sums, 0, 8 * 4 * 1024 * 8, 0));
+                OK(launch_bn_bwd(b, 0));
+            });
+            b.barrier = nullptr;
+            b.fsums = nullptr;
             const double bytes = (double)N * c.Ho * c.Wo * c.Cout * 4;
+            printf("bn C=%3d HW=%2d  one-pass bwd %6.1f us (%.2f TB/s over 4 passes)\n", c.Cout, c.Ho, tfz, 4 * bytes / tfz * 1e-6);
             printf("bn C=%3d HW=%2d  elems=%9.0f  fwd(3 tensors) %6.1f us %5.2f TB/s   bwd(reduce+apply, 7 tensor passes) %6.1f us %5.2f TB/s\n",
                    c.Cout, c.Ho, bytes / 4, tf, 3 * bytes / tf * 1e-6, tb, 7 * bytes / tb * 1e-6);
             if (sweep) {

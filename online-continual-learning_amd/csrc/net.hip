@@ -29,6 +29,7 @@ struct BnInfo {
     int gamma_t, beta_t;  // tensor indices
     int64_t stat_off;     // into the running flat array: mean[C], var[C]
     int64_t arena_off;    // into per-BN arenas of size kGmax*2*C (doubles) / 2*C floats for the fold
+    int64_t fused_off;    // one-pass BatchNorm backward: replicated accumulators + arrival counter (doubles, in the bsums arena)
     int64_t save_off;     // into the slot's saved mean/invstd area (floats): mean[kGmax*C], invstd[kGmax*C]
 };
 struct ConvInfo : ConvShape {
@@ -327,8 +328,14 @@ static int build_layout(ocl_net* n) {
     n->stats_doubles = so * kStatReps;   // kStatReps replicas of the whole arena, replica stride `so`
     n->stats_rep_stride = so;
     n->off_stats = takeb(n->stats_doubles * 8);
-    n->bsums_doubles = so;  // backward: [G][2][C] per BN as well
-    n->off_bsums = takeb(so * 8);
+    // backward: [G][2][C] per BN as well, followed by the one-pass kernel's arenas (8 replicas x 2 groups x 2 x C + counter per BN)
+    int64_t fo = so;
+    for (auto& b : n->bns) {
+        b.fused_off = fo;
+        fo += (int64_t)8 * 2 * 2 * b.C + 8;   // + 9 arrival counters (unsigned)
+    }
+    n->bsums_doubles = fo;
+    n->off_bsums = takeb(fo * 8);
     n->off_pack = takeb(n->pack_floats * 4);
     n->fold_floats = n->n_stats;  // scale[C], shift[C] per BN, same layout as running stats
     n->off_fold = takeb(n->fold_floats * 4);
@@ -339,7 +346,7 @@ static int build_layout(ocl_net* n) {
     for (int i = 0; i < ocl_net::kDyRing; ++i) n->off_dy2[i] = takeb(max_act * 4);
     n->off_partial2 = takeb(n->partial_floats * 4);
     n->off_stats2 = takeb(n->stats_doubles * 8);
-    n->off_bsums2 = takeb(so * 8);
+    n->off_bsums2 = takeb(n->bsums_doubles * 8);
     n->off_grad2 = takeb(n->n_params * 4);
     {   // conv / BatchNorm tensors were added first: they form a prefix of the flat array
         int64_t end = 0, sum = 0;
@@ -882,7 +889,7 @@ int ocl_net_forward(ocl_net* n, const float* x, int N, int groups, uint32_t flag
 // (single-chain passes of large batches); null: everything on `s`, in order (dual-chain passes, small batches, measurements).
 // -----------------------------------------------------------------------------------------------------
 static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, float* S, int img0, int Nc, int G, int g0, int ch,
-                          int accumulate, const float* dfeat, hipStream_t s, hipStream_t side) {
+                          int accumulate, const float* dfeat, hipStream_t s, hipStream_t side, bool ch_shared = false) {
     float* pack = (float*)(n->ws + n->off_pack);
     float* partial = n->partialbuf(ch);
     double* bsums = n->bsumsbuf(ch);
@@ -956,6 +963,12 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
         }
         // sums are addressed [set][G][2][C] inside conv_a's arena of kGmax*2*C doubles: two sets need 2*G <= kGmax
         a.sums = bsums + n->bns[ca.bn].arena_off;
+        // one-pass kernel (one BatchNorm, <= 2 groups); not for the two-chain schedule (two such kernels at once could each hold CUs
+        // the other waits for)
+        if (conv_b < 0 && G <= 2 && !ch_shared) {
+            a.fsums = bsums + n->bns[ca.bn].fused_off;
+            a.barrier = (unsigned*)(a.fsums + (int64_t)8 * 2 * 2 * ca.Cout);
+        }
         if (conv_b >= 0 && 2 * G > kGmax) {
             set_error("bn_bwd: groups=%d too large for a shared reduction arena", G);
             return OCL_ERR_ARG;
@@ -1122,7 +1135,7 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
             ocl_net::GraphKey key{3, Nc, 1, slot, ch | (accumulate ? 2 : 0), 0u, P};
             auto body = [&](hipStream_t st, bool) -> int {
                 return trunk_backward(n, ps, P, ch ? G2 : Gr, S, ch * Nc, Nc, 1, ch, ch, ch ? 0 : accumulate, dfeat + (int64_t)ch * Nc * FD, st,
-                                      nullptr);
+                                      nullptr, true);
             };
             if ((rc = run_cached(n, key, ch ? n->s2 : s, dm == 1, body))) return rc;
         }

@@ -133,6 +133,45 @@ __global__ void __launch_bounds__(256) ce_kernel(const float* __restrict__ logit
     }
 }
 
+// Cross-entropy over a column segment (agents/base.py:96-108, the labels trick and the separated softmax): seg[j] in {-1, 0, 1, ...}
+// assigns every logit column to a segment (-1: takes no part); row r is a softmax over the columns of its label's segment.
+__device__ __forceinline__ float ce_row_seg(const float* __restrict__ x, const int* __restrict__ seg, int c, int64_t y, int lane,
+                                            float* __restrict__ dx, float scale) {
+    const int sid = seg[y];
+    float m = -INFINITY;
+    for (int j = lane; j < c; j += 64)
+        if (seg[j] == sid) m = fmaxf(m, x[j]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int j = lane; j < c; j += 64)
+        if (seg[j] == sid) s += expf(x[j] - m);
+    s = wave_sum(s);
+    const float lse = logf(s) + m;
+    const float xy = x[y];
+    if (dx) {
+        const float inv = 1.0f / s;
+        for (int j = lane; j < c; j += 64) {
+            const float p = seg[j] == sid ? expf(x[j] - m) * inv : 0.f;
+            dx[j] = (p - (j == (int)y ? 1.f : 0.f)) * scale;
+        }
+    }
+    return lse - xy;
+}
+
+__global__ void __launch_bounds__(256) ce_seg_kernel(const float* __restrict__ logits, const int64_t* __restrict__ y,
+                                                     const int* __restrict__ seg, int n, int c, float* __restrict__ loss_out,
+                                                     float* __restrict__ dlogits) {
+    __shared__ float part[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const float scale = 1.0f / (float)n;
+    float acc = 0.f;
+    for (int r = wid; r < n; r += 4)
+        acc += ce_row_seg(logits + (int64_t)r * c, seg, c, y[r], lane, dlogits ? dlogits + (int64_t)r * c : nullptr, scale);
+    if (lane == 0) part[wid] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) loss_out[0] = (part[0] + part[1] + part[2] + part[3]) / (float)n;
+}
+
 // K12 MIR: post CE - pre CE per sample
 __global__ void __launch_bounds__(256) mir_kernel(const float* __restrict__ pre, const float* __restrict__ post,
                                                   const int64_t* __restrict__ y, int n, int c, float* __restrict__ out) {
@@ -685,6 +724,16 @@ int ocl_ce_fwd_bwd(const float* logits, const int64_t* y, int n, int c, int redu
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(PROF_HEAD, s);
     hipLaunchKernelGGL(ce_kernel, dim3(1), dim3(256), 0, s, logits, y, n, c, reduction, loss_out, dlogits);
+    OCL_LAUNCH_CHECK();
+    return OCL_OK;
+}
+
+int ocl_ce_segmented_fwd_bwd(const float* logits, const int64_t* y, const int32_t* seg, int n, int c, float* loss_out, float* dlogits,
+                             void* stream) {
+    OCL_REQUIRE(logits && y && seg && loss_out && n > 0 && c > 0, "ce_segmented: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(PROF_HEAD, s);
+    hipLaunchKernelGGL(ce_seg_kernel, dim3(1), dim3(256), 0, s, logits, y, seg, n, c, loss_out, dlogits);
     OCL_LAUNCH_CHECK();
     return OCL_OK;
 }

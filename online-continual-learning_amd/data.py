@@ -65,6 +65,7 @@ class DeviceLoader(object):
             self.last_y_host = self.y_host[self.last_index_host]
             bx = ops.gather_u8_images(self.x, idx)
             by = ops.gather_rows(self.y, idx)
+            by.host = self.last_y_host   # numpy mirror of the labels (host-side bookkeeping without a device sync)
             start += sz
             yield bx, by
 

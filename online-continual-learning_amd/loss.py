@@ -23,6 +23,25 @@ def cross_entropy_mean(logits, labels):
     return _CEFunction.apply(logits, labels)
 
 
+class _CESegFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, seg):
+        loss, dl = ops.cross_entropy_segmented(logits, labels, seg, want_grad=True)
+        ctx.save_for_backward(dl)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g, None, None
+
+
+def cross_entropy_segmented_mean(logits, labels, seg):
+    """Mean cross-entropy with each row's softmax restricted to the logit columns of its label's segment
+    (agents/base.py:96-108: labels trick = one segment of the classes in the batch; separated softmax = old / new)."""
+    return _CESegFunction.apply(logits, labels, seg)
+
+
 class _SupConFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat_vm, labels, n_views, temperature):

@@ -131,6 +131,21 @@ def cross_entropy(logits, y, reduction="mean", want_grad=True):
     return (loss if red == 0 else loss[0]), dl
 
 
+def cross_entropy_segmented(logits, y, seg, want_grad=True):
+    """(mean loss, dlogits) of the softmax over each row's label segment; seg: int32 [c] on the device (agents/base.py:96-108)."""
+    ffi.init()
+    logits = _f32(logits)
+    y = _i64(y)
+    n, c = logits.shape
+    if seg.dtype != torch.int32 or not seg.is_cuda or seg.numel() != c:
+        raise RuntimeError("segment ids must be an int32 [%d] tensor on the GPU" % c)
+    loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+    dl = torch.empty_like(logits) if want_grad else None
+    ffi.check(ffi.lib().ocl_ce_segmented_fwd_bwd(ffi.ptr(logits), ffi.ptr(y), ffi.ptr(seg.contiguous()), n, c, ffi.ptr(loss), ffi.ptr(dl),
+                                                 ffi.stream()), "ce_segmented")
+    return loss[0], dl
+
+
 # ---- K7 ----------------------------------------------------------------------------------------------
 def supcon(feat_view_major, y, n_views, temperature, want_grad=True):
     """(loss, dfeat) for view-major features [n_views*bsz, dim] (utils/loss.py:19-96)."""

@@ -104,6 +104,44 @@ def gen_supcon():
     print("supcon ok")
 
 
+def gen_ce_tricks():
+    """agents/base.py:93-108 through the reference's own ContinualLearner.criterion (unbound, on a stand-in `self`)."""
+    from types import SimpleNamespace
+    R.activate()
+    import agents.base as ref_base
+    out = {}
+    cases = [("labels", 10, 100, list(range(20, 30)), []), ("labels", 20, 10, [3, 7], []), ("labels", 1, 100, [5], []),
+             ("sep", 10, 100, list(range(10)), list(range(10, 20))), ("sep", 20, 10, [0, 1, 2, 3], [8, 9]),
+             ("sep", 10, 100, [], [4, 5, 6])]
+    for ci, (kind, n, c, cls_a, cls_b) in enumerate(cases):
+        rng = np.random.default_rng(700 + ci)
+        logits = (3.0 * rng.standard_normal((n, c))).astype(np.float32)
+        pool = np.array(cls_a + cls_b if kind == "sep" else cls_a)
+        y = pool[rng.integers(0, len(pool), n)].astype(np.int64)
+        trick = {k: False for k in ('labels_trick', 'kd_trick', 'separated_softmax', 'review_trick', 'ncm_trick', 'kd_trick_star')}
+        trick['labels_trick' if kind == "labels" else 'separated_softmax'] = True
+        if kind == "sep":
+            old, new = list(cls_a), list(cls_b)
+            inv = {l: i for i, l in enumerate(old + new)}
+        else:
+            old, new, inv = [], [], {}
+        fake = SimpleNamespace(params=SimpleNamespace(trick=trick, agent="ER", temp=0.07), old_labels=old, new_labels=new, lbl_inv_map=inv)
+        lt = torch.from_numpy(logits).requires_grad_(True)
+        loss = ref_base.ContinualLearner.criterion(fake, lt, torch.from_numpy(y))
+        loss.backward()
+        lt2 = torch.from_numpy(logits).requires_grad_(True)
+        l2 = O.ce_labels_trick(lt2, torch.from_numpy(y)) if kind == "labels" else O.ce_separated_softmax(lt2, torch.from_numpy(y), old, new, inv)
+        l2.backward()
+        assert abs(float(loss) - float(l2)) < 1e-6 and (lt.grad - lt2.grad).abs().max() < 1e-7
+        out["c%d_kind" % ci] = np.array(kind)
+        out["c%d_logits" % ci], out["c%d_y" % ci] = logits, y
+        out["c%d_old" % ci], out["c%d_new" % ci] = np.array(old, dtype=np.int64), np.array(new, dtype=np.int64)
+        out["c%d_loss" % ci], out["c%d_grad" % ci] = np.float64(float(loss)), lt.grad.numpy()
+    out["n_cases"] = np.int64(len(cases))
+    np.savez_compressed(os.path.join(GOLD, "ce_tricks.npz"), **out)
+    print("ce tricks ok")
+
+
 def gen_buffer_ops():
     """reservoir slot sequences + random_retrieve index sequences for fixed seeds."""
     _, _, ref_res, ref_bu = _ref_modules()
@@ -293,11 +331,13 @@ if __name__ == "__main__":
     assert R.available(), "reference tree not found"
     torch.set_num_threads(1)
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["knn", "supcon", "buffer", "resnet", "steps"]
+    which = sys.argv[1:] or ["knn", "supcon", "ce_tricks", "buffer", "resnet", "steps"]
     if "knn" in which:
         gen_knn_sv()
     if "supcon" in which:
         gen_supcon()
+    if "ce_tricks" in which:
+        gen_ce_tricks()
     if "buffer" in which:
         gen_buffer_ops()
     if "resnet" in which:

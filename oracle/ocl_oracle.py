@@ -142,6 +142,24 @@ def ce_mean(logits, y):
     return F.cross_entropy(logits, y, reduction="mean")
 
 
+def ce_labels_trick(logits, labels):
+    """agents/base.py:96-101: cross-entropy over the heads that appear in the batch only."""
+    labels = labels.clone()
+    unq = labels.unique().sort()[0]
+    for i, lbl in enumerate(unq):
+        labels[labels == lbl] = i
+    return F.cross_entropy(logits[:, unq], labels, reduction="mean")
+
+
+def ce_separated_softmax(logits, labels, old_labels, new_labels, lbl_inv_map):
+    """agents/base.py:102-108: old and new classes normalised separately, NLL over the concatenation."""
+    old_ss = F.log_softmax(logits[:, old_labels], dim=1)
+    new_ss = F.log_softmax(logits[:, new_labels], dim=1)
+    ss = torch.cat([old_ss, new_ss], dim=1)
+    idx = torch.tensor([lbl_inv_map[int(l)] for l in labels.tolist()], dtype=torch.long)
+    return F.nll_loss(ss, idx)
+
+
 def mir_scores(logits_pre, logits_post, y):
     """mir_retrieve.py:26-28."""
     return F.cross_entropy(logits_post, y, reduction="none") - F.cross_entropy(logits_pre, y, reduction="none")

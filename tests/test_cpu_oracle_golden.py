@@ -42,6 +42,22 @@ def test_supcon_matches_reference():
         assert np.abs(f.grad.numpy() - g["c%d_grad" % ci]).max() < 1e-6
 
 
+def test_ce_tricks_match_reference():
+    """Labels trick / separated softmax (agents/base.py:96-108) vs the reference's ContinualLearner.criterion + autograd."""
+    g = gold("ce_tricks")
+    for ci in range(int(g["n_cases"])):
+        lt = torch.from_numpy(g["c%d_logits" % ci]).requires_grad_(True)
+        y = torch.from_numpy(g["c%d_y" % ci])
+        old, new = g["c%d_old" % ci].tolist(), g["c%d_new" % ci].tolist()
+        if str(g["c%d_kind" % ci]) == "labels":
+            loss = O.ce_labels_trick(lt, y)
+        else:
+            loss = O.ce_separated_softmax(lt, y, old, new, {l: i for i, l in enumerate(old + new)})
+        loss.backward()
+        assert abs(float(loss.detach()) - float(g["c%d_loss" % ci])) < 1e-6
+        assert np.abs(lt.grad.numpy() - g["c%d_grad" % ci]).max() < 1e-7
+
+
 def test_reservoir_and_random_retrieve_sequences_exact():
     g = gold("buffer_ops")
     for ci in range(int(g["n_cases"])):
