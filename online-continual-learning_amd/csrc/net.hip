@@ -114,6 +114,7 @@ struct ocl_net {
     bool ev_done_pending[6] = {false, false, false, false, false, false};
     hipEvent_t ev_join = nullptr, ev_fork = nullptr;
     int dy_next = 0;
+    size_t ev_next = 0;
 
     // hipGraph cache: the launch sequence of a forward / backward depends only on the key below (all other pointers are
     // engine-owned or bound once), so from the kGraphWarmCalls-th call with the same key on it is replayed as one graph
@@ -500,6 +501,7 @@ static const size_t kMaxGraphs = 48;
 // one chain (+ the weight-gradient stream), 2.93 ms with two chains, graphs or not -- the half-size launches of the two chains slow
 // each other down by more than the interleaving recovers, so this stays an opt-in experiment.
 static const int kTwoStreamMinBatch = 48;
+static const int kSideExtraMinBatch = 96;   // projection shortcut / head weight gradients on the side stream (MIR's 50-image passes lose 3 %)
 static const int kDualMinHalf = 8;
 static int dual_mode(const ocl_net* n) {
     static const int env = [] {
@@ -518,11 +520,26 @@ static int ensure_side_stream(ocl_net* n) {
     for (int i = 0; i < ocl_net::kDyRing; ++i) OCL_HIP(hipEventCreateWithFlags(&n->ev_done[i], hipEventDisableTiming));
     OCL_HIP(hipEventCreateWithFlags(&n->ev_join, hipEventDisableTiming));
     OCL_HIP(hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming));
-    for (int i = 0; i < 24; ++i) {   // one per publish() of a backward (2 per block + stem); created up front: none during capture
+    for (int i = 0; i < 48; ++i) {   // rolling pool for side_wait / side_join; created up front: none during capture
         hipEvent_t e;
         OCL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
         n->ev_ready.push_back(e);
     }
+    return OCL_OK;
+}
+
+// the side stream waits for everything issued on `s` so far (rolling pool of events; a wait captures the event's state at the call)
+static int side_wait(ocl_net* n, hipStream_t s) {
+    hipEvent_t e = n->ev_ready[n->ev_next++ % n->ev_ready.size()];
+    OCL_HIP(hipEventRecord(e, s));
+    OCL_HIP(hipStreamWaitEvent(n->s2, e, 0));
+    return OCL_OK;
+}
+// ... and `s` for everything issued on the side stream so far
+static int side_join(ocl_net* n, hipStream_t s) {
+    hipEvent_t e = n->ev_ready[n->ev_next++ % n->ev_ready.size()];
+    OCL_HIP(hipEventRecord(e, n->s2));
+    OCL_HIP(hipStreamWaitEvent(s, e, 0));
     return OCL_OK;
 }
 
@@ -691,13 +708,15 @@ int ocl_net_bind(ocl_net* net, float* params, float* grads, float* running, int6
 // (single chain); a dual-chain pass updates them afterwards, in group order, from both chains' statistics.
 // -----------------------------------------------------------------------------------------------------
 static int trunk_forward_train(ocl_net* n, PlanSet* ps, const float* P, float* S, int img0, int Nc, int G, int g0, int ch, bool upd,
-                               float* feat, hipStream_t st) {
+                               float* feat, hipStream_t st, bool side = false) {
     float* pack = (float*)(n->ws + n->off_pack);
     double* stats = n->statsbuf(ch);
     int rc = OCL_OK;
     OCL_HIP(hipMemsetAsync(stats, 0, n->stats_doubles * 8, st));
     auto at = [&](int64_t off, const ConvInfo& c) { return S + off + (int64_t)img0 * c.Ho * c.Wo * c.Cout; };
-    auto bn_fwd = [&](int conv_i, const float* y, float* z, const float* res, int relu) -> int {
+    // side: the projection shortcut (1x1 conv + BatchNorm, 3 blocks) runs on the engine's second stream next to conv1 / bn1 /
+    // conv2 of its block, which do not depend on it
+    auto bn_fwd = [&](int conv_i, const float* y, float* z, const float* res, int relu, hipStream_t st) -> int {
         const ConvInfo& c = n->convs[conv_i];
         const BnInfo& b = n->bns[c.bn];
         BnFwdArgs a;
@@ -717,33 +736,36 @@ static int trunk_forward_train(ocl_net* n, PlanSet* ps, const float* P, float* S
         a.momentum = 0.1f; a.eps = 1e-5f;
         return launch_bn_fwd(a, st);
     };
-    auto conv_stats = [&](int conv_i, const float* in) -> int {
+    auto conv_stats = [&](int conv_i, const float* in, hipStream_t st) -> int {
         const ConvInfo& c = n->convs[conv_i];
         return run_conv(n, ps->fwd[conv_i], in, pack + c.f_off, at(c.y_off, c), EPI_STATS, stats + n->bns[c.bn].arena_off, nullptr,
                         nullptr, nullptr, nullptr, st);
     };
     const ConvInfo& c0 = n->convs[0];
     const float* x4 = S + n->x4_off + (int64_t)img0 * n->d.in_h * n->d.in_w * 4;
-    if ((rc = conv_stats(0, x4))) return rc;
+    if ((rc = conv_stats(0, x4, st))) return rc;
     float* cur = at(n->zstem_off, c0);
-    if ((rc = bn_fwd(0, at(c0.y_off, c0), cur, nullptr, 1))) return rc;
+    if ((rc = bn_fwd(0, at(c0.y_off, c0), cur, nullptr, 1, st))) return rc;
     for (auto& b : n->blocks) {
         const ConvInfo& c1 = n->convs[b.conv1];
         const ConvInfo& c2 = n->convs[b.conv2];
         float* a1 = at(b.a1_off, c1);
         float* z = at(b.z_off, c2);
-        if ((rc = conv_stats(b.conv1, cur))) return rc;
-        if ((rc = bn_fwd(b.conv1, at(c1.y_off, c1), a1, nullptr, 1))) return rc;
-        if ((rc = conv_stats(b.conv2, a1))) return rc;
         const float* res = cur;
         if (b.convs >= 0) {
             const ConvInfo& cs = n->convs[b.convs];
-            if ((rc = conv_stats(b.convs, cur))) return rc;
+            hipStream_t ss = side ? n->s2 : st;
+            if (side && (rc = side_wait(n, st))) return rc;       // `cur` (and the zeroed statistics) are ready
+            if ((rc = conv_stats(b.convs, cur, ss))) return rc;
             float* sc = n->gbuf(0, ch);
-            if ((rc = bn_fwd(b.convs, at(cs.y_off, cs), sc, nullptr, 0))) return rc;
+            if ((rc = bn_fwd(b.convs, at(cs.y_off, cs), sc, nullptr, 0, ss))) return rc;
             res = sc;
         }
-        if ((rc = bn_fwd(b.conv2, at(c2.y_off, c2), z, res, 1))) return rc;
+        if ((rc = conv_stats(b.conv1, cur, st))) return rc;
+        if ((rc = bn_fwd(b.conv1, at(c1.y_off, c1), a1, nullptr, 1, st))) return rc;
+        if ((rc = conv_stats(b.conv2, a1, st))) return rc;
+        if (b.convs >= 0 && side && (rc = side_join(n, st))) return rc;
+        if ((rc = bn_fwd(b.conv2, at(c2.y_off, c2), z, res, 1, st))) return rc;
         cur = z;
     }
     return launch_avgpool_fwd(cur, feat, Nc, n->Hf, n->Wf, n->convs[n->blocks.back().conv2].Cout, st);
@@ -835,7 +857,11 @@ int ocl_net_forward(ocl_net* n, const float* x, int N, int groups, uint32_t flag
         if (feat_direct) OCL_HIP(hipMemcpyAsync(feat_out, featS, (size_t)N * n->feat_dim * 4, hipMemcpyDeviceToDevice, s));
         feat = featS;
     } else if (train) {
-        if ((rc = trunk_forward_train(n, ps, P, S, 0, N, groups, 0, 0, upd, feat, s))) return rc;
+        static const bool env_single = [] { const char* e = getenv("OCL_SINGLE_STREAM"); return e && e[0] == '1'; }();
+        static const bool env_noextra = [] { const char* e = getenv("OCL_SIDE_EXTRA"); return e && e[0] == '0'; }();
+        const bool side = n->dbg_stop < 0 && N >= kSideExtraMinBatch && !prof_on() && !env_single && !env_noextra;
+        if (side && (rc = ensure_side_stream(n))) return rc;
+        if ((rc = trunk_forward_train(n, ps, P, S, 0, N, groups, 0, 0, upd, feat, s, side))) return rc;
     } else {
         float* fold = (float*)(n->ws + n->off_fold);
         if ((rc = launch_bn_fold(P, n->running, fold, fold_descs(n), (int)n->bns.size(), 1e-5f, s))) return rc;
@@ -910,7 +936,6 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
     hipStream_t sw = two_streams ? side : s;   // stream of the weight gradients
     n->dy_next = 0;
     for (int i = 0; i < ocl_net::kDyRing; ++i) n->ev_done_pending[i] = false;
-    size_t ready_used = 0;
     auto take_dy = [&](int* slot_out) -> float* {   // next ring slot; the main stream waits for its previous readers
         const int r = n->dy_next;
         n->dy_next = (r + 1) % ocl_net::kDyRing;
@@ -922,16 +947,7 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
         return n->dybuf(r, ch);
     };
     auto publish = [&]() -> int {   // everything the main stream has written so far is visible to the wgrad stream
-        if (!two_streams) return OCL_OK;
-        if (ready_used == n->ev_ready.size()) {
-            hipEvent_t e;
-            OCL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            n->ev_ready.push_back(e);
-        }
-        hipEvent_t e = n->ev_ready[ready_used++];
-        OCL_HIP(hipEventRecord(e, s));
-        OCL_HIP(hipStreamWaitEvent(sw, e, 0));
-        return OCL_OK;
+        return two_streams ? side_wait(n, s) : OCL_OK;
     };
     auto release = [&](int r) -> int {   // the wgrad stream is done reading ring slot r
         if (!two_streams) return OCL_OK;
@@ -1095,11 +1111,24 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
     float* norms = S + n->norms_off;
 
     // ---- head -------------------------------------------------------------------------------------
+    // Single chain, two HIP streams for the large batches: the caller's stream carries the dependent chain (head dx -> BatchNorm
+    // backward -> data gradient -> ...); the weight gradients (head dW / db, conv_wgrad_kernel + reduce: a third of the step's MFMA
+    // work, needed by nobody until the optimiser step) run on a second stream as soon as their dL/dy exists.  dL/dy buffers of the
+    // trunk come from a ring, a slot is rewritten only after the event behind its last weight-gradient reader.  Replay batches of
+    // 10-20 images are latency-bound: the event traffic costs more than the overlap returns there.  Debug stops and measurement
+    // runs (ocl_prof_enable, OCL_SINGLE_STREAM=1: per-kernel durations of the kernel alone) stay on one stream as well.
+    static const bool env_single = [] { const char* e = getenv("OCL_SINGLE_STREAM"); return e && e[0] == '1'; }();
+    const bool two_streams = !dual && n->dbg_stop < 0 && N >= kTwoStreamMinBatch && !prof_on() && !env_single;
+    if (two_streams && (rc = ensure_side_stream(n))) return rc;
     auto lin_bwd = [&](const float* dy, int ncol, const float* xin, int kin, int tw, int tb, float* dx) -> int {
         // y = x W^T + b, W [ncol, kin]
-        int r = ocl_gemm_small(dy, 1, ncol, xin, kin, 1, GT(tw), kin, ncol, kin, N, nullptr, 0, accumulate, s);  // dW = dy^T x
+        static const bool env_noextra = [] { const char* e = getenv("OCL_SIDE_EXTRA"); return e && e[0] == '0'; }();
+        const bool hs = two_streams && N >= kSideExtraMinBatch && !env_noextra;
+        hipStream_t sw = hs ? n->s2 : s;
+        int r = hs ? side_wait(n, s) : OCL_OK;   // dy is complete
         if (r) return r;
-        if ((r = launch_colsum(dy, N, ncol, GT(tb), accumulate, s))) return r;
+        if ((r = ocl_gemm_small(dy, 1, ncol, xin, kin, 1, GT(tw), kin, ncol, kin, N, nullptr, 0, accumulate, sw))) return r;  // dW = dy^T x
+        if ((r = launch_colsum(dy, N, ncol, GT(tb), accumulate, sw))) return r;
         if (dx) r = ocl_gemm_small(dy, ncol, 1, T(tw), kin, 1, dx, kin, N, kin, ncol, nullptr, 0, 0, s);  // dx = dy W
         return r;
     };
@@ -1143,15 +1172,6 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
         OCL_HIP(hipStreamWaitEvent(s, n->ev_join, 0));
         return launch_add_inplace(Gr, G2, n->trunk_params, s);
     }
-    // Single chain.  Two HIP streams for the large batches: the caller's stream carries the dependent chain (BatchNorm backward ->
-    // data gradient -> ...), the weight gradients (conv_wgrad_kernel + reduce: a third of the step's MFMA work, needed by nobody
-    // until the optimiser step) run on a second stream as soon as their dL/dy exists; dL/dy buffers come from a ring, a slot is
-    // rewritten only after the event behind its last weight-gradient reader.  Replay batches of 10-20 images are latency-bound:
-    // the event traffic costs more than the overlap returns there.  Debug stops and measurement runs (ocl_prof_enable,
-    // OCL_SINGLE_STREAM=1: per-kernel durations of the kernel alone) stay on one stream as well.
-    static const bool env_single = [] { const char* e = getenv("OCL_SINGLE_STREAM"); return e && e[0] == '1'; }();
-    const bool two_streams = n->dbg_stop < 0 && N >= kTwoStreamMinBatch && !prof_on() && !env_single;
-    if (two_streams && (rc = ensure_side_stream(n))) return rc;
     return trunk_backward(n, ps, P, Gr, S, 0, N, G, 0, 0, accumulate, dfeat, s, two_streams ? n->s2 : nullptr);
 }
 
