@@ -3,7 +3,9 @@
 Per iteration: retrieve -> concat -> augment -> two views through SupConResNet -> SupCon loss -> SGD ->
 reservoir update.  The two views run as one batched pass with per-view BatchNorm statistics (the reference
 calls model.forward twice, scr.py:55)."""
+import contextlib
 import math
+import os
 
 import torch
 
@@ -76,21 +78,48 @@ class SupContrastReplay(ContinualLearner):
         losses = AverageMeter()
         acc_batch = AverageMeter()
 
+        # Data path on its own stream (random retrieve / reservoir update only: they never touch the model).  Same statements, same
+        # order, same RNG draws as the reference's loop; only the stream they are issued on differs, so that the gather / concat /
+        # augment / scatter launches of step i+1 (~20 tiny launches, ~0.15 ms back to back) run next to step i's backward instead
+        # of in front of step i+1's forward.
+        overlap = (self.cuda and self.params.retrieve == 'random' and self.params.update == 'random' and not debug.on()
+                   and os.environ.get("OCL_DATA_STREAM", "1") != "0")
+        main = torch.cuda.current_stream() if self.cuda else None
+        ds = ops.data_stream(x_train.device if torch.is_tensor(x_train) and x_train.is_cuda else torch.cuda.current_device()) if overlap else None
+        if overlap:
+            ds.wait_stream(main)
+
+        def on_data():
+            return torch.cuda.stream(ds) if overlap else contextlib.nullcontext()
+
         for ep in range(self.epoch):
-            for i, batch_data in enumerate(train_loader):
+            loader_it = iter(train_loader)
+            i = -1
+            while True:
+                with on_data():
+                    batch_data = next(loader_it, None)
+                if batch_data is None:
+                    break
+                i += 1
                 # batch update
                 batch_x, batch_y = batch_data
                 batch_y_host = train_loader.last_y_host
 
                 for j in range(self.mem_iters):
-                    mem_x, mem_y = self.buffer.retrieve(x=batch_x, y=batch_y)
+                    with on_data():
+                        mem_x, mem_y = self.buffer.retrieve(x=batch_x, y=batch_y)
 
                     if mem_x.size(0) > 0:
-                        mem_x = maybe_cuda(mem_x, self.cuda)
-                        mem_y = maybe_cuda(mem_y, self.cuda)
-                        combined_batch = torch.cat((mem_x, batch_x))
-                        combined_labels = torch.cat((mem_y, batch_y))
-                        combined_batch_aug = self.transform(combined_batch)
+                        with on_data():
+                            mem_x = maybe_cuda(mem_x, self.cuda)
+                            mem_y = maybe_cuda(mem_y, self.cuda)
+                            combined_batch = torch.cat((mem_x, batch_x))
+                            combined_labels = torch.cat((mem_y, batch_y))
+                            combined_batch_aug = self.transform(combined_batch)
+                        if overlap:
+                            main.wait_stream(ds)
+                            for t in (combined_batch, combined_batch_aug, combined_labels):
+                                t.record_stream(main)   # allocated on the data stream, consumed on the main one
                         features = self.model.forward_views([combined_batch, combined_batch_aug])
                         loss = self.criterion_views(features, combined_labels, 2)
                         if self.verbose:
@@ -102,10 +131,13 @@ class SupContrastReplay(ContinualLearner):
                         self.opt.step()
 
                 # update mem
-                self.buffer.update(batch_x, batch_y, y_host=batch_y_host)
+                with on_data():
+                    self.buffer.update(batch_x, batch_y, y_host=batch_y_host)
                 if i % 100 == 1 and self.verbose:
                         print(
                             '==>>> it: {}, avg. loss: {:.6f}, '
                                 .format(i, losses.avg(), acc_batch.avg())
                         )
+        if overlap:
+            main.wait_stream(ds)
         self.after_train()

@@ -39,6 +39,17 @@ class _PinnedRing(object):
 
 _ring = _PinnedRing()
 
+_data_streams = {}
+
+
+def data_stream(device):
+    """The stream of the data path (loader gather, buffer retrieve / update, concatenation, augmentation): none of it depends on
+    the weights, so an agent can issue step i+1's data work next to step i's backward (agents/scr.py)."""
+    key = torch.device(device).index
+    if key not in _data_streams:
+        _data_streams[key] = torch.cuda.Stream(device=device)
+    return _data_streams[key]
+
 
 def upload(t, device):
     """Asynchronous upload of a small CPU tensor (or numpy array) to `device`."""

@@ -427,3 +427,27 @@ def test_reference_style_agent_code_runs_on_the_engine(cuda):
     before = model.flat_params().clone()
     topt.step()
     assert torch.allclose(model.flat_params(), before - 0.1 * g, atol=1e-7)
+
+
+def test_scr_data_stream_overlap_is_schedule_only(cuda, monkeypatch):
+    """agents/scr.py issues the data path (loader gather, random retrieve, concat, augmentation, reservoir scatter) on its own
+    stream so that it runs next to the previous step's backward.  Same statements, same RNG draws: 60 free-running SCR steps
+    (real augmentation kernel, buffer filling up and being overwritten) with and without the overlap must end in the same
+    replay buffer bit for bit and the same weights up to the order of the fp64 statistic atomics."""
+    cfg = dict(STEP_CASES["scr_c100"], mem_size=200)
+    rng = np.random.default_rng(77)
+    x = rng.integers(0, 256, (600, 32, 32, 3), dtype=np.uint8)
+    y = rng.integers(0, 10, 600).astype(np.int64)
+    finals = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("OCL_DATA_STREAM", flag)
+        params, model, agent = build_agent(cfg)
+        from ocl_amd.agents.scr import ScrAugment
+        agent.transform = ScrAugment(size=(32, 32), scale=(0.2, 1.))
+        agent.train_learner(torch.from_numpy(x).to(cuda), y)
+        torch.cuda.synchronize()
+        finals.append((model.flat_params().cpu().numpy().copy(), agent.buffer.buffer_img.cpu().numpy().copy(),
+                       agent.buffer.buffer_label.cpu().numpy().copy(), agent.buffer.n_seen_so_far))
+    (w1, b1, l1, n1), (w0, b0, l0, n0) = finals
+    assert n1 == n0 == 600 and np.array_equal(l1, l0) and np.array_equal(b1, b0)
+    assert np.abs(w1 - w0).max() < 1e-4 * max(1.0, np.abs(w0).max())
