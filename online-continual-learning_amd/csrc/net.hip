@@ -1062,14 +1062,17 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
     int rS;
     float* gS = take_dy(&rS);
     if ((rc = bn_bwd(gA, at(n->zstem_off, c0), 0, gS, -1, nullptr))) return rc;
-    if ((rc = publish())) return rc;
-    if ((rc = wgrad(0, S + n->x4_off + (int64_t)img0 * n->d.in_h * n->d.in_w * 4, gS))) return rc;
-    if ((rc = release(rS))) return rc;
-    if (two_streams) {   // the caller's stream continues (optimiser step, next forward) only after every weight gradient
+    // The stem's weight gradient is the tail of the backward (nothing left to overlap it with): it runs on the caller's stream, after
+    // the join (the side stream's last kernels share the split-K slab buffer), without two more cross-stream hand-offs (~30 us of
+    // event latency in the trace) around it.
+    (void)rS;
+    if (two_streams) {
         OCL_HIP(hipEventRecord(n->ev_join, sw));
         OCL_HIP(hipStreamWaitEvent(s, n->ev_join, 0));
         for (int i = 0; i < ocl_net::kDyRing; ++i) n->ev_done_pending[i] = false;   // covered by the join
+        sw = s;
     }
+    if ((rc = wgrad(0, S + n->x4_off + (int64_t)img0 * n->d.in_h * n->d.in_w * 4, gS))) return rc;
     return OCL_OK;
 }
 
