@@ -345,11 +345,15 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs a) {
                                     }
                         }
                     };
-                    if (W == 16 && a.KU == 5) {   // 16x16x4: five groups in flight; 32x32x2 (64-cycle MFMAs): one is enough
-                        for (int s = 0; s < a.KC; s += 20) kgroups(s, std::integral_constant<int, 5>());
-                    } else {
-                        for (int s = 0; s < a.KC; s += 4) kgroups(s, std::integral_constant<int, 1>());
-                    }
+                    // 16x16x4: five k-groups in flight, then the remainder one at a time (main + remainder loops in sequence, not an
+                    // if / else on the trip count: the two arms of a branch got their accumulators in different registers and 24
+                    // v_accvgpr_mov + MFMA-hazard nops per tap to reconcile them); 32x32x2 (64-cycle MFMAs): one group is enough.
+                    // (Reading the LDS operands of group q+1 ahead of the MFMAs of group q by hand was measured too: +6 % on
+                    // layer 3, nothing elsewhere -- two waves per SIMD already cover that latency.)
+                    int s = 0;
+                    if constexpr (W == 16)
+                        for (; s + 20 <= a.KC; s += 20) kgroups(s, std::integral_constant<int, 5>());
+                    for (; s < a.KC; s += 4) kgroups(s, std::integral_constant<int, 1>());
                 }
             };
             if constexpr (WREG) {
