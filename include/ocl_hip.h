@@ -77,6 +77,11 @@ int ocl_ce_fwd_bwd(const float* logits, const int64_t* y, int n, int c, int redu
 int ocl_ce_segmented_fwd_bwd(const float* logits, const int64_t* y, const int32_t* seg, int n, int c, float* loss_out,
                              float* dlogits, void* stream);
 
+/* Knowledge-distillation loss of the KD tricks (utils/kd_manager.py:6-11, loss_fn_kd):
+ * mean_r(-sum_j softmax(target_r/T)_j * log_softmax(scores_r/T)_j) * T^2; dscores (may be NULL) = d(loss)/d(scores). */
+int ocl_kd_fwd_bwd(const float* scores, const float* target_scores, int n, int c, float T, float* loss_out, float* dscores,
+                   void* stream);
+
 /* ---- K7: supervised contrastive loss ---------------------------------------------------------------
  * SupConLoss.forward with contrast_mode='all' (utils/loss.py:19-96).  feat is VIEW-MAJOR
  * [n_views*bsz, dim] (= torch.cat(torch.unbind(features,1)), loss.py:56).  workspace: at least

@@ -1,8 +1,8 @@
 """agents/base.py:14-227 — ContinualLearner: label bookkeeping, criterion (CE / SupCon), review trick, and
 evaluate() with the nearest-class-mean classifier (NCM) or argmax, on the MI355X.
 
-The labels trick and the separated softmax share one segmented cross-entropy kernel; the KD tricks raise
-NotImplementedError instead of silently doing something else."""
+The labels trick and the separated softmax share one segmented cross-entropy kernel; the KD tricks use ocl_kd_fwd_bwd with a
+parameter-snapshot teacher (kd_manager.py)."""
 from abc import abstractmethod
 import abc
 import copy
@@ -12,6 +12,7 @@ import torch
 
 from .. import ops
 from ..loss import SupConLoss, cross_entropy_mean, cross_entropy_segmented_mean
+from ..kd_manager import KdManager
 from ..utils import maybe_cuda, AverageMeter
 
 
@@ -35,9 +36,7 @@ class ContinualLearner(torch.nn.Module, metaclass=abc.ABCMeta):
         self.task_seen = 0
         self.lbl_inv_map = {}
         self.class_task_map = {}
-        for t in ('kd_trick', 'kd_trick_star'):
-            if params.trick.get(t, False):
-                raise NotImplementedError("trick %r is outside the HIP hot path (BASELINE configs keep it off)" % t)
+        self.kd_manager = KdManager()
         if getattr(params, 'error_analysis', False):
             raise NotImplementedError("error_analysis is outside the HIP hot path")
 
@@ -88,6 +87,8 @@ class ContinualLearner(torch.nn.Module, metaclass=abc.ABCMeta):
                         self.opt.zero_grad()
                         loss.backward()
                         self._step_scaled(0.1)   # grads / 10 (base.py:84-87)
+        if self.params.trick['kd_trick'] or self.params.agent == 'LWF':   # base.py:90-91 (kd_trick_star alone never gets a teacher)
+            self.kd_manager.update_teacher(self.model)
 
     def _step_scaled(self, scale):
         if hasattr(self.opt, "model"):

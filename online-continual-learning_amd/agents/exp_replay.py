@@ -39,6 +39,12 @@ class ExperienceReplay(ContinualLearner):
                 for j in range(self.mem_iters):
                     logits = self.model.forward(batch_x)
                     loss = self.criterion(logits, batch_y)
+                    if self.params.trick['kd_trick']:
+                        loss = 1 / (self.task_seen + 1) * loss + (1 - 1 / (self.task_seen + 1)) * \
+                                   self.kd_manager.get_kd_loss(logits, batch_x)
+                    if self.params.trick['kd_trick_star']:
+                        loss = 1/((self.task_seen + 1) ** 0.5) * loss + \
+                               (1 - 1/((self.task_seen + 1) ** 0.5)) * self.kd_manager.get_kd_loss(logits, batch_x)
                     if self.verbose:
                         # trackers only (the reference syncs with .item() every iteration; here only when printing)
                         _, pred_label = torch.max(logits, 1)
@@ -57,6 +63,13 @@ class ExperienceReplay(ContinualLearner):
                         mem_y = maybe_cuda(mem_y, self.cuda)
                         mem_logits = self.model.forward(mem_x)
                         loss_mem = self.criterion(mem_logits, mem_y)
+                        if self.params.trick['kd_trick']:
+                            loss_mem = 1 / (self.task_seen + 1) * loss_mem + (1 - 1 / (self.task_seen + 1)) * \
+                                       self.kd_manager.get_kd_loss(mem_logits, mem_x)
+                        if self.params.trick['kd_trick_star']:
+                            loss_mem = 1 / ((self.task_seen + 1) ** 0.5) * loss_mem + \
+                                   (1 - 1 / ((self.task_seen + 1) ** 0.5)) * self.kd_manager.get_kd_loss(mem_logits,
+                                                                                                         mem_x)
                         if self.verbose:
                             losses_mem.update(loss_mem, mem_y.size(0))
                             _, pred_label = torch.max(mem_logits, 1)

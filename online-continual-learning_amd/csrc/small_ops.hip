@@ -172,6 +172,45 @@ __global__ void __launch_bounds__(256) ce_seg_kernel(const float* __restrict__ l
     if (threadIdx.x == 0) loss_out[0] = (part[0] + part[1] + part[2] + part[3]) / (float)n;
 }
 
+// Knowledge-distillation loss (utils/kd_manager.py:6-11): mean_r( -sum_j softmax(t_r/T)_j * log_softmax(s_r/T)_j ) * T^2, and its
+// gradient w.r.t. the student scores, (softmax(s/T) - softmax(t/T)) * T / n.  One wave per row.
+__global__ void __launch_bounds__(256) kd_kernel(const float* __restrict__ scores, const float* __restrict__ target, int n, int c,
+                                                 float T, float* __restrict__ loss_out, float* __restrict__ dscores) {
+    __shared__ float part[4];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const float invT = 1.0f / T;
+    float acc = 0.f;
+    for (int r = wid; r < n; r += 4) {
+        const float* s = scores + (int64_t)r * c;
+        const float* t = target + (int64_t)r * c;
+        float ms = -INFINITY, mt = -INFINITY;
+        for (int j = lane; j < c; j += 64) {
+            ms = fmaxf(ms, s[j] * invT);
+            mt = fmaxf(mt, t[j] * invT);
+        }
+        ms = wave_max(ms);
+        mt = wave_max(mt);
+        float ss = 0.f, st = 0.f;
+        for (int j = lane; j < c; j += 64) {
+            ss += expf(s[j] * invT - ms);
+            st += expf(t[j] * invT - mt);
+        }
+        ss = wave_sum(ss);
+        st = wave_sum(st);
+        const float lse = logf(ss) + ms, inv_s = 1.0f / ss, inv_t = 1.0f / st;
+        float row = 0.f;
+        for (int j = lane; j < c; j += 64) {
+            const float pt = expf(t[j] * invT - mt) * inv_t;
+            row -= pt * (s[j] * invT - lse);
+            if (dscores) dscores[(int64_t)r * c + j] = (expf(s[j] * invT - ms) * inv_s - pt) * T / (float)n;
+        }
+        acc += wave_sum(row);
+    }
+    if (lane == 0) part[wid] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) loss_out[0] = (part[0] + part[1] + part[2] + part[3]) / (float)n * T * T;
+}
+
 // K12 MIR: post CE - pre CE per sample
 __global__ void __launch_bounds__(256) mir_kernel(const float* __restrict__ pre, const float* __restrict__ post,
                                                   const int64_t* __restrict__ y, int n, int c, float* __restrict__ out) {
@@ -734,6 +773,16 @@ int ocl_ce_segmented_fwd_bwd(const float* logits, const int64_t* y, const int32_
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(PROF_HEAD, s);
     hipLaunchKernelGGL(ce_seg_kernel, dim3(1), dim3(256), 0, s, logits, y, seg, n, c, loss_out, dlogits);
+    OCL_LAUNCH_CHECK();
+    return OCL_OK;
+}
+
+int ocl_kd_fwd_bwd(const float* scores, const float* target_scores, int n, int c, float T, float* loss_out, float* dscores,
+                   void* stream) {
+    OCL_REQUIRE(scores && target_scores && loss_out && n > 0 && c > 0 && T > 0.f, "kd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(PROF_HEAD, s);
+    hipLaunchKernelGGL(kd_kernel, dim3(1), dim3(256), 0, s, scores, target_scores, n, c, T, loss_out, dscores);
     OCL_LAUNCH_CHECK();
     return OCL_OK;
 }

@@ -36,6 +36,7 @@ SIGNATURES = {
     "ocl_sgd_step": (C.c_int, [vp, vp, i64, f32, f32, f32, vp, vp]),
     "ocl_ce_fwd_bwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),
     "ocl_ce_segmented_fwd_bwd": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, vp, vp]),
+    "ocl_kd_fwd_bwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_float, vp, vp, vp]),
     "ocl_supcon_workspace_bytes": (i64, [C.c_int]),
     "ocl_supcon_fwd_bwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, f32, vp, vp, vp, vp]),
     "ocl_knn_sv": (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),

@@ -42,6 +42,24 @@ def cross_entropy_segmented_mean(logits, labels, seg):
     return _CESegFunction.apply(logits, labels, seg)
 
 
+class _KDFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scores, target_scores, T):
+        loss, ds = ops.kd_loss(scores, target_scores, T, want_grad=True)
+        ctx.save_for_backward(ds)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (ds,) = ctx.saved_tensors
+        return ds * g, None, None
+
+
+def loss_fn_kd(scores, target_scores, T=2.):
+    """utils/kd_manager.py:6-11."""
+    return _KDFunction.apply(scores, target_scores.detach(), T)
+
+
 class _SupConFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat_vm, labels, n_views, temperature):

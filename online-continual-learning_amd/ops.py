@@ -157,6 +157,19 @@ def cross_entropy_segmented(logits, y, seg, want_grad=True):
     return loss[0], dl
 
 
+def kd_loss(scores, target_scores, T=2.0, want_grad=True):
+    """(loss, dscores) of utils/kd_manager.py:6-11 (loss_fn_kd)."""
+    ffi.init()
+    scores, target_scores = _f32(scores), _f32(target_scores)
+    if scores.shape != target_scores.shape or scores.dim() != 2:
+        raise RuntimeError("kd_loss: scores %s vs target %s" % (tuple(scores.shape), tuple(target_scores.shape)))
+    n, c = scores.shape
+    loss = torch.empty(1, dtype=torch.float32, device=scores.device)
+    ds = torch.empty_like(scores) if want_grad else None
+    ffi.check(ffi.lib().ocl_kd_fwd_bwd(ffi.ptr(scores), ffi.ptr(target_scores), n, c, float(T), ffi.ptr(loss), ffi.ptr(ds), ffi.stream()), "kd")
+    return loss[0], ds
+
+
 # ---- K7 ----------------------------------------------------------------------------------------------
 def supcon(feat_view_major, y, n_views, temperature, want_grad=True):
     """(loss, dfeat) for view-major features [n_views*bsz, dim] (utils/loss.py:19-96)."""

@@ -142,6 +142,30 @@ def gen_ce_tricks():
     print("ce tricks ok")
 
 
+def gen_kd():
+    """utils/kd_manager.py:6-11 through the reference's own loss_fn_kd + autograd."""
+    R.activate()
+    import utils.kd_manager as ref_kd
+    out = {}
+    cases = [(10, 100, 2.0), (20, 10, 2.0), (1, 100, 2.0), (10, 10, 4.0)]
+    for ci, (n, c, T) in enumerate(cases):
+        rng = np.random.default_rng(800 + ci)
+        s_ = (3.0 * rng.standard_normal((n, c))).astype(np.float32)
+        t_ = (3.0 * rng.standard_normal((n, c))).astype(np.float32)
+        st = torch.from_numpy(s_).requires_grad_(True)
+        loss = ref_kd.loss_fn_kd(st, torch.from_numpy(t_), T)
+        loss.backward()
+        st2 = torch.from_numpy(s_).requires_grad_(True)
+        l2 = O.loss_fn_kd(st2, torch.from_numpy(t_), T)
+        l2.backward()
+        assert abs(float(loss) - float(l2)) < 1e-6 and (st.grad - st2.grad).abs().max() < 1e-7
+        out["c%d_s" % ci], out["c%d_t" % ci], out["c%d_T" % ci] = s_, t_, np.float64(T)
+        out["c%d_loss" % ci], out["c%d_grad" % ci] = np.float64(float(loss)), st.grad.numpy()
+    out["n_cases"] = np.int64(len(cases))
+    np.savez_compressed(os.path.join(GOLD, "kd.npz"), **out)
+    print("kd ok")
+
+
 def gen_buffer_ops():
     """reservoir slot sequences + random_retrieve index sequences for fixed seeds."""
     _, _, ref_res, ref_bu = _ref_modules()
@@ -331,13 +355,15 @@ if __name__ == "__main__":
     assert R.available(), "reference tree not found"
     torch.set_num_threads(1)
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["knn", "supcon", "ce_tricks", "buffer", "resnet", "steps"]
+    which = sys.argv[1:] or ["knn", "supcon", "ce_tricks", "kd", "buffer", "resnet", "steps"]
     if "knn" in which:
         gen_knn_sv()
     if "supcon" in which:
         gen_supcon()
     if "ce_tricks" in which:
         gen_ce_tricks()
+    if "kd" in which:
+        gen_kd()
     if "buffer" in which:
         gen_buffer_ops()
     if "resnet" in which:

@@ -160,6 +160,13 @@ def ce_separated_softmax(logits, labels, old_labels, new_labels, lbl_inv_map):
     return F.nll_loss(ss, idx)
 
 
+def loss_fn_kd(scores, target_scores, T=2.0):
+    """utils/kd_manager.py:6-11."""
+    log_scores_norm = F.log_softmax(scores / T, dim=1)
+    targets_norm = F.softmax(target_scores / T, dim=1)
+    return (-1 * targets_norm * log_scores_norm).sum(dim=1).mean() * T ** 2
+
+
 def mir_scores(logits_pre, logits_post, y):
     """mir_retrieve.py:26-28."""
     return F.cross_entropy(logits_post, y, reduction="none") - F.cross_entropy(logits_pre, y, reduction="none")

@@ -58,6 +58,16 @@ def test_ce_tricks_match_reference():
         assert np.abs(lt.grad.numpy() - g["c%d_grad" % ci]).max() < 1e-7
 
 
+def test_kd_loss_matches_reference():
+    g = gold("kd")
+    for ci in range(int(g["n_cases"])):
+        st = torch.from_numpy(g["c%d_s" % ci]).requires_grad_(True)
+        loss = O.loss_fn_kd(st, torch.from_numpy(g["c%d_t" % ci]), float(g["c%d_T" % ci]))
+        loss.backward()
+        assert abs(float(loss.detach()) - float(g["c%d_loss" % ci])) < 1e-6
+        assert np.abs(st.grad.numpy() - g["c%d_grad" % ci]).max() < 1e-7
+
+
 def test_reservoir_and_random_retrieve_sequences_exact():
     g = gold("buffer_ops")
     for ci in range(int(g["n_cases"])):

@@ -249,3 +249,15 @@ def test_ce_tricks_match_reference_golden(cuda):
             bad = dev(np.array([99], dtype=np.int64), cuda)
             with pytest.raises(KeyError):
                 ContinualLearner.criterion(fake, dev(g["c%d_logits" % ci][:1], cuda), bad)
+
+
+def test_kd_loss_matches_reference_golden(cuda):
+    """ocl_kd_fwd_bwd + its autograd node vs the reference's loss_fn_kd + autograd (1e-5 abs)."""
+    from ocl_amd.loss import loss_fn_kd
+    g = gold("kd")
+    for ci in range(int(g["n_cases"])):
+        st = dev(g["c%d_s" % ci], cuda).requires_grad_(True)
+        loss = loss_fn_kd(st, dev(g["c%d_t" % ci], cuda), float(g["c%d_T" % ci]))
+        (0.25 * loss).backward()
+        assert abs(float(loss) - float(g["c%d_loss" % ci])) < 1e-5
+        assert np.abs(st.grad.cpu().numpy() - 0.25 * g["c%d_grad" % ci]).max() < 1e-5

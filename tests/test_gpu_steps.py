@@ -451,3 +451,52 @@ def test_scr_data_stream_overlap_is_schedule_only(cuda, monkeypatch):
     (w1, b1, l1, n1), (w0, b0, l0, n0) = finals
     assert n1 == n0 == 600 and np.array_equal(l1, l0) and np.array_equal(b1, b0)
     assert np.abs(w1 - w0).max() < 1e-4 * max(1.0, np.abs(w0).max())
+
+
+def test_kd_trick_teacher_and_combined_loss_vs_oracle(cuda):
+    """KD trick (agents/exp_replay.py:42-44,64-66, utils/kd_manager.py): after the first task the teacher is the end-of-task
+    model; its train-mode forward (batch statistics, no effect on the student's running statistics) and the combined loss
+    1/(t+1) * CE + (1 - 1/(t+1)) * KD and its gradient w.r.t. the student logits against the oracle (torch-CPU autograd);
+    then one more task runs through the KD branches of the ER loop."""
+    cfg = STEP_CASES["er_c10"]
+    trick = dict(TRICK, kd_trick=True)
+    params, model, agent = build_agent(cfg, trick=trick)
+    tasks, _ = make_stream(cfg)
+    x0, y0 = tasks[0]
+    assert agent.kd_manager.teacher_model is None
+    agent.train_learner(x0[:40], y0[:40])
+    teacher = agent.kd_manager.teacher_model
+    assert teacher is not None and agent.task_seen == 1 and torch.equal(teacher, model.flat_params())
+    sd_teacher = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    # move the student away from the teacher
+    with torch.no_grad():
+        model.flat_params().mul_(1.01)
+    running_before = {k: v.clone() for k, v in model.state_dict().items() if "running" in k}
+    x1, y1 = tasks[1]
+    bx = torch.from_numpy(x1[:10].transpose(0, 3, 1, 2).astype(np.float32) / 255)
+    by = torch.from_numpy(y1[:10])
+    model.train()
+    with torch.no_grad():
+        t_logits = model.forward_with_params(bx.to(cuda), teacher)
+    t_ref = O.OracleNet(O.clone_state(sd_teacher, requires_grad=False), head=None, training=True)
+    with torch.no_grad():
+        t_logits_ref = t_ref.forward(bx)
+    assert np.abs(t_logits.cpu().numpy() - t_logits_ref.numpy()).max() < 1e-4 * max(1.0, float(t_logits_ref.abs().max()))
+    for k, v in running_before.items():
+        assert torch.equal(model.state_dict()[k], v), "teacher forward touched the student's %s" % k
+    # combined loss on leaf logits: kernels + autograd glue
+    rng = np.random.default_rng(3)
+    lg = (2.0 * rng.standard_normal((10, 10))).astype(np.float32)
+    a = 1 / (agent.task_seen + 1)
+    lt = torch.from_numpy(lg).to(cuda).requires_grad_(True)
+    loss = a * agent.criterion(lt, by.to(cuda)) + (1 - a) * agent.kd_manager.get_kd_loss(lt, bx.to(cuda))
+    loss.backward()
+    lr = torch.from_numpy(lg).requires_grad_(True)
+    loss_ref = a * O.ce_mean(lr, by) + (1 - a) * O.loss_fn_kd(lr, t_logits_ref)
+    loss_ref.backward()
+    assert abs(float(loss.detach()) - float(loss_ref.detach())) < 1e-4
+    assert np.abs(lt.grad.cpu().numpy() - lr.grad.numpy()).max() < 1e-4
+    # the ER loop with the KD branches (batch and memory passes), second task
+    agent.train_learner(x1[:40], y1[:40])
+    assert agent.task_seen == 2 and torch.isfinite(model.flat_params()).all()
+    assert not torch.equal(agent.kd_manager.teacher_model, teacher)
