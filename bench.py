@@ -242,7 +242,9 @@ def main():
     rank, world, local = odist.init_from_env()
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    res = gpu_leg(args, rank, world, local)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):   # the agents print like the reference ("buffer has N slots"): stdout carries the JSON only
+        res = gpu_leg(args, rank, world, local)
     if rank != 0:
         return
     w = WORKLOADS[args.workload]
@@ -272,7 +274,8 @@ def main():
     if "roofline" in res:
         line["roofline"] = res["roofline"]
     if not args.no_cpu_baseline and world == 1:
-        line["cpu_baseline"] = cpu_leg(args)
+        with contextlib.redirect_stdout(sys.stderr):
+            line["cpu_baseline"] = cpu_leg(args)
     print(json.dumps(line))
 
 
