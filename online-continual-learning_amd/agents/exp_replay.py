@@ -1,4 +1,6 @@
 """agents/exp_replay.py:10-104 — Experience Replay inner loop (also hosts MIR / ASER through the plugins)."""
+import os
+
 import numpy as np
 import torch
 
@@ -30,6 +32,9 @@ class ExperienceReplay(ContinualLearner):
         acc_batch = AverageMeter()
         acc_mem = AverageMeter()
         aser = self.params.update == 'ASER' or self.params.retrieve == 'ASER'
+        # one two-group pass instead of the batch pass + memory pass (see below)
+        merge = (self.params.retrieve == 'random' and not aser and not self.params.trick['kd_trick'] and not self.params.trick['kd_trick_star']
+                 and os.environ.get("OCL_ER_MERGE", "1") != "0")
 
         for ep in range(self.epoch):
             for i, batch_data in enumerate(train_loader):
@@ -37,6 +42,37 @@ class ExperienceReplay(ContinualLearner):
                 batch_x, batch_y = batch_data
                 batch_y_host = train_loader.last_y_host
                 for j in range(self.mem_iters):
+                    if merge:
+                        # Random retrieval reads neither the model nor its gradients, and nothing between the batch forward and
+                        # the retrieval draws from an RNG: retrieving first leaves every RNG stream as the reference's order does.
+                        # The batch pass and the memory pass (same weights, gradients summed by the two backward() calls) then
+                        # run as ONE two-group pass with per-group BatchNorm statistics, like SCR's two views: half the launches
+                        # of a step whose kernels sit at their latency floor.
+                        mem_x, mem_y = self.buffer.retrieve(x=batch_x, y=batch_y)
+                        if mem_x.size(0) == batch_x.size(0):
+                            mem_x = maybe_cuda(mem_x, self.cuda)
+                            mem_y = maybe_cuda(mem_y, self.cuda)
+                            both = self.model.forward_views([batch_x, mem_x])
+                            logits, mem_logits = both[:batch_x.size(0)], both[batch_x.size(0):]
+                            loss = self.criterion(logits, batch_y)
+                            loss_mem = self.criterion(mem_logits, mem_y)
+                            if self.verbose:
+                                _, pred_label = torch.max(logits, 1)
+                                acc_batch.update((pred_label == batch_y).sum() / batch_y.size(0), batch_y.size(0))
+                                losses_batch.update(loss, batch_y.size(0))
+                                losses_mem.update(loss_mem, mem_y.size(0))
+                                _, pred_label = torch.max(mem_logits, 1)
+                                acc_mem.update((pred_label == mem_y).sum() / mem_y.size(0), mem_y.size(0))
+                            if debug.on():
+                                debug.emit("er_loss", loss=float(loss.detach()))
+                                debug.emit("er_loss_mem", loss=float(loss_mem.detach()))
+                            self.opt.zero_grad()
+                            (loss + loss_mem).backward()
+                            self.opt.step()
+                            continue
+                        pre_retrieved = (mem_x, mem_y)     # empty or short memory batch: the reference's two passes
+                    else:
+                        pre_retrieved = None
                     logits = self.model.forward(batch_x)
                     loss = self.criterion(logits, batch_y)
                     if self.params.trick['kd_trick']:
@@ -52,12 +88,15 @@ class ExperienceReplay(ContinualLearner):
                         losses_batch.update(loss, batch_y.size(0))
                     if debug.on():
                         debug.emit("er_loss", loss=float(loss.detach()))
-                    # backward
+                    # backward (in ASER mode the gradients of this pass and of the memory pass are discarded by the zero_grad()
+                    # in front of the combined pass below -- only their forward's BatchNorm running-stat updates survive -- so
+                    # the backward is skipped unless MIR retrieval reads this pass's gradient vector)
                     self.opt.zero_grad()
-                    loss.backward()
+                    if not aser or self.params.retrieve == 'MIR':
+                        loss.backward()
 
                     # mem update
-                    mem_x, mem_y = self.buffer.retrieve(x=batch_x, y=batch_y)
+                    mem_x, mem_y = pre_retrieved if pre_retrieved is not None else self.buffer.retrieve(x=batch_x, y=batch_y)
                     if mem_x.size(0) > 0:
                         mem_x = maybe_cuda(mem_x, self.cuda)
                         mem_y = maybe_cuda(mem_y, self.cuda)
@@ -77,7 +116,8 @@ class ExperienceReplay(ContinualLearner):
 
                         if debug.on():
                             debug.emit("er_loss_mem", loss=float(loss_mem.detach()))
-                        loss_mem.backward()
+                        if not aser:
+                            loss_mem.backward()
 
                     if aser:
                         # opt update: passes #1/#2 only leave their BatchNorm running-stat updates behind
