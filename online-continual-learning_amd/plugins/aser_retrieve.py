@@ -7,7 +7,7 @@ from .. import ops
 from .. import debug
 from ..setup_elements import n_classes
 from ..utils import maybe_cuda
-from .aser_utils import compute_knn_sv
+from .aser_utils import compute_knn_sv, compute_knn_sv_pair
 from .buffer_utils import ClassBalancedRandomSampling, random_retrieve
 
 
@@ -53,23 +53,26 @@ class ASER_retrieve(object):
         # Type 1 - Adversarial SV: eval <- current input
         eval_adv_x, eval_adv_y = cur_x, cur_y
         dbg = debug.on()
-        sv_matrix_adv = compute_knn_sv(model, eval_adv_x, eval_adv_y, cand_x, cand_y, self.k, device=self.device, want_order=dbg)
         order_adv = order_coop = None
-        if dbg:
-            sv_matrix_adv, order_adv = sv_matrix_adv
 
         if self.aser_type != "neg_sv":
-            # Type 2 - Cooperative SV: eval <- class balanced subsamples from memory excluding the candidates
+            # Type 2 - Cooperative SV: eval <- class balanced subsamples from memory excluding the candidates.  Sampled before
+            # the adversarial values are computed (nothing in between draws from an RNG), so that both Shapley matrices come
+            # from ONE feature pass over current input + cooperative samples + candidates.
             excl_indices = set(cand_ind.tolist())
             eval_coop_x, eval_coop_y, _ = \
                 ClassBalancedRandomSampling.sample(buffer_x, buffer_y, self.n_smp_cls,
                                                    excl_indices=excl_indices, device=self.device)
-            sv_matrix_coop = \
-                compute_knn_sv(model, eval_coop_x, eval_coop_y, cand_x, cand_y, self.k, device=self.device, want_order=dbg)
+            sv_matrix_adv, sv_matrix_coop = compute_knn_sv_pair(model, eval_adv_x, eval_adv_y, eval_coop_x, eval_coop_y, cand_x, cand_y,
+                                                                self.k, want_order=dbg)
             if dbg:
+                sv_matrix_adv, order_adv = sv_matrix_adv
                 sv_matrix_coop, order_coop = sv_matrix_coop
             sv = ops.aser_score(sv_matrix_adv, sv_matrix_coop, self.aser_type)
         else:
+            sv_matrix_adv = compute_knn_sv(model, eval_adv_x, eval_adv_y, cand_x, cand_y, self.k, device=self.device, want_order=dbg)
+            if dbg:
+                sv_matrix_adv, order_adv = sv_matrix_adv
             sv = ops.aser_score(sv_matrix_adv, None, "neg_sv")
 
         ret_ind = ops.argsort_desc(sv)[:num_retrieve].contiguous()

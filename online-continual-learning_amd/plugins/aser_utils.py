@@ -32,6 +32,18 @@ def compute_knn_sv(model, eval_x, eval_y, cand_x, cand_y, k, device="cpu", want_
     return ops.knn_sv(eval_df.contiguous(), eval_y, cand_df.contiguous(), cand_y, k, want_order=want_order)
 
 
+def compute_knn_sv_pair(model, eval_a_x, eval_a_y, eval_b_x, eval_b_y, cand_x, cand_y, k, want_order=False):
+    """Two compute_knn_sv calls over the SAME candidates (aser_retrieve.py:56-76: adversarial and cooperative Shapley values)
+    with ONE eval-mode feature pass over eval_a + eval_b + candidates: eval-mode features are per-sample, so the candidates'
+    features (computed twice by the reference) are the same in both calls."""
+    na, nb, nc = eval_a_x.size(0), eval_b_x.size(0), cand_x.size(0)
+    total_x = maybe_cuda(torch.cat((eval_a_x, eval_b_x, cand_x), 0))
+    f = mini_batch_deep_features(model, total_x, na + nb + nc)
+    fa, fb, fc = f[0:na].contiguous(), f[na:na + nb].contiguous(), f[na + nb:].contiguous()
+    return (ops.knn_sv(fa, eval_a_y, fc, cand_y, k, want_order=want_order),
+            ops.knn_sv(fb, eval_b_y, fc, cand_y, k, want_order=want_order))
+
+
 def add_minority_class_input(cur_x, cur_y, mem_size, num_class, cur_y_host=None):
     """aser_utils.py:119-157.  Threshold ~ U(0, 1/num_class) on the torch CPU generator; class counts come from
     ClassBalancedRandomSampling.class_num_cache (host)."""
