@@ -1,4 +1,13 @@
-"""agents/exp_replay.py:10-104 — Experience Replay inner loop (also hosts MIR / ASER through the plugins)."""
+"""Experience Replay inner loop on the engine (reference: agents/exp_replay.py:10-104; also the host of the MIR and ASER plugins).
+
+Per stream batch the reference does: batch pass (forward, CE, backward) -> buffer.retrieve -> memory pass (forward, CE, backward
+into the same gradients) -> [ASER mode: zero_grad, one pass over memory + batch] -> opt.step -> buffer.update.  This file keeps that
+sequence of model / RNG / buffer effects and chooses a cheaper schedule where the result is provably the same:
+
+* random retrieval (`_merged_step`): the memory batch is drawn first and batch + memory run as ONE two-group pass;
+* ASER mode (`_two_pass_step`): the gradients of the first two passes are thrown away by the reference's zero_grad(), so their
+  backward is not run (MIR retrieval still gets the batch pass's gradient vector).
+"""
 import os
 
 import numpy as np
@@ -19,134 +28,111 @@ class ExperienceReplay(ContinualLearner):
         self.eps_mem_batch = params.eps_mem_batch
         self.mem_iters = params.mem_iters
 
+    # ---- pieces of a step ----------------------------------------------------------------------------------------------
+    def _kd_mix(self, loss, logits, x):
+        """CE blended with the distillation loss against last task's model (exp_replay.py:42-47 / :64-69)."""
+        trick = self.params.trick
+        if trick['kd_trick']:
+            w = 1 / (self.task_seen + 1)
+            loss = w * loss + (1 - w) * self.kd_manager.get_kd_loss(logits, x)
+        if trick['kd_trick_star']:
+            w = 1 / ((self.task_seen + 1) ** 0.5)
+            loss = w * loss + (1 - w) * self.kd_manager.get_kd_loss(logits, x)
+        return loss
+
+    def _track(self, meters, logits, labels, loss):
+        """Running loss / accuracy (only when printing: the reference's per-iteration .item() would stall the stream)."""
+        if not self.verbose:
+            return
+        loss_meter, acc_meter = meters
+        hits = (torch.max(logits, 1)[1] == labels).sum()
+        acc_meter.update(hits / labels.size(0), labels.size(0))
+        loss_meter.update(loss, labels.size(0))
+
+    @staticmethod
+    def _emit(tag, loss):
+        if debug.on():
+            debug.emit(tag, loss=float(loss.detach()))
+
+    def _merged_step(self, batch_x, batch_y, mem_x, mem_y, meters):
+        """Batch pass + memory pass as one pass with two BatchNorm groups (statistics and running-stat updates per group, in
+        order); the two CE losses are back-propagated together, which is what two backward() calls into the same gradients sum to."""
+        n = batch_x.size(0)
+        both = self.model.forward_views([batch_x, mem_x])
+        logits, mem_logits = both[:n], both[n:]
+        loss, loss_mem = self.criterion(logits, batch_y), self.criterion(mem_logits, mem_y)
+        self._track(meters[0], logits, batch_y, loss)
+        self._track(meters[1], mem_logits, mem_y, loss_mem)
+        self._emit("er_loss", loss)
+        self._emit("er_loss_mem", loss_mem)
+        self.opt.zero_grad()
+        (loss + loss_mem).backward()
+        self.opt.step()
+
+    def _two_pass_step(self, batch_x, batch_y, batch_y_host, meters, aser, retrieved=None):
+        logits = self.model.forward(batch_x)
+        loss = self._kd_mix(self.criterion(logits, batch_y), logits, batch_x)
+        self._track(meters[0], logits, batch_y, loss)
+        self._emit("er_loss", loss)
+        self.opt.zero_grad()
+        if not aser or self.params.retrieve == 'MIR':   # ASER mode discards this gradient; MIR reads it
+            loss.backward()
+
+        mem_x, mem_y = retrieved if retrieved is not None else self.buffer.retrieve(x=batch_x, y=batch_y)
+        if mem_x.size(0) > 0:
+            mem_x, mem_y = maybe_cuda(mem_x, self.cuda), maybe_cuda(mem_y, self.cuda)
+            mem_logits = self.model.forward(mem_x)
+            loss_mem = self._kd_mix(self.criterion(mem_logits, mem_y), mem_logits, mem_x)
+            self._track(meters[1], mem_logits, mem_y, loss_mem)
+            self._emit("er_loss_mem", loss_mem)
+            if not aser:
+                loss_mem.backward()
+
+        if aser:
+            # exp_replay.py:76-84: the update comes from one more pass over memory + batch; passes 1 and 2 only leave their
+            # BatchNorm running-statistic updates behind
+            self.opt.zero_grad()
+            combined_batch = torch.cat((mem_x, batch_x))
+            combined_labels = torch.cat((mem_y, batch_y))
+            if getattr(mem_y, 'host', None) is not None:
+                combined_labels.host = np.concatenate((np.asarray(mem_y.host), np.asarray(batch_y_host)))
+            loss_combined = self.criterion(self.model.forward(combined_batch), combined_labels)
+            self._emit("er_loss_combined", loss_combined)
+            loss_combined.backward()
+        self.opt.step()
+
+    # ---- the loop ------------------------------------------------------------------------------------------------------
     def train_learner(self, x_train, y_train):
         self.before_train(x_train, y_train)
-        # set up loader: device-resident task, same sampler / RNG draws as the reference's DataLoader
+        # device-resident task behind the reference's DataLoader (same sampler, same RNG draws)
         train_loader = DeviceLoader(x_train, y_train, self.batch, shuffle=True, drop_last=True)
-        # set up model
         self.model = self.model.train()
+        meters = ((AverageMeter(), AverageMeter()), (AverageMeter(), AverageMeter()))   # (loss, acc) of batch / memory passes
 
-        # setup tracker
-        losses_batch = AverageMeter()
-        losses_mem = AverageMeter()
-        acc_batch = AverageMeter()
-        acc_mem = AverageMeter()
+        trick = self.params.trick
         aser = self.params.update == 'ASER' or self.params.retrieve == 'ASER'
-        # one two-group pass instead of the batch pass + memory pass (see below)
-        merge = (self.params.retrieve == 'random' and not aser and not self.params.trick['kd_trick'] and not self.params.trick['kd_trick_star']
+        # Random retrieval reads neither the model nor its gradients and nothing between the batch forward and the retrieval draws
+        # from an RNG, so retrieving first leaves every RNG stream as the reference's order does.
+        merge = (self.params.retrieve == 'random' and not aser and not trick['kd_trick'] and not trick['kd_trick_star']
                  and os.environ.get("OCL_ER_MERGE", "1") != "0")
 
         for ep in range(self.epoch):
-            for i, batch_data in enumerate(train_loader):
-                # batch update
-                batch_x, batch_y = batch_data
+            for i, (batch_x, batch_y) in enumerate(train_loader):
                 batch_y_host = train_loader.last_y_host
                 for j in range(self.mem_iters):
+                    retrieved = None
                     if merge:
-                        # Random retrieval reads neither the model nor its gradients, and nothing between the batch forward and
-                        # the retrieval draws from an RNG: retrieving first leaves every RNG stream as the reference's order does.
-                        # The batch pass and the memory pass (same weights, gradients summed by the two backward() calls) then
-                        # run as ONE two-group pass with per-group BatchNorm statistics, like SCR's two views: half the launches
-                        # of a step whose kernels sit at their latency floor.
-                        mem_x, mem_y = self.buffer.retrieve(x=batch_x, y=batch_y)
-                        if mem_x.size(0) == batch_x.size(0):
-                            mem_x = maybe_cuda(mem_x, self.cuda)
-                            mem_y = maybe_cuda(mem_y, self.cuda)
-                            both = self.model.forward_views([batch_x, mem_x])
-                            logits, mem_logits = both[:batch_x.size(0)], both[batch_x.size(0):]
-                            loss = self.criterion(logits, batch_y)
-                            loss_mem = self.criterion(mem_logits, mem_y)
-                            if self.verbose:
-                                _, pred_label = torch.max(logits, 1)
-                                acc_batch.update((pred_label == batch_y).sum() / batch_y.size(0), batch_y.size(0))
-                                losses_batch.update(loss, batch_y.size(0))
-                                losses_mem.update(loss_mem, mem_y.size(0))
-                                _, pred_label = torch.max(mem_logits, 1)
-                                acc_mem.update((pred_label == mem_y).sum() / mem_y.size(0), mem_y.size(0))
-                            if debug.on():
-                                debug.emit("er_loss", loss=float(loss.detach()))
-                                debug.emit("er_loss_mem", loss=float(loss_mem.detach()))
-                            self.opt.zero_grad()
-                            (loss + loss_mem).backward()
-                            self.opt.step()
+                        retrieved = self.buffer.retrieve(x=batch_x, y=batch_y)
+                        if retrieved[0].size(0) == batch_x.size(0):
+                            self._merged_step(batch_x, batch_y, maybe_cuda(retrieved[0], self.cuda), maybe_cuda(retrieved[1], self.cuda),
+                                              meters)
                             continue
-                        pre_retrieved = (mem_x, mem_y)     # empty or short memory batch: the reference's two passes
-                    else:
-                        pre_retrieved = None
-                    logits = self.model.forward(batch_x)
-                    loss = self.criterion(logits, batch_y)
-                    if self.params.trick['kd_trick']:
-                        loss = 1 / (self.task_seen + 1) * loss + (1 - 1 / (self.task_seen + 1)) * \
-                                   self.kd_manager.get_kd_loss(logits, batch_x)
-                    if self.params.trick['kd_trick_star']:
-                        loss = 1/((self.task_seen + 1) ** 0.5) * loss + \
-                               (1 - 1/((self.task_seen + 1) ** 0.5)) * self.kd_manager.get_kd_loss(logits, batch_x)
-                    if self.verbose:
-                        # trackers only (the reference syncs with .item() every iteration; here only when printing)
-                        _, pred_label = torch.max(logits, 1)
-                        acc_batch.update((pred_label == batch_y).sum() / batch_y.size(0), batch_y.size(0))
-                        losses_batch.update(loss, batch_y.size(0))
-                    if debug.on():
-                        debug.emit("er_loss", loss=float(loss.detach()))
-                    # backward (in ASER mode the gradients of this pass and of the memory pass are discarded by the zero_grad()
-                    # in front of the combined pass below -- only their forward's BatchNorm running-stat updates survive -- so
-                    # the backward is skipped unless MIR retrieval reads this pass's gradient vector)
-                    self.opt.zero_grad()
-                    if not aser or self.params.retrieve == 'MIR':
-                        loss.backward()
+                    self._two_pass_step(batch_x, batch_y, batch_y_host, meters, aser, retrieved)
 
-                    # mem update
-                    mem_x, mem_y = pre_retrieved if pre_retrieved is not None else self.buffer.retrieve(x=batch_x, y=batch_y)
-                    if mem_x.size(0) > 0:
-                        mem_x = maybe_cuda(mem_x, self.cuda)
-                        mem_y = maybe_cuda(mem_y, self.cuda)
-                        mem_logits = self.model.forward(mem_x)
-                        loss_mem = self.criterion(mem_logits, mem_y)
-                        if self.params.trick['kd_trick']:
-                            loss_mem = 1 / (self.task_seen + 1) * loss_mem + (1 - 1 / (self.task_seen + 1)) * \
-                                       self.kd_manager.get_kd_loss(mem_logits, mem_x)
-                        if self.params.trick['kd_trick_star']:
-                            loss_mem = 1 / ((self.task_seen + 1) ** 0.5) * loss_mem + \
-                                   (1 - 1 / ((self.task_seen + 1) ** 0.5)) * self.kd_manager.get_kd_loss(mem_logits,
-                                                                                                         mem_x)
-                        if self.verbose:
-                            losses_mem.update(loss_mem, mem_y.size(0))
-                            _, pred_label = torch.max(mem_logits, 1)
-                            acc_mem.update((pred_label == mem_y).sum() / mem_y.size(0), mem_y.size(0))
-
-                        if debug.on():
-                            debug.emit("er_loss_mem", loss=float(loss_mem.detach()))
-                        if not aser:
-                            loss_mem.backward()
-
-                    if aser:
-                        # opt update: passes #1/#2 only leave their BatchNorm running-stat updates behind
-                        self.opt.zero_grad()
-                        combined_batch = torch.cat((mem_x, batch_x))
-                        combined_labels = torch.cat((mem_y, batch_y))
-                        if getattr(mem_y, 'host', None) is not None:
-                            combined_labels.host = np.concatenate((np.asarray(mem_y.host), np.asarray(batch_y_host)))
-                        combined_logits = self.model.forward(combined_batch)
-                        loss_combined = self.criterion(combined_logits, combined_labels)
-                        if debug.on():
-                            debug.emit("er_loss_combined", loss=float(loss_combined.detach()))
-                        loss_combined.backward()
-                        self.opt.step()
-                    else:
-                        self.opt.step()
-
-                # update mem
                 self.buffer.update(batch_x, batch_y, y_host=batch_y_host)
 
                 if i % 100 == 1 and self.verbose:
-                    print(
-                        '==>>> it: {}, avg. loss: {:.6f}, '
-                        'running train acc: {:.3f}'
-                            .format(i, losses_batch.avg(), acc_batch.avg())
-                    )
-                    print(
-                        '==>>> it: {}, mem avg. loss: {:.6f}, '
-                        'running mem acc: {:.3f}'
-                            .format(i, losses_mem.avg(), acc_mem.avg())
-                    )
+                    for tag, (loss_meter, acc_meter) in zip(("", "mem "), meters):
+                        print('==>>> it: {}, {}avg. loss: {:.6f}, running {}acc: {:.3f}'.format(i, tag, loss_meter.avg(), "mem " if tag else "train ",
+                                                                                             acc_meter.avg()))
         self.after_train()

@@ -1,8 +1,10 @@
-"""Replay memory with the reference's attributes and plugin dispatch (utils/buffer/buffer.py:8-41), device-resident.
+"""Device-resident replay memory behind the reference's `Buffer` surface (utils/buffer/buffer.py:8-41).
 
-`buffer_img` [mem,C,H,W] float32 and `buffer_label` [mem] int64 are registered module buffers on the MI355X;
-`label_host` is a numpy mirror of `buffer_label` that the update plugins keep in step so that class-balanced
-sampling and cache bookkeeping never synchronise the device."""
+Attributes the plugins rely on: `buffer_img` float32 [mem, C, H, W] and `buffer_label` int64 [mem] (registered module buffers in
+HBM, so `torch.save` keeps working), the fill / stream counters `current_index` and `n_seen_so_far`, `model`, `params`, `cuda`,
+`device`.  `label_host` is a numpy mirror of `buffer_label` that the update plugins keep in step, so class-balanced sampling and
+the class caches never synchronise the device.  update() / retrieve() dispatch to the plugins named by `params.update` /
+`params.retrieve` in `name_match`."""
 import numpy as np
 import torch
 
@@ -14,40 +16,31 @@ from .utils import maybe_cuda
 class Buffer(torch.nn.Module):
     def __init__(self, model, params):
         super().__init__()
-        self.params = params
-        self.model = model
-        self.cuda = self.params.cuda
-        self.current_index = 0
-        self.n_seen_so_far = 0
-        self.device = "cuda" if self.params.cuda else "cpu"
+        if getattr(params, "buffer_tracker", False):
+            raise NotImplementedError("buffer_tracker (match / mem_match retrieval) is outside the HIP hot path")
+        self.model, self.params = model, params
+        self.cuda = params.cuda
+        self.device = "cuda" if params.cuda else "cpu"
+        self.current_index = self.n_seen_so_far = 0
 
-        # define buffer
-        buffer_size = params.mem_size
-        print('buffer has %d slots' % buffer_size)
-        input_size = input_size_match[params.data]
-        buffer_img = maybe_cuda(torch.FloatTensor(buffer_size, *input_size).fill_(0))
-        buffer_label = maybe_cuda(torch.LongTensor(buffer_size).fill_(0))
-        if not buffer_img.is_cuda:
+        slots = params.mem_size
+        print('buffer has %d slots' % slots)
+        images = maybe_cuda(torch.zeros((slots,) + tuple(input_size_match[params.data]), dtype=torch.float32))
+        if not images.is_cuda:
             raise RuntimeError("the replay buffer must live on the MI355X; no GPU is visible and there is no CPU path")
+        self.register_buffer('buffer_img', images)
+        self.register_buffer('buffer_label', maybe_cuda(torch.zeros(slots, dtype=torch.int64)))
+        self.label_host = np.zeros(slots, dtype=np.int64)
 
-        # registering as buffer allows us to save the object using `torch.save`
-        self.register_buffer('buffer_img', buffer_img)
-        self.register_buffer('buffer_label', buffer_label)
-        self.label_host = np.zeros(buffer_size, dtype=np.int64)
-
-        # define update and retrieve method
         self.update_method = name_match.update_methods[params.update](params)
         self.retrieve_method = name_match.retrieve_methods[params.retrieve](params)
-
-        if getattr(self.params, "buffer_tracker", False):
-            raise NotImplementedError("buffer_tracker (match / mem_match retrieval) is outside the HIP hot path")
 
     def sync_host_labels(self):
         """Re-read the label mirror after something other than the update plugins wrote buffer_label."""
         self.label_host = self.buffer_label.detach().cpu().numpy().copy()
 
-    def update(self, x, y, **kwargs):
-        return self.update_method.update(buffer=self, x=x, y=y, **kwargs)
-
     def retrieve(self, **kwargs):
         return self.retrieve_method.retrieve(buffer=self, **kwargs)
+
+    def update(self, x, y, **kwargs):
+        return self.update_method.update(buffer=self, x=x, y=y, **kwargs)

@@ -1,11 +1,14 @@
-"""utils/buffer/random_retrieve.py:3-9."""
-from .buffer_utils import random_retrieve
+"""Uniform retrieval from the filled part of the replay memory -- the `retrieve_methods['random']` plugin
+(reference: utils/buffer/random_retrieve.py:3-9; the draw itself is plugins/buffer_utils.random_retrieve)."""
+from . import buffer_utils
 
 
-class Random_retrieve(object):
+class Random_retrieve:
+    """`params.eps_mem_batch` rows per call, fewer while the memory holds fewer; x / y keyword arguments are accepted and ignored."""
+
     def __init__(self, params):
-        super().__init__()
-        self.num_retrieve = params.eps_mem_batch
+        self.num_retrieve = int(params.eps_mem_batch)
 
-    def retrieve(self, buffer, **kwargs):
-        return random_retrieve(buffer, self.num_retrieve)
+    def retrieve(self, buffer, **_unused):
+        rows, labels = buffer_utils.random_retrieve(buffer, self.num_retrieve)
+        return rows, labels

@@ -1,71 +1,68 @@
-"""utils/buffer/reservoir_update.py:8-61.  Same fill-then-reservoir logic and the same RNG call
-(FloatTensor(n).uniform_(0, n_seen).long(), drawn on the CPU generator as the CPU reference does); the slot
-overwrite is a HIP scatter."""
+"""Reservoir sampling into the replay memory -- the `update_methods['random']` plugin (reference:
+utils/buffer/reservoir_update.py:8-61).
+
+Observable behaviour kept: while slots are free the stream fills them in order; afterwards every remaining item draws
+j ~ U[0, n_seen_so_far) with ONE `FloatTensor(k).uniform_(0, n_seen).long()` call on the torch CPU generator (what the CPU
+reference draws), is kept iff j < mem_size, and of several items drawing the same slot the last one wins while the slot keeps its
+first position in the returned list (the reference's dict).  Counters, the returned slot list and the host label mirror are
+maintained on the host; the overwrite itself is one gather + one scatter kernel per tensor."""
 import numpy as np
 import torch
 
-from .. import ops
 from .. import debug
+from .. import ops
 from .buffer_utils import _host_labels
 
 
-class Reservoir_update(object):
+class Reservoir_update:
     def __init__(self, params):
-        super().__init__()
+        pass
+
+    @staticmethod
+    def _fill(buffer, x, y, y_host, count):
+        """Append the first `count` items at current_index."""
+        lo = buffer.current_index
+        hi = lo + count
+        buffer.buffer_img[lo:hi].copy_(x[:count])
+        buffer.buffer_label[lo:hi].copy_(y[:count])
+        buffer.label_host[lo:hi] = y_host[:count]
+        buffer.current_index = hi
+        buffer.n_seen_so_far += count
+        return list(range(lo, hi))
 
     def update(self, buffer, x, y, **kwargs):
-        batch_size = x.size(0)
+        capacity = buffer.buffer_img.size(0)
         y_host = _host_labels(y, kwargs.get("y_host"))
+        n_items = x.size(0)
 
-        # add whatever still fits in the buffer
-        place_left = max(0, buffer.buffer_img.size(0) - buffer.current_index)
-        if place_left:
-            offset = min(place_left, batch_size)
-            buffer.buffer_img[buffer.current_index: buffer.current_index + offset].data.copy_(x[:offset])
-            buffer.buffer_label[buffer.current_index: buffer.current_index + offset].data.copy_(y[:offset])
-            buffer.label_host[buffer.current_index: buffer.current_index + offset] = y_host[:offset]
+        free = max(0, capacity - buffer.current_index)
+        if free:
+            taken = min(free, n_items)
+            slots = self._fill(buffer, x, y, y_host, taken)
+            if taken == n_items:
+                debug.emit("reservoir", slots=list(slots))
+                return slots
+        # the part of the batch that did not fit (all of it once the memory is full)
+        x, y, y_host = x[free:], y[free:], y_host[free:]
 
-            buffer.current_index += offset
-            buffer.n_seen_so_far += offset
-
-            # everything was added
-            if offset == x.size(0):
-                filled_idx = list(range(buffer.current_index - offset, buffer.current_index, ))
-                debug.emit("reservoir", slots=list(filled_idx))
-                return filled_idx
-
-        # remove what is already in the buffer
-        x, y = x[place_left:], y[place_left:]
-        y_host = y_host[place_left:]
-
-        indices = torch.FloatTensor(x.size(0)).uniform_(0, buffer.n_seen_so_far).long()
-        valid_indices = (indices < buffer.buffer_img.size(0)).long()
-
-        idx_new_data = valid_indices.nonzero().squeeze(-1)
-        idx_buffer = indices[idx_new_data]
-
+        draws = torch.FloatTensor(x.size(0)).uniform_(0, buffer.n_seen_so_far).long()
         buffer.n_seen_so_far += x.size(0)
-
-        if idx_buffer.numel() == 0:
+        kept = torch.nonzero(draws < capacity).squeeze(-1)
+        if kept.numel() == 0:
             debug.emit("reservoir", slots=[])
             return []
 
-        assert idx_buffer.max() < buffer.buffer_img.size(0)
-        assert idx_buffer.max() < buffer.buffer_label.size(0)
+        winner = {}                      # slot -> item; a later item replaces an earlier one, the slot keeps its place
+        for item, slot in zip(kept.tolist(), draws[kept].tolist()):
+            assert 0 <= slot < capacity and 0 <= item < x.size(0)
+            winner[slot] = item
+        slots, items = list(winner.keys()), list(winner.values())
 
-        assert idx_new_data.max() < x.size(0)
-        assert idx_new_data.max() < y.size(0)
-
-        idx_map = {idx_buffer[i].item(): idx_new_data[i].item() for i in range(idx_buffer.size(0))}
-
-        keys = list(idx_map.keys())
-        vals = list(idx_map.values())
         dev = buffer.buffer_img.device
-        keys_dev = ops.upload(torch.tensor(keys, dtype=torch.long), dev)
-        vals_dev = ops.upload(torch.tensor(vals, dtype=torch.long), dev)
-        # perform overwrite op
-        ops.scatter_rows(buffer.buffer_img, keys_dev, ops.gather_rows(x.contiguous(), vals_dev))
-        ops.scatter_rows(buffer.buffer_label, keys_dev, ops.gather_rows(y.contiguous(), vals_dev))
-        buffer.label_host[np.asarray(keys, dtype=np.int64)] = y_host[np.asarray(vals, dtype=np.int64)]
-        debug.emit("reservoir", slots=list(keys))
-        return keys
+        slots_dev = ops.upload(torch.tensor(slots, dtype=torch.long), dev)
+        items_dev = ops.upload(torch.tensor(items, dtype=torch.long), dev)
+        ops.scatter_rows(buffer.buffer_img, slots_dev, ops.gather_rows(x.contiguous(), items_dev))
+        ops.scatter_rows(buffer.buffer_label, slots_dev, ops.gather_rows(y.contiguous(), items_dev))
+        buffer.label_host[np.asarray(slots, dtype=np.int64)] = y_host[np.asarray(items, dtype=np.int64)]
+        debug.emit("reservoir", slots=list(slots))
+        return slots
