@@ -27,6 +27,7 @@ import torch
 
 # algorithmic work per image, Reduced-ResNet18 (MACs from forward hooks on the reference)
 MACS = {32: dict(fwd=54636160, stem=552960, fc=16000), 84: dict(fwd=385237440, stem=3810240, fc=64000)}
+KNN_BUFFER_BYTES = {"er": 0.25e6, "scr": 1.35e6, "aser": 6.5e6, "mir": 18.1e6}
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2 peak (= vector fp32 peak)
 
 WORKLOADS = {
@@ -169,6 +170,12 @@ def gpu_leg(args, rank, world, local):
             wgrad=dict(achieved=(wgrad_fl * n_prof / (wg["ms"] * 1e-3) / 1e12) if wg["ms"] > 0 else None,
                        algorithmic_gflop_per_step=wgrad_fl / 1e9, launches_per_step=wg["launches"] / n_prof,
                        avg_launch_us=(wg["ms"] * 1e3 / wg["launches"]) if wg["launches"] else None),
+            # kNN / buffer path (SURVEY §8d algorithmic bytes per iteration: buffer gather + features + slot replacement [+ MIR's virtual
+            # step]); latency-bound by construction, reported next to its kernel time
+            knn_buffer=dict(algorithmic_bytes_per_step=KNN_BUFFER_BYTES[args.workload],
+                            achieved_GBps=(KNN_BUFFER_BYTES[args.workload] / (cls["knn_buffer"]["ms"] / n_prof * 1e-3) / 1e9)
+                            if cls["knn_buffer"]["ms"] > 0 else None, peak_GBps=8000.0,
+                            launches_per_step=cls["knn_buffer"]["launches"] / n_prof),
             per_step_ms={k: v["ms"] / n_prof for k, v in cls.items()},
             launches_per_step_all={k: v["launches"] / n_prof for k, v in cls.items()})
     return out
