@@ -131,6 +131,13 @@ int ocl_ncm_predict(const float* feat, int n, int d, const float* means, int n_c
 int ocl_mir_scores(const float* logits_pre, const float* logits_post, const int64_t* y, int n,
                    int c, float* scores_out, void* stream);
 
+/* ---- GSS-Greedy: gradient-direction similarity ------------------------------------------------------
+ * max_i cosine_similarity(mem[i], g) over k stored flat gradient vectors of n floats (utils/buffer/buffer_utils.py:51-56:
+ * x1.x2 / max(|x1||x2|, eps); call sites utils/buffer/gss_greedy_update.py:79,121 `max(cosine_similarity(mem_grads, grad))`).
+ * n % 4 == 0, 16-byte aligned rows.  workspace: ocl_cosine_max_workspace_bytes(k) bytes. out: one float. */
+int64_t ocl_cosine_max_workspace_bytes(int k);
+int ocl_cosine_max(const float* mem, int k, int64_t n, const float* g, float eps, float* out, void* workspace, void* stream);
+
 /* ---- K13: SCR view augmentation --------------------------------------------------------------------
  * stands in for the kornia pipeline of agents/scr.py:18-24 (RandomResizedCrop -> HorizontalFlip ->
  * ColorJitter -> RandomGrayscale); kornia 0.4.1's RNG parameterisation is unpinned, so
@@ -195,6 +202,10 @@ int ocl_net_bind(ocl_net* net, float* params, float* grads, float* running, int6
 #define OCL_FWD_SAVE_TAPE 2u      /* keep activations in `slot` for ocl_net_backward */
 #define OCL_FWD_UPDATE_RUNNING 4u /* momentum-0.1 running-stat update (nn.BatchNorm2d default);
                                      applied once per group, in group order */
+#define OCL_FWD_FROZEN_BN 8u      /* with OCL_FWD_SAVE_TAPE and without OCL_FWD_TRAIN: eval-mode BatchNorm (running statistics) but
+                                     the activations are kept, so that ocl_net_backward gives the gradients of an eval-mode
+                                     forward: model.eval() followed by loss.backward(), utils/buffer/gss_greedy_update.py:16,
+                                     77-79,97-100,116-118 */
 /* x: [n,3,H,W] fp32 NCHW (what the reference's agents hand to model.forward).
  * groups: the batch is `groups` equal consecutive sub-batches that the reference would have run as
  * separate forward calls (SCR's two views, agents/scr.py:55): BatchNorm statistics are per group.

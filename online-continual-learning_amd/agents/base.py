@@ -11,6 +11,7 @@ import numpy as np
 import torch
 
 from .. import ops
+from .. import debug
 from ..loss import SupConLoss, cross_entropy_mean, cross_entropy_segmented_mean
 from ..kd_manager import KdManager
 from ..utils import maybe_cuda, AverageMeter
@@ -84,6 +85,8 @@ class ContinualLearner(torch.nn.Module, metaclass=abc.ABCMeta):
                         else:
                             logits = self.model.forward(batch_x)
                             loss = self.criterion(logits, batch_y)
+                        if debug.on():
+                            debug.emit("review", indices=idx.cpu().numpy().copy(), loss=float(loss.detach()))
                         self.opt.zero_grad()
                         loss.backward()
                         self._step_scaled(0.1)   # grads / 10 (base.py:84-87)
@@ -169,6 +172,7 @@ class ContinualLearner(torch.nn.Module, metaclass=abc.ABCMeta):
                 acc = AverageMeter()
                 correct = []
                 sizes = []
+                seen_idx, seen_pred = [], []
                 for i, (batch_x, batch_y) in enumerate(test_loader):
                     batch_x = maybe_cuda(batch_x, self.cuda)
                     batch_y = maybe_cuda(batch_y, self.cuda)
@@ -181,6 +185,12 @@ class ContinualLearner(torch.nn.Module, metaclass=abc.ABCMeta):
                         _, pred_label = torch.max(logits, 1)
                     correct.append((pred_label == batch_y).sum())
                     sizes.append(batch_y.size(0))
+                    if debug.on():
+                        seen_idx.append(np.asarray(test_loader.last_index_host).copy())
+                        seen_pred.append(pred_label.cpu().numpy())
+                if debug.on():
+                    debug.emit("evaluate", task=task, index=np.concatenate(seen_idx) if seen_idx else np.zeros(0, dtype=np.int64),
+                               pred=np.concatenate(seen_pred) if seen_pred else np.zeros(0, dtype=np.int64))
                 if correct:
                     correct_h = torch.stack(correct).cpu().tolist()   # one sync per task loader
                     for c, n in zip(correct_h, sizes):

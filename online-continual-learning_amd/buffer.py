@@ -3,7 +3,8 @@
 Attributes the plugins rely on: `buffer_img` float32 [mem, C, H, W] and `buffer_label` int64 [mem] (registered module buffers in
 HBM, so `torch.save` keeps working), the fill / stream counters `current_index` and `n_seen_so_far`, `model`, `params`, `cuda`,
 `device`.  `label_host` is a numpy mirror of `buffer_label` that the update plugins keep in step, so class-balanced sampling and
-the class caches never synchronise the device.  update() / retrieve() dispatch to the plugins named by `params.update` /
+the class caches never synchronise the device; `buffer_tracker` (params.buffer_tracker) is the class -> slots index the match
+retrievals read.  update() / retrieve() dispatch to the plugins named by `params.update` /
 `params.retrieve` in `name_match`."""
 import numpy as np
 import torch
@@ -16,8 +17,6 @@ from .utils import maybe_cuda
 class Buffer(torch.nn.Module):
     def __init__(self, model, params):
         super().__init__()
-        if getattr(params, "buffer_tracker", False):
-            raise NotImplementedError("buffer_tracker (match / mem_match retrieval) is outside the HIP hot path")
         self.model, self.params = model, params
         self.cuda = params.cuda
         self.device = "cuda" if params.cuda else "cpu"
@@ -34,6 +33,11 @@ class Buffer(torch.nn.Module):
 
         self.update_method = name_match.update_methods[params.update](params)
         self.retrieve_method = name_match.retrieve_methods[params.retrieve](params)
+
+        if getattr(params, "buffer_tracker", False):   # utils/buffer/buffer.py:33-34
+            from .plugins.buffer_utils import BufferClassTracker
+            from .setup_elements import n_classes
+            self.buffer_tracker = BufferClassTracker(n_classes[params.data], self.device)
 
     def sync_host_labels(self):
         """Re-read the label mirror after something other than the update plugins wrote buffer_label."""

@@ -150,6 +150,8 @@ struct BnFwdArgs {
     int64_t m_per_group;  // pixels per group
     int G, C, relu;
     float momentum, eps;
+    const float* frozen_mean;   // non-null: normalise with these statistics instead of the batch's (eval-mode BatchNorm kept on the
+    const float* frozen_var;    // tape: the forward of model.eval() under autograd, utils/buffer/gss_greedy_update.py:16,77-79)
 };
 int launch_bn_fwd(const BnFwdArgs& a, hipStream_t s);
 
@@ -199,6 +201,7 @@ struct BnBwdArgs {
     unsigned* barrier;    // zeroed by the caller, or null: arrival counter of the one-pass kernel (nsets == 1, G <= 2, see launch_bn_bwd)
     double* fsums;        // one-pass kernel: zeroed accumulators [8 replicas][G][2][C]
     int accumulate;       // dgamma/dbeta += (1) or = (0)
+    int frozen;           // 1: the forward normalised with constant (running) statistics: dy = gamma*invstd*dpre, no mean terms
 };
 int launch_bn_bwd(const BnBwdArgs& a, hipStream_t s);
 void bn_bwd_tune(int block_cap, int unroll, int phase);

@@ -1180,9 +1180,13 @@ __global__ void __launch_bounds__(256) bn_fwd_kernel(const BnFwdArgs a) {
             s1 += a.stats[r * a.stat_rep_stride + ((int64_t)g * 2 + 0) * a.C + c];
             s2 += a.stats[r * a.stat_rep_stride + ((int64_t)g * 2 + 1) * a.C + c];
         }
-        const double mean = s1 / M;
+        double mean = s1 / M;
         double var = s2 / M - mean * mean;
         if (var < 0.0) var = 0.0;
+        if (a.frozen_mean) {   // eval-mode BatchNorm on the tape: the running statistics, folded exactly as bn_fold_kernel does
+            mean = (double)a.frozen_mean[c];
+            var = (double)a.frozen_var[c];
+        }
         const double invstd = 1.0 / sqrt(var + (double)a.eps);
         const float scale = a.gamma[c] * (float)invstd;
         sc[c] = scale;
@@ -1415,8 +1419,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const BnBwdArgs a) {
         const double sdx = a.sums[(((int64_t)k * a.G + g) * 2 + 1) * a.C + c];
         float* s = sm + (size_t)k * 5 * a.C;
         const float istd = a.invstd[k][(int64_t)g * a.C + c];
-        s[c] = (float)(sdy / Md);
-        s[a.C + c] = (float)(sdx / Md);
+        s[c] = a.frozen ? 0.f : (float)(sdy / Md);
+        s[a.C + c] = a.frozen ? 0.f : (float)(sdx / Md);
         s[2 * a.C + c] = a.gamma[k][c] * istd;
         s[3 * a.C + c] = a.mean[k][(int64_t)g * a.C + c];
         s[4 * a.C + c] = istd;
@@ -1615,7 +1619,7 @@ int launch_bn_bwd(const BnBwdArgs& a, hipStream_t s) {
         const char* e = getenv("OCL_BN_FUSED");
         g_bn_fused = e ? atoi(e) : 1;
     }
-    if (g_bn_fused && a.barrier && a.fsums && a.nsets == 1 && a.G <= 2 && a.C <= 160 && g_bn_bwd_phase == 0) {
+    if (g_bn_fused && a.barrier && a.fsums && a.nsets == 1 && a.G <= 2 && a.C <= 160 && g_bn_bwd_phase == 0 && !a.frozen) {
         if (!g_num_cus) {
             int dev = 0;
             hipDeviceProp_t prop;

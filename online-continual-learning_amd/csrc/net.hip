@@ -92,7 +92,7 @@ struct ocl_net {
     int dbg_stop = -1;            // debug: return from backward right after stage (block*10 + step)
     float* dbg_role[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<int> slot_n, slot_groups;
-    std::vector<bool> slot_valid;
+    std::vector<bool> slot_valid, slot_frozen;
     std::map<std::pair<int, int>, PlanSet> plans;
 
     // scratch of the second chain (dual-chain passes, see ocl_net_forward) + its gradient staging array
@@ -364,6 +364,7 @@ static int build_layout(ocl_net* n) {
     n->slot_n.assign(d.n_slots, 0);
     n->slot_groups.assign(d.n_slots, 1);
     n->slot_valid.assign(d.n_slots, false);
+    n->slot_frozen.assign(d.n_slots, false);
     return OCL_OK;
 }
 
@@ -708,7 +709,7 @@ int ocl_net_bind(ocl_net* net, float* params, float* grads, float* running, int6
 // (single chain); a dual-chain pass updates them afterwards, in group order, from both chains' statistics.
 // -----------------------------------------------------------------------------------------------------
 static int trunk_forward_train(ocl_net* n, PlanSet* ps, const float* P, float* S, int img0, int Nc, int G, int g0, int ch, bool upd,
-                               float* feat, hipStream_t st, bool side = false) {
+                               float* feat, hipStream_t st, bool side = false, bool frozen = false) {
     float* pack = (float*)(n->ws + n->off_pack);
     double* stats = n->statsbuf(ch);
     int rc = OCL_OK;
@@ -734,6 +735,10 @@ static int trunk_forward_train(ocl_net* n, PlanSet* ps, const float* P, float* S
         a.m_per_group = (int64_t)(Nc / G) * c.Ho * c.Wo;
         a.G = G; a.C = b.C; a.relu = relu;
         a.momentum = 0.1f; a.eps = 1e-5f;
+        if (frozen) {
+            a.frozen_mean = n->running + b.stat_off;
+            a.frozen_var = n->running + b.stat_off + b.C;
+        }
         return launch_bn_fwd(a, st);
     };
     auto conv_stats = [&](int conv_i, const float* in, hipStream_t st) -> int {
@@ -805,7 +810,10 @@ int ocl_net_forward(ocl_net* n, const float* x, int N, int groups, uint32_t flag
     OCL_REQUIRE(groups >= 1 && groups <= kGmax && N % groups == 0, "net_forward: groups=%d must divide n=%d (<= %d)", groups, N, kGmax);
     OCL_REQUIRE(slot >= 0 && slot < n->d.n_slots, "net_forward: slot %d", slot);
     hipStream_t s = (hipStream_t)stream;
-    const bool train = (flags & OCL_FWD_TRAIN) != 0;
+    const bool frozen = (flags & OCL_FWD_FROZEN_BN) != 0;   // eval-mode BatchNorm, activations kept for ocl_net_backward
+    OCL_REQUIRE(!frozen || ((flags & OCL_FWD_SAVE_TAPE) && !(flags & (OCL_FWD_TRAIN | OCL_FWD_UPDATE_RUNNING)) && groups == 1),
+                "net_forward: OCL_FWD_FROZEN_BN goes with OCL_FWD_SAVE_TAPE only, one group");
+    const bool train = (flags & OCL_FWD_TRAIN) != 0 || frozen;   // frozen: the train-mode kernel sequence with constant statistics
     OCL_REQUIRE(train || groups == 1, "net_forward: groups only apply to train-mode BatchNorm");
     if (!n->descs_uploaded) {
         int rc = upload_descs(n, s);
@@ -818,7 +826,7 @@ int ocl_net_forward(ocl_net* n, const float* x, int N, int groups, uint32_t flag
     // filled by the other's kernels; each chain is a plain sequence, replayed as one hipGraph (graphs with parallel branches
     // leave the fast path on ROCm 7.2, two single-chain graphs on two streams do not).
     const int dm = dual_mode(n);
-    const bool dual = train && groups == 2 && dm != 0 && N / 2 >= kDualMinHalf;
+    const bool dual = train && !frozen && groups == 2 && dm != 0 && N / 2 >= kDualMinHalf;
     PlanSet* ps = nullptr;
     int rc = get_plans(n, dual ? N / 2 : N, (train && !dual) ? groups : 1, &ps);
     if (rc != OCL_OK) return rc;
@@ -861,7 +869,7 @@ int ocl_net_forward(ocl_net* n, const float* x, int N, int groups, uint32_t flag
         static const bool env_noextra = [] { const char* e = getenv("OCL_SIDE_EXTRA"); return e && e[0] == '0'; }();
         const bool side = n->dbg_stop < 0 && N >= kSideExtraMinBatch && !prof_on() && !env_single && !env_noextra;
         if (side && (rc = ensure_side_stream(n))) return rc;
-        if ((rc = trunk_forward_train(n, ps, P, S, 0, N, groups, 0, 0, upd, feat, s, side))) return rc;
+        if ((rc = trunk_forward_train(n, ps, P, S, 0, N, groups, 0, 0, upd && !frozen, feat, s, side, frozen))) return rc;
     } else {
         float* fold = (float*)(n->ws + n->off_fold);
         if ((rc = launch_bn_fold(P, n->running, fold, fold_descs(n), (int)n->bns.size(), 1e-5f, s))) return rc;
@@ -901,6 +909,7 @@ int ocl_net_forward(ocl_net* n, const float* x, int N, int groups, uint32_t flag
     }
     if (train && (flags & OCL_FWD_SAVE_TAPE) && !params_override) {
         n->slot_valid[slot] = true;
+        n->slot_frozen[slot] = frozen;
         n->slot_n[slot] = N;
         n->slot_groups[slot] = groups;
     }
@@ -915,7 +924,8 @@ int ocl_net_forward(ocl_net* n, const float* x, int N, int groups, uint32_t flag
 // (single-chain passes of large batches); null: everything on `s`, in order (dual-chain passes, small batches, measurements).
 // -----------------------------------------------------------------------------------------------------
 static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, float* S, int img0, int Nc, int G, int g0, int ch,
-                          int accumulate, const float* dfeat, hipStream_t s, hipStream_t side, bool ch_shared = false) {
+                          int accumulate, const float* dfeat, hipStream_t s, hipStream_t side, bool ch_shared = false,
+                          bool frozen = false) {
     float* pack = (float*)(n->ws + n->off_pack);
     float* partial = n->partialbuf(ch);
     double* bsums = n->bsumsbuf(ch);
@@ -990,6 +1000,7 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
             return OCL_ERR_ARG;
         }
         a.accumulate = accumulate;
+        a.frozen = frozen ? 1 : 0;
         return launch_bn_bwd(a, s);
     };
     auto wgrad = [&](int conv_i, const float* xin, const float* dy) -> int {   // on the weight-gradient stream
@@ -1086,7 +1097,8 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
     hipStream_t s = (hipStream_t)stream;
     const int N = n->slot_n[slot], G = n->slot_groups[slot];
     const int dm = dual_mode(n);
-    const bool dual = G == 2 && dm != 0 && N / 2 >= kDualMinHalf;
+    const bool frozen = n->slot_frozen[slot];
+    const bool dual = G == 2 && dm != 0 && N / 2 >= kDualMinHalf && !frozen;
     PlanSet* ps = nullptr;
     int rc = get_plans(n, dual ? N / 2 : N, dual ? 1 : G, &ps);
     if (rc != OCL_OK) return rc;
@@ -1175,7 +1187,7 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
         OCL_HIP(hipStreamWaitEvent(s, n->ev_join, 0));
         return launch_add_inplace(Gr, G2, n->trunk_params, s);
     }
-    return trunk_backward(n, ps, P, Gr, S, 0, N, G, 0, 0, accumulate, dfeat, s, two_streams ? n->s2 : nullptr);
+    return trunk_backward(n, ps, P, Gr, S, 0, N, G, 0, 0, accumulate, dfeat, s, two_streams ? n->s2 : nullptr, false, frozen);
 }
 
 int ocl_net_graph_enable(ocl_net* n, int mode) {

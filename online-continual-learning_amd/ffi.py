@@ -46,6 +46,8 @@ SIGNATURES = {
     "ocl_ncm_class_means": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, vp, vp]),
     "ocl_ncm_predict": (C.c_int, [vp, C.c_int, C.c_int, vp, C.c_int, vp, vp]),
     "ocl_mir_scores": (C.c_int, [vp, vp, vp, C.c_int, C.c_int, vp, vp]),
+    "ocl_cosine_max_workspace_bytes": (i64, [C.c_int]),
+    "ocl_cosine_max": (C.c_int, [vp, C.c_int, i64, vp, f32, vp, vp, vp]),
     "ocl_scr_augment": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     "ocl_gemm_small": (C.c_int, [vp, i64, i64, vp, i64, i64, vp, i64, C.c_int, C.c_int, C.c_int, vp,
                                  C.c_int, C.c_int, vp]),
@@ -74,7 +76,7 @@ SIGNATURES = {
     "ocl_prof_query": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(i64)]),
 }
 
-FWD_TRAIN, FWD_SAVE_TAPE, FWD_UPDATE_RUNNING = 1, 2, 4
+FWD_TRAIN, FWD_SAVE_TAPE, FWD_UPDATE_RUNNING, FWD_FROZEN_BN = 1, 2, 4, 8
 
 
 def lib():

@@ -35,9 +35,12 @@ retrieve_methods = _Lazy({
     'MIR': ('.plugins.mir_retrieve', 'MIR_retrieve'),
     'random': ('.plugins.random_retrieve', 'Random_retrieve'),
     'ASER': ('.plugins.aser_retrieve', 'ASER_retrieve'),
+    'match': ('.plugins.sc_retrieve', 'Match_retrieve'),
+    'mem_match': ('.plugins.mem_match', 'MemMatch_retrieve'),
 })
 
 update_methods = _Lazy({
     'random': ('.plugins.reservoir_update', 'Reservoir_update'),
+    'GSS': ('.plugins.gss_greedy_update', 'GSSGreedyUpdate'),
     'ASER': ('.plugins.aser_update', 'ASER_update'),
 })

@@ -238,6 +238,21 @@ def argsort_desc(v):
     return out
 
 
+def cosine_max(mem_grads, grad, out=None, eps=1e-8):
+    """max_i cosine_similarity(mem_grads[i], grad) (utils/buffer/buffer_utils.py:51-56, gss_greedy_update.py:79,121) -> [1]."""
+    ffi.init()
+    mem_grads, grad = _f32(mem_grads), _f32(grad)
+    k, n = mem_grads.shape
+    if grad.numel() != n:
+        raise RuntimeError("cosine_max: %d-vector against rows of %d" % (grad.numel(), n))
+    if out is None:
+        out = torch.empty(1, dtype=torch.float32, device=grad.device)
+    ws = torch.empty(ffi.lib().ocl_cosine_max_workspace_bytes(k), dtype=torch.uint8, device=grad.device)
+    ffi.check(ffi.lib().ocl_cosine_max(ffi.ptr(mem_grads), k, n, ffi.ptr(grad), float(eps), ffi.ptr(out), ffi.ptr(ws), ffi.stream()),
+              "cosine_max")
+    return out
+
+
 # ---- K11 ---------------------------------------------------------------------------------------------
 def ncm_class_means(feat, labels, class_ids):
     ffi.init()

@@ -39,6 +39,36 @@ def random_retrieve(buffer, num_retrieve, excl_indices=None, return_indices=Fals
         return x, y
 
 
+def match_retrieve(buffer, cur_y, exclud_idx=None):
+    """buffer_utils.py:29-49: for every item of the batch one buffered sample of the same class, drawn per class with Python's
+    global `random.sample` from the tracker's slot set (CPython set order is part of the behaviour); two empty tensors when some
+    class of the batch has too few slots.  Labels come from the numpy mirror the loader attaches (`cur_y.host`)."""
+    import random
+    from collections import Counter
+    ys = _host_labels(cur_y, getattr(cur_y, "host", None)).tolist()
+    per_class = Counter(ys)
+    positions = defaultdict(list)
+    for pos, label in enumerate(ys):
+        positions[label].append(pos)
+    chosen = [None] * len(ys)
+    for label in per_class:
+        slots = buffer.buffer_tracker.class_index_cache[label]
+        if exclud_idx is not None:
+            slots = slots - set(exclud_idx.tolist())
+        if not slots or len(slots) < per_class[label]:
+            print('match retrieve attempt fail')
+            return torch.tensor([]), torch.tensor([])
+        for pos, slot in zip(positions[label], random.sample(list(slots), per_class[label])):
+            chosen[pos] = slot
+    indices = torch.tensor(chosen)
+    debug.emit("match_retrieve", indices=indices.numpy().copy())
+    idx_dev = ops.upload(indices, buffer.buffer_img.device)
+    x = ops.gather_rows(buffer.buffer_img, idx_dev)
+    y = ops.gather_rows(buffer.buffer_label, idx_dev)
+    y.host = buffer.label_host[indices.numpy()]
+    return x, y
+
+
 def get_grad_vector(model):
     """buffer_utils.py:58-71: the flat gradient vector (zeros where a parameter has no gradient).  The engine's
     flat gradient array already has that layout; before any backward it is logically zero."""
@@ -112,3 +142,25 @@ class ClassBalancedRandomSampling:
             for i, c in enumerate(buffer_y_host):
                 cls_ind_cache[int(c)].add(i)
             cls.class_index_cache = cls_ind_cache
+
+
+class BufferClassTracker(object):
+    """buffer_utils.py:163-203: per-buffer class -> set-of-slots index and per-class counts, maintained by the reservoir update
+    (utils/buffer/reservoir_update.py:25-26,56-57) and read by match_retrieve.  `buffer_y` is the numpy label mirror."""
+
+    def __init__(self, num_class, device="cpu"):
+        self.class_index_cache = defaultdict(set)
+        self.class_num_cache = np.zeros(num_class)
+
+    def update_cache(self, buffer_y, new_y=None, ind=None):
+        for slot, new_label in zip(ind, new_y):
+            slot, new_label, old_label = int(slot), int(new_label), int(buffer_y[slot])
+            if old_label in self.class_index_cache and slot in self.class_index_cache[old_label]:
+                self.class_index_cache[old_label].remove(slot)
+                self.class_num_cache[old_label] -= 1
+            self.class_index_cache[new_label].add(slot)
+            self.class_num_cache[new_label] += 1
+
+    def check_tracker(self):
+        print(self.class_num_cache.sum())
+        print(len([k for i in self.class_index_cache.values() for k in i]))

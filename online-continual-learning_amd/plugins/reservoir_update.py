@@ -40,6 +40,9 @@ class Reservoir_update:
             taken = min(free, n_items)
             slots = self._fill(buffer, x, y, y_host, taken)
             if taken == n_items:
+                # the reference refreshes the tracker only when the whole batch fitted (:22-27; its TODO at :30 notes the gap)
+                if getattr(buffer.params, "buffer_tracker", False):
+                    buffer.buffer_tracker.update_cache(buffer.label_host, y_host[:taken], slots)
                 debug.emit("reservoir", slots=list(slots))
                 return slots
         # the part of the batch that did not fit (all of it once the memory is full)
@@ -58,6 +61,8 @@ class Reservoir_update:
             winner[slot] = item
         slots, items = list(winner.keys()), list(winner.values())
 
+        if getattr(buffer.params, "buffer_tracker", False):   # before the overwrite: the tracker reads the labels being replaced (:55-57)
+            buffer.buffer_tracker.update_cache(buffer.label_host, y_host[np.asarray(items, dtype=np.int64)], slots)
         dev = buffer.buffer_img.device
         slots_dev = ops.upload(torch.tensor(slots, dtype=torch.long), dev)
         items_dev = ops.upload(torch.tensor(items, dtype=torch.long), dev)

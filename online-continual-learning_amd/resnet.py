@@ -44,15 +44,15 @@ class _NetFunction(torch.autograd.Function):
     flat gradient buffer (overwrite or accumulate, as loss.backward() would) and returns no tensors for them."""
 
     @staticmethod
-    def forward(ctx, x, anchor, owner, groups):
-        out, slot, gen = owner._engine_train_forward(x, groups, save=True)
+    def forward(ctx, x, anchor, owner, groups, frozen=False):
+        out, slot, gen = owner._engine_train_forward(x, groups, save=True, frozen=frozen)
         ctx.owner, ctx.slot, ctx.gen = owner, slot, gen
         return out
 
     @staticmethod
     def backward(ctx, dout):
         ctx.owner._engine_backward(ctx.slot, ctx.gen, dout)
-        return None, None, None, None
+        return None, None, None, None, None
 
 
 class _EngineMixin:
@@ -109,6 +109,7 @@ class _EngineMixin:
         ffi.check(L.ocl_net_create(C.byref(desc), C.byref(h)), "net_create")
         self._net = h
         self._desc = desc
+        self._n_tapes = desc.n_slots - 1   # the engine's last slot is the scratch slot of forwards that keep no tape
         n_params = L.ocl_net_param_count(h)
         # --- flat parameters / gradients: re-point every nn.Parameter into the flat arrays
         named = dict(self.named_parameters())
@@ -207,17 +208,26 @@ class _EngineMixin:
             raise RuntimeError("batch %d exceeds the engine's max_batch %d" % (x.shape[0], self._desc.max_batch))
         return x.contiguous()
 
-    def _engine_train_forward(self, x, groups, save, params_override=None, update_running=True, want_feat=False):
+    def _tape_slot(self):
+        """Next activation tape (round robin over the model's n_slots); a generation counter detects overwritten tapes."""
+        slot = self._slot_rr
+        self._slot_rr = (self._slot_rr + 1) % self._n_tapes
+        gen = self._slot_gen.get(slot, 0) + 1
+        self._slot_gen[slot] = gen
+        return slot, gen
+
+    def _engine_train_forward(self, x, groups, save, params_override=None, update_running=True, want_feat=False, frozen=False):
         self._ensure_bound()
         x = self._check_input(x)
         n = x.shape[0]
-        slot = self._slot_rr
-        self._slot_rr = (self._slot_rr + 1) % self._desc.n_slots
-        gen = self._slot_gen.get(slot, 0) + 1
-        self._slot_gen[slot] = gen
+        # forwards that keep no tape (MIR's scoring passes, the KD teacher, no_grad passes) run in a scratch slot of their own, so
+        # that any number of them may sit between a taped forward and its backward
+        slot, gen = self._tape_slot() if save else (self._n_tapes, 0)
         out = torch.empty((n, self.out_dim), dtype=torch.float32, device=x.device)
         feat = torch.empty((n, self.feature_dim), dtype=torch.float32, device=x.device) if want_feat else None
         flags = ffi.FWD_TRAIN | (ffi.FWD_SAVE_TAPE if save else 0) | (ffi.FWD_UPDATE_RUNNING if update_running else 0)
+        if frozen:   # model.eval() under autograd: running statistics, activations kept for backward
+            flags = ffi.FWD_SAVE_TAPE | ffi.FWD_FROZEN_BN
         ffi.check(ffi.lib().ocl_net_forward(self._net, ffi.ptr(x), n, groups, flags, ffi.ptr(params_override), ffi.ptr(feat),
                                             ffi.ptr(out), slot, ffi.stream()), "net_forward(train)")
         if want_feat:
@@ -230,17 +240,14 @@ class _EngineMixin:
         n = x.shape[0]
         out = torch.empty((n, self.out_dim), dtype=torch.float32, device=x.device) if want_out else None
         feat = torch.empty((n, self.feature_dim), dtype=torch.float32, device=x.device) if want_feat else None
-        slot = self._slot_rr  # eval forwards only borrow the slot's input staging area; keep live tapes intact
-        self._slot_rr = (self._slot_rr + 1) % self._desc.n_slots
-        self._slot_gen[slot] = self._slot_gen.get(slot, 0) + 1
         ffi.check(ffi.lib().ocl_net_forward(self._net, ffi.ptr(x), n, 1, 0, ffi.ptr(params_override), ffi.ptr(feat), ffi.ptr(out),
-                                            slot, ffi.stream()), "net_forward(eval)")
+                                            self._n_tapes, ffi.stream()), "net_forward(eval)")
         return out, feat
 
     def _engine_backward(self, slot, gen, dout):
         if self._slot_gen.get(slot) != gen:
             raise RuntimeError("backward through a forward whose activations were overwritten: more than %d forward "
-                               "passes are alive at once (raise model.n_slots before first use)" % self._desc.n_slots)
+                               "passes are alive at once (raise model.n_slots before first use)" % self._n_tapes)
         fresh = self._attach_grads()
         dout = dout.contiguous()
         if dout.dtype != torch.float32:
@@ -256,6 +263,10 @@ class _EngineMixin:
                 return _NetFunction.apply(x, self._anchor, self, groups)
             out, _, _ = self._engine_train_forward(x, groups, save=False)
             return out
+        if torch.is_grad_enabled() and groups == 1:
+            # eval mode under autograd (utils/buffer/gss_greedy_update.py:16,77-79): BatchNorm uses its running statistics and the
+            # pass is differentiable w.r.t. every parameter
+            return _NetFunction.apply(x, self._anchor, self, 1, True)
         out, _ = self._engine_eval_forward(x, want_out=True)
         return out
 
@@ -326,7 +337,7 @@ class ResNet(nn.Module, _EngineMixin):
     def _engine_desc(self):
         h, w = self.in_hw
         mb = self.max_batch or (512 if h * w <= 32 * 32 else 256)
-        return ffi.NetDesc(h, w, self.nf, self.linear.out_features, 0, 0, mb, self.n_slots)
+        return ffi.NetDesc(h, w, self.nf, self.linear.out_features, 0, 0, mb, self.n_slots + 1)   # + the scratch slot
 
     def features(self, x):
         '''Features before FC layers'''
@@ -368,7 +379,7 @@ class SupConResNet(nn.Module, _EngineMixin):
         h, w = self.encoder.in_hw
         kind = {'mlp': 1, 'linear': 2, 'None': 3}[self.head_kind]
         mb = self.max_batch or (512 if h * w <= 32 * 32 else 256)
-        return ffi.NetDesc(h, w, self.encoder.nf, 100, kind, self.feat_dim, mb, self.n_slots)
+        return ffi.NetDesc(h, w, self.encoder.nf, 100, kind, self.feat_dim, mb, self.n_slots + 1)   # + the scratch slot
 
     def forward(self, x):
         return self._forward_out(x)

@@ -329,8 +329,9 @@ def random_retrieve_indices(buf, num, excl=None):
     return np.random.choice(valid, num, replace=False).astype(np.int64)
 
 
-def reservoir_update(buf, x, y):
-    """utils/buffer/reservoir_update.py:8-61 (torch CPU RNG).  Returns the list of written slots."""
+def reservoir_update(buf, x, y, tracker=None):
+    """utils/buffer/reservoir_update.py:8-61 (torch CPU RNG).  Returns the list of written slots.  tracker: the
+    BufferClassTracker hooks of :25-26 (after the fill, only when the whole batch fitted) and :56-57 (before the overwrite)."""
     n = x.shape[0]
     room = max(0, buf.mem_size - buf.current_index)
     if room:
@@ -340,7 +341,10 @@ def reservoir_update(buf, x, y):
         buf.current_index += take
         buf.n_seen_so_far += take
         if take == n:
-            return list(range(buf.current_index - take, buf.current_index))
+            filled = list(range(buf.current_index - take, buf.current_index))
+            if tracker is not None:
+                tracker.update(buf.label, y[:take], filled)
+            return filled
     x, y = x[room:], y[room:]
     draw = torch.FloatTensor(x.shape[0]).uniform_(0, buf.n_seen_so_far).long()
     keep = (draw < buf.mem_size).nonzero().squeeze(-1)
@@ -352,9 +356,52 @@ def reservoir_update(buf, x, y):
     for s, src in zip(slots.tolist(), keep.tolist()):
         last_writer[s] = src
     ks, vs = list(last_writer.keys()), list(last_writer.values())
+    if tracker is not None:
+        tracker.update(buf.label, y[vs], ks)
     buf.img[ks] = x[vs]
     buf.label[ks] = y[vs]
     return ks
+
+
+class ClassTracker(object):
+    """utils/buffer/buffer_utils.py:163-203 (BufferClassTracker): class -> set of slots, class counts (numpy float)."""
+
+    def __init__(self, num_class):
+        self.index = defaultdict(set)
+        self.count = np.zeros(num_class)
+
+    def update(self, labels, new_y, ind):
+        orig = labels[ind]
+        for i, ny, oy in zip(ind, new_y, orig):
+            oy, ny = oy.item(), ny.item()
+            if oy in self.index and i in self.index[oy]:
+                self.index[oy].remove(i)
+                self.count[oy] -= 1
+            self.index[ny].add(i)
+            self.count[ny] += 1
+
+
+def match_retrieve_indices(tracker, cur_y, exclude=None):
+    """utils/buffer/buffer_utils.py:29-49 (match_retrieve): one buffered sample of the same class per item of the batch, drawn
+    with Python's `random.sample` from the class's slot set (CPython set order); empty when a class is short."""
+    import random
+    from collections import Counter
+    ys = cur_y.tolist()
+    counter = Counter(ys)
+    where = defaultdict(list)
+    for pos, val in enumerate(ys):
+        where[val].append(pos)
+    select = [None] * len(ys)
+    for c in counter:
+        members = tracker.index[c]
+        if exclude is not None:
+            members = members - set(exclude.tolist())
+        if not members or len(members) < counter[c]:
+            return np.zeros(0, dtype=np.int64)
+        got = random.sample(list(members), counter[c])
+        for pos, val in zip(where[c], got):
+            select[pos] = val
+    return np.asarray(select, dtype=np.int64)
 
 
 class ClassCache(object):
@@ -505,10 +552,19 @@ def identity_aug(x):
     return x
 
 
-def scr_step(state, names, buf, batch_x, batch_y, params, aug=identity_aug):
+def _retrieve_indices(buf, params, retrieve, batch_y, tracker, warmup):
+    """random (utils/buffer/random_retrieve.py:3-9) or match (utils/buffer/sc_retrieve.py:4-15) retrieval -> buffer slots."""
+    if retrieve == "match":
+        if buf.n_seen_so_far > params["eps_mem_batch"] * warmup:
+            return match_retrieve_indices(tracker, batch_y)
+        return np.zeros(0, dtype=np.int64)
+    return random_retrieve_indices(buf, params["eps_mem_batch"])
+
+
+def scr_step(state, names, buf, batch_x, batch_y, params, aug=identity_aug, retrieve="random", tracker=None, warmup=4):
     """agents/scr.py:40-63 for ONE iteration. Returns (loss or None, retrieved indices, written slots)."""
     net = OracleNet(state, head=params.get("head", "mlp"), training=True)
-    idx = random_retrieve_indices(buf, params["eps_mem_batch"])
+    idx = _retrieve_indices(buf, params, retrieve, batch_y, tracker, warmup)
     loss = None
     if idx.shape[0] > 0:
         mem_x, mem_y = buf.img[idx], buf.label[idx]
@@ -519,12 +575,12 @@ def scr_step(state, names, buf, batch_x, batch_y, params, aug=identity_aug):
         zero_grad(state, names)
         loss.backward()
         sgd_step(state, names, params["lr"])
-    slots = reservoir_update(buf, batch_x, batch_y)
+    slots = reservoir_update(buf, batch_x, batch_y, tracker=tracker)
     return (None if loss is None else float(loss.detach())), idx, slots
 
 
-def er_step(state, names, buf, batch_x, batch_y, params, retrieve="random"):
-    """agents/exp_replay.py:34-92 for ONE iteration with random or MIR retrieval and reservoir update."""
+def er_step(state, names, buf, batch_x, batch_y, params, retrieve="random", gss=None, tracker=None, warmup=4):
+    """agents/exp_replay.py:34-92 for ONE iteration with random / MIR / match retrieval and reservoir or GSS update."""
     net = OracleNet(state, head=None, training=True)
     logits = net.forward(batch_x)
     loss = ce_mean(logits, batch_y)
@@ -557,7 +613,7 @@ def er_step(state, names, buf, batch_x, batch_y, params, retrieve="random"):
         else:
             idx = sub
     else:
-        idx = random_retrieve_indices(buf, params["eps_mem_batch"])
+        idx = _retrieve_indices(buf, params, retrieve, batch_y, tracker, warmup)
     info["idx"] = idx
     if idx.shape[0] > 0:
         mem_logits = net.forward(buf.img[idx])
@@ -565,7 +621,10 @@ def er_step(state, names, buf, batch_x, batch_y, params, retrieve="random"):
         loss_mem.backward()
         info["loss_mem"] = float(loss_mem.detach())
     sgd_step(state, names, params["lr"])
-    info["slots"] = reservoir_update(buf, batch_x, batch_y)
+    if gss is not None:
+        info["gss"] = gss_update(gss, state, names, buf, batch_x, batch_y)
+    else:
+        info["slots"] = reservoir_update(buf, batch_x, batch_y, tracker=tracker)
     return info
 
 
@@ -591,6 +650,145 @@ def aser_er_step(state, names, buf, cache, batch_x, batch_y, params):
     sgd_step(state, names, params["lr"])
     info["loss"] = float(lc.detach())
     info["upd"] = aser_update(net, buf, cache, batch_x, batch_y, params)
+    return info
+
+
+def mir_scores_for_gradient(state, names, grad_vector, sub_x, sub_y, lr):
+    """utils/buffer/mir_retrieve.py:19-28 for a GIVEN gradient vector: per-sample CE at theta - lr*g minus per-sample CE at theta,
+    both forwards in train mode under no_grad on copies of `state` (the deepcopy's BatchNorm buffers, :35)."""
+    pre_state = OrderedDict((k, v.detach().clone()) for k, v in state.items())
+    virt = OrderedDict()
+    o = 0
+    for k, v in state.items():
+        if k in names:
+            n_el = v.numel()
+            virt[k] = v.detach() - lr * grad_vector[o:o + n_el].view_as(v)
+            o += n_el
+        else:
+            virt[k] = v.detach().clone()
+    with torch.no_grad():
+        pre = OracleNet(pre_state, head=None, training=True).forward(sub_x)
+        post = OracleNet(virt, head=None, training=True).forward(sub_x)
+        return mir_scores(pre, post, sub_y).numpy()
+
+
+def review_epoch(state, names, buf, params, agent, aug=identity_aug):
+    """agents/base.py:62-88 (review trick, run by after_train): one epoch over the filled part of the buffer in shuffled
+    mini-batches of eps_mem_batch (drop_last), each step with the gradients divided by 10.  For SCR the reference runs one plain
+    forward first (:77; only its BatchNorm running-statistic update survives) and then the two view forwards (:78-80).
+    Returns the per-batch (indices, loss)."""
+    n = buf.current_index
+    out = []
+    if n == 0:
+        return out
+    head = params.get("head") if agent == "SCR" else None
+    net = OracleNet(state, head=head, training=True)
+    loader = torch.utils.data.DataLoader(_Idx(n), batch_size=params["eps_mem_batch"], shuffle=True, num_workers=0, drop_last=True)
+    for idx in loader:
+        bx, by = buf.img[idx], buf.label[idx]
+        logits = net.forward(bx)
+        if agent == "SCR":
+            feats = torch.cat([net.forward(bx).unsqueeze(1), net.forward(aug(bx)).unsqueeze(1)], dim=1)
+            loss = supcon_loss(feats, by, params["temp"])
+        else:
+            loss = ce_mean(logits, by)
+        zero_grad(state, names)
+        loss.backward()
+        with torch.no_grad():
+            for k in names:
+                if state[k].grad is not None:
+                    state[k].grad.copy_(state[k].grad.clone() / 10.)
+        sgd_step(state, names, params["lr"])
+        out.append((idx.numpy().copy(), float(loss.detach())))
+    return out
+
+
+# ======================================================================================================
+# GSS-Greedy update — utils/buffer/gss_greedy_update.py:6-122
+# ======================================================================================================
+
+
+class GssState(object):
+    """:7-13: gss_mem_strength gradient vectors of gss_batch_size samples each, one score per slot."""
+
+    def __init__(self, cfg):
+        self.mem_strength = cfg.get("gss_mem_strength", 10)
+        self.batch_size = cfg.get("gss_batch_size", 10)
+        self.score = torch.zeros(cfg["mem_size"])
+
+
+def cosine_similarity(x1, x2, eps=1e-8):
+    """utils/buffer/buffer_utils.py:51-56."""
+    w1 = x1.norm(p=2, dim=1, keepdim=True)
+    w2 = x2.norm(p=2, dim=1, keepdim=True)
+    return torch.mm(x1, x2.t()) / (w1 * w2.t()).clamp(min=eps)
+
+
+def eval_mode_grad(state, names, x, y):
+    """Flat gradient of the mean CE of an EVAL-mode forward (the plugin calls model.eval() first, :16): BatchNorm is the affine
+    map of its running statistics.  get_grad_vector layout (buffer_utils.py:58-71)."""
+    net = OracleNet(state, head=None, training=False)
+    zero_grad(state, names)
+    F.cross_entropy(net.forward(x), y).backward()
+    return flat_grad(state, names).detach().clone()
+
+
+def gss_rand_mem_grads(gss, state, names, buf):
+    """:82-104."""
+    bs = min(gss.batch_size, buf.current_index)
+    n_sub = min(gss.mem_strength, buf.current_index // bs)
+    perm = torch.randperm(buf.current_index)
+    rows = []
+    for i in range(n_sub):
+        idx = perm[i * bs:i * bs + bs]
+        rows.append(eval_mode_grad(state, names, buf.img[idx], buf.label[idx]))
+    return torch.stack(rows)
+
+
+def gss_each_sample_sim(state, names, mem_grads, x, y):
+    """:106-122."""
+    out = torch.zeros(x.shape[0])
+    for i in range(x.shape[0]):
+        g = eval_mode_grad(state, names, x[i:i + 1], y[i:i + 1]).unsqueeze(0)
+        out[i] = max(cosine_similarity(mem_grads, g))
+    return out
+
+
+def gss_update(gss, state, names, buf, x, y):
+    """:15-64.  Returns a record of what happened (for the parity tests)."""
+    info = {}
+    room = buf.mem_size - buf.current_index
+    if room <= 0:
+        mem_grads = gss_rand_mem_grads(gss, state, names, buf)
+        batch_grad = eval_mode_grad(state, names, x, y).unsqueeze(0)
+        batch_sim = max(cosine_similarity(mem_grads, batch_grad))
+        info["batch_sim"] = float(batch_sim)
+        if batch_sim < 0:
+            score = gss.score[:buf.current_index]
+            sim = (score - torch.min(score)) / ((torch.max(score) - torch.min(score)) + 0.01)
+            index = torch.multinomial(sim, x.shape[0], replacement=False)
+            item_sim = gss_each_sample_sim(state, names, mem_grads, x, y)
+            scaled = ((item_sim + 1) / 2).unsqueeze(1)
+            repl = ((gss.score[index] + 1) / 2).unsqueeze(1)
+            outcome = torch.multinomial(torch.cat((scaled, repl), dim=1), 1, replacement=False)
+            sub = outcome.squeeze(1).bool()
+            buf.img[index[sub]] = x[sub].clone()
+            buf.label[index[sub]] = y[sub].clone()
+            gss.score[index[sub]] = item_sim[sub].clone()
+            info.update(index=index.numpy().copy(), item_sim=item_sim.numpy().copy(), sub=sub.numpy().copy())
+    else:
+        take = min(room, x.shape[0])
+        x, y = x[:take], y[:take]
+        if buf.current_index == 0:
+            cos = torch.zeros(x.shape[0]) + 0.1
+        else:
+            mem_grads = gss_rand_mem_grads(gss, state, names, buf)
+            cos = gss_each_sample_sim(state, names, mem_grads, x, y)
+        buf.img[buf.current_index:buf.current_index + take] = x
+        buf.label[buf.current_index:buf.current_index + take] = y
+        gss.score[buf.current_index:buf.current_index + take] = cos
+        buf.current_index += take
+        info.update(fill=take, item_sim=cos.numpy().copy())
     return info
 
 
@@ -667,7 +865,8 @@ def to_tensor(x_u8):
 
 class OracleAgent(object):
     """ONE run of agents/exp_replay.py / agents/scr.py + agents/base.py on CPU, built from the step functions above.
-    `cfg` is an oracle.synth.STEP_CASES-style dict."""
+    `cfg` is an oracle.synth.STEP_CASES-style dict; cfg["trick"] may switch on review_trick / ncm_trick (agents/base.py:62-88,
+    :121)."""
 
     def __init__(self, cfg, aug=identity_aug):
         self.cfg = dict(cfg)
@@ -683,10 +882,14 @@ class OracleAgent(object):
         self.p = dict(eps_mem_batch=cfg["eps_mem_batch"], temp=cfg.get("temp", 0.07), lr=cfg.get("lr", 0.1), head=self.head,
                       subsample=cfg.get("subsample", 50), k=cfg.get("k", 3), n_smp_cls=cfg.get("n_smp_cls", 1.5),
                       aser_type=cfg.get("aser_type", "asvm"), mem_size=cfg["mem_size"], n_classes=self.n_classes)
+        self.trick = dict(cfg.get("trick", {}))
         self.old_labels = []
         self.aug = aug
         self.batch = cfg.get("batch", 10)
         self.log = []
+        self.review_log = []
+        self.gss = GssState(cfg) if cfg.get("update") == "GSS" else None
+        self.tracker = ClassTracker(self.n_classes) if cfg.get("buffer_tracker") else None
 
     def train_learner(self, x_u8, y):
         new = list(set(y.tolist()))                                            # base.py:43-44
@@ -696,20 +899,34 @@ class OracleAgent(object):
         for idx in loader:
             bx, by = xs[idx], ys[idx]
             if self.agent == "SCR":
-                self.log.append(scr_step(self.state, self.names, self.buf, bx, by, self.p, self.aug))
+                self.log.append(scr_step(self.state, self.names, self.buf, bx, by, self.p, self.aug, retrieve=self.cfg.get("retrieve", "random"),
+                                         tracker=self.tracker, warmup=self.cfg.get("warmup", 4)))
             elif self.cfg["retrieve"] == "ASER" or self.cfg["update"] == "ASER":
                 self.log.append(aser_er_step(self.state, self.names, self.buf, self.cache, bx, by, self.p))
             else:
-                self.log.append(er_step(self.state, self.names, self.buf, bx, by, self.p, self.cfg["retrieve"]))
-        self.old_labels += new                                                 # base.py:58
+                self.log.append(er_step(self.state, self.names, self.buf, bx, by, self.p, self.cfg["retrieve"], gss=self.gss,
+                                        tracker=self.tracker, warmup=self.cfg.get("warmup", 4)))
+        self.after_train(new)
 
-    def evaluate(self, tests, test_batch=128):
-        """base.py:118-227 (NCM for SCR, argmax otherwise); test loaders shuffle (2 RNG draws each)."""
+    def after_train(self, new):
+        """base.py:56-91: label bookkeeping, then (review trick) one epoch over the buffer at batch eps_mem_batch with the
+        gradients divided by 10."""
+        self.old_labels += new                                                 # base.py:58
+        if self.trick.get("review_trick"):
+            self.review_log.append(review_epoch(self.state, self.names, self.buf, self.p, self.agent, self.aug))
+
+    def evaluate(self, tests, test_batch=128, detail=None):
+        """base.py:118-227 (NCM for SCR / ncm_trick, argmax otherwise); test loaders shuffle (2 RNG draws each).  `detail`
+        (a list) receives per task a dict(index=sample order, pred=predicted labels[, dist=NCM distance matrix])."""
         net = OracleNet(self.state, head=self.head, training=False)
         acc = np.zeros(len(tests))
+        ncm = self.agent == "SCR" or self.trick.get("ncm_trick", False)
         with torch.no_grad():
-            if self.agent == "SCR":
+            if ncm:
                 n = self.buf.current_index
+                for c in self.buf.label[:n].tolist():
+                    if c not in self.old_labels:
+                        raise KeyError(c)                                      # cls_exemplar[y.item()], base.py:126
                 feats = deep_features(net, self.buf.img[:n]) if n else torch.zeros(0, 160)
                 means = ncm_means(feats, self.buf.label[:n], self.old_labels)
                 for i in range(len(self.old_labels)):
@@ -720,16 +937,25 @@ class OracleAgent(object):
                 xs, ys = to_tensor(x_u8), torch.from_numpy(np.asarray(y)).long()
                 loader = torch.utils.data.DataLoader(_Idx(len(ys)), batch_size=test_batch, shuffle=True)
                 tot, cnt = 0.0, 0
+                rec = dict(index=[], pred=[], dist=[])
                 for idx in loader:
                     bx, by = xs[idx], ys[idx]
-                    if self.agent == "SCR":
-                        pred = torch.tensor(self.old_labels)[ncm_predict(net.features(bx), means)]
+                    if ncm:
+                        f = net.features(bx)
+                        f = f / f.norm(dim=1, keepdim=True)
+                        d = ((f[:, None, :] - means[None, :, :]) ** 2).sum(-1)
+                        pred = torch.tensor(self.old_labels)[d.min(1)[1]]
+                        rec["dist"].append(d.numpy())
                     else:
                         pred = net.forward(bx).max(1)[1]
+                    rec["index"].append(idx.numpy())
+                    rec["pred"].append(pred.numpy())
                     c = (pred == by).sum().item() / by.size(0)
                     tot += c * by.size(0)
                     cnt += by.size(0)
                 acc[t] = float(tot) / cnt
+                if detail is not None:
+                    detail.append({k: np.concatenate(v) for k, v in rec.items() if v})
         return acc
 
     def state_dict(self):

@@ -28,14 +28,37 @@ STEP_CASES = {
     # ER --retrieve MIR at 32x32, two tasks (seed chosen tie-free: saturated logits give exactly-zero scores otherwise)
     "mir_c10": dict(agent="ER", retrieve="MIR", update="random", data="cifar10", mem_size=40, eps_mem_batch=10, seed=4,
                     tasks=[[0, 1, 2, 3, 4], [5, 6, 7, 8, 9]], n_train=10, n_test=8, subsample=20),
+    # review trick (agents/base.py:62-88): one pass over the buffer after every task with gradients / 10; ER with the NCM classifier
+    # (ncm_trick) so that evaluate()'s exemplar-mean branch is pinned for a plain ResNet as well
+    "er_review": dict(agent="ER", retrieve="random", update="random", data="cifar10", mem_size=50, eps_mem_batch=10, seed=6,
+                      tasks=[[0, 1], [2, 3]], n_train=30, n_test=20, trick=dict(review_trick=True, ncm_trick=True)),
+    # SCR + review trick (the paper's SCR setting, config_CVPR/agent/scr/scr_5k.yml:9-10: temp 0.1 + review_trick)
+    "scr_review": dict(agent="SCR", retrieve="random", update="random", data="cifar100", mem_size=60, eps_mem_batch=20, seed=7,
+                       tasks=[[3, 17], [40, 41]], n_train=25, n_test=20, temp=0.1, head="mlp", trick=dict(review_trick=True)),
+    # SCR with 3 slots for 4 classes: at the second evaluate() at least one seen class has no exemplar -> the random class mean of
+    # agents/base.py:135-137 (a torch.normal draw on the CPU generator, which also shifts every later RNG draw)
+    "scr_tiny": dict(agent="SCR", retrieve="random", update="random", data="cifar100", mem_size=3, eps_mem_batch=2, seed=10,
+                     tasks=[[3, 17], [40, 41]], n_train=15, n_test=20, temp=0.07, head="mlp"),
+    # ER --retrieve match with the BufferClassTracker (utils/buffer/sc_retrieve.py, buffer_utils.py:29-49,163-203)
+    "er_match": dict(agent="ER", retrieve="match", update="random", data="cifar10", mem_size=60, eps_mem_batch=10, seed=8,
+                     tasks=[[0, 1], [2, 3]], n_train=30, n_test=20, buffer_tracker=True, warmup=2),
+    # ER --update GSS (utils/buffer/gss_greedy_update.py): eval-mode per-sample gradients, cosine similarity, multinomial draws
+    # (single-class tasks: the first batches of class 1 have gradients pointing away from every memory gradient, max cosine < 0, so
+    # the replacement branch :23-43 with its two multinomial draws is taken twice in this run)
+    "er_gss": dict(agent="ER", retrieve="random", update="GSS", data="cifar10", mem_size=20, eps_mem_batch=10, seed=9,
+                   tasks=[[0], [1]], n_train=30, n_test=20, gss_mem_strength=3, gss_batch_size=5, free_run_gpu=False),
 }
 
 
 def case_params(cfg):
     keys = ("agent", "retrieve", "update", "data", "mem_size", "eps_mem_batch", "seed", "temp", "head", "k", "n_smp_cls", "aser_type",
-            "subsample")
+            "subsample", "buffer_tracker", "warmup", "gss_mem_strength", "gss_batch_size")
     p = {k: cfg[k] for k in keys if k in cfg}
     p["num_tasks"] = len(cfg["tasks"])
+    if "trick" in cfg:
+        trick = {k: False for k in ('labels_trick', 'kd_trick', 'separated_softmax', 'review_trick', 'ncm_trick', 'kd_trick_star')}
+        trick.update(cfg["trick"])
+        p["trick"] = trick
     return p
 
 

@@ -82,8 +82,12 @@ def test_module_containers_match_reference_state_dict_and_seeded_init():
 def test_registries_have_reference_keys():
     from ocl_amd import name_match
     assert set(name_match.agents.keys()) == {"ER", "SCR"}
-    assert set(name_match.retrieve_methods.keys()) == {"MIR", "random", "ASER"}
-    assert set(name_match.update_methods.keys()) == {"random", "ASER"}
+    # every retrieve / update key of the reference's registries (utils/name_match.py:41-55)
+    assert set(name_match.retrieve_methods.keys()) == {"MIR", "random", "ASER", "match", "mem_match"}
+    assert set(name_match.update_methods.keys()) == {"random", "GSS", "ASER"}
+    assert name_match.update_methods["GSS"].__name__ == "GSSGreedyUpdate"
+    assert name_match.retrieve_methods["match"].__name__ == "Match_retrieve"
+    assert name_match.retrieve_methods["mem_match"].__name__ == "MemMatch_retrieve"
     assert name_match.agents["SCR"].__name__ == "SupContrastReplay"
     assert name_match.retrieve_methods["ASER"].__name__ == "ASER_retrieve"
     with pytest.raises(KeyError):

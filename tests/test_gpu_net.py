@@ -42,7 +42,7 @@ def layer_report(m, net_rec, n):
         cnt = ref.size
         dst = torch.empty(cnt, dtype=torch.float32, device="cuda")
         nw = ffi.i64(0)
-        slot = (m._slot_rr - 1) % m._desc.n_slots
+        slot = (m._slot_rr - 1) % m._n_tapes
         ffi.check(L.ocl_net_debug_copy(m._net, slot, 0, i, ffi.ptr(dst), cnt, C.byref(nw), ffi.stream()))
         got = dst.cpu().numpy().reshape(ref.shape[0], ref.shape[2], ref.shape[3], ref.shape[1]).transpose(0, 3, 1, 2)
         rows.append((name, relmax(got, ref)))
@@ -71,7 +71,7 @@ def fetch_act(m, what, index, shape_nchw):
     cnt = n * c * h * w
     dst = torch.empty(cnt, dtype=torch.float32, device="cuda")
     nw = ffi.i64(0)
-    slot = (m._slot_rr - 1) % m._desc.n_slots
+    slot = (m._slot_rr - 1) % m._n_tapes
     ffi.check(ffi.lib().ocl_net_debug_copy(m._net, slot, what, index, ffi.ptr(dst), cnt, C.byref(nw), ffi.stream()))
     return dst.cpu().view(n, h, w, c).permute(0, 3, 1, 2).contiguous()
 

@@ -45,7 +45,9 @@ def build_agent(cfg, **over):
     return params, model, agent
 
 
-@pytest.mark.parametrize("name", [n for n, c in STEP_CASES.items() if c.get("golden", True)])
+# er_gss is left out here: its multinomial draws are weighted by gradient similarities of the free-running weights, so the slots
+# are not a function of the host RNG alone; test_gpu_parity2.test_cosim_gss compares it step by step from identical state
+@pytest.mark.parametrize("name", [n for n, c in STEP_CASES.items() if c.get("golden", True) and c.get("free_run_gpu", True)])
 def test_free_running_cases_vs_reference_golden(cuda, name):
     """Whole tasks, free running, against the run recorded from the REAL reference.  Everything driven by the host RNGs
     (which slots are written, with which samples, in which order; counters) must be bit-exact.  The weights themselves
@@ -94,7 +96,7 @@ def _flat(state, names):
     return torch.cat([state[k].detach().reshape(-1) for k in names]).double().numpy()
 
 
-def cosim(cfg, n_iters, cuda, prefill=None, x_stream=None, before_hip=None):
+def cosim(cfg, n_iters, cuda, prefill=None, x_stream=None, before_hip=None, sync_extra=None):
     """Yields per iteration (events of the HIP agent, oracle log entry, dict of checks already made).  Before every
     iteration the HIP model is loaded with the oracle's weights and BatchNorm buffers (teacher forcing); both sides then
     consume the SAME host RNG streams (state saved / restored), and must leave them in the same state."""
@@ -113,6 +115,10 @@ def cosim(cfg, n_iters, cuda, prefill=None, x_stream=None, before_hip=None):
     for it in range(n_iters):
         x, y = xs[it * 10:(it + 1) * 10], ys[it * 10:(it + 1) * 10]
         model.load_state_dict(oa.state_dict())
+        if sync_extra is not None:
+            sync_extra(agent, oa)          # plugin state beyond weights / memory (e.g. GSS slot scores)
+        state_before = {k: v.clone() for k, v in oa.state_dict().items()}
+        buf_before = (oa.buf.img, oa.buf.label.clone())   # images of a slot change only when it is overwritten: callers index rows the step did not touch
         w0 = _flat(oa.state, oa.names)
         st = _rng_get()
         n_log = len(oa.log)
@@ -133,7 +139,8 @@ def cosim(cfg, n_iters, cuda, prefill=None, x_stream=None, before_hip=None):
         w1_m = model.flat_params().double().cpu().numpy()
         dw_o, dw_m = w1_o - w0, w1_m - w0
         upd_err = float(np.linalg.norm(dw_m - dw_o) / (1e-30 + np.linalg.norm(dw_o))) if np.linalg.norm(dw_o) > 0 else float(np.linalg.norm(dw_m))
-        yield it, ev, oa.log[-1], dict(rng_equal=_rng_equal(st_o, st_m), upd_err=upd_err, agent=agent, oa=oa, model=model)
+        yield it, ev, oa.log[-1], dict(rng_equal=_rng_equal(st_o, st_m), upd_err=upd_err, agent=agent, oa=oa, model=model,
+                                       state_before=state_before, buf_before=buf_before)
 
 
 def _buffers_equal(agent, oa):
@@ -143,8 +150,9 @@ def _buffers_equal(agent, oa):
 
 def test_cosim_er_random(cuda):
     """BASELINE config 1 shape (ER random/random): per step, both CE losses within 1e-4 (north_star tolerance; observed
-    ~1e-6), retrieved indices / reservoir slots / RNG state exact, SGD update within 5e-2 norm-wise (a handful of ReLU
-    sign flips at ~0 per step perturb single channels; the gradient itself is checked to 2e-4 in test_gpu_net)."""
+    ~1e-6), retrieved indices / reservoir slots / RNG state exact, SGD update within 1e-2 norm-wise (observed <= 4e-3: a handful
+    of ReLU sign flips at ~0 per step perturb single channels; with the activation pattern teacher-forced the gradient agrees to
+    2e-4, test_gpu_net and test_gpu_parity2.test_er_step_gradient_with_forced_relu_pattern_at_early_iterations)."""
     cfg = dict(STEP_CASES["er_c10"], mem_size=30)
     worst = 0.0
     for it, ev, ol, chk in cosim(cfg, 6, cuda):
@@ -158,7 +166,7 @@ def test_cosim_er_random(cuda):
         assert _buffers_equal(chk["agent"], chk["oa"])
         worst = max(worst, chk["upd_err"])
         print("er it", it, "update err", chk["upd_err"])
-    assert worst < 5e-2
+    assert worst < 1e-2
 
 
 def test_cosim_scr(cuda):
@@ -177,7 +185,7 @@ def test_cosim_scr(cuda):
         assert _buffers_equal(chk["agent"], chk["oa"])
         worst = max(worst, chk["upd_err"])
         print("scr it", it, "update err", chk["upd_err"])
-    assert worst < 5e-2
+    assert worst < 1e-2
 
 
 def _force_mir_gradient(monkeypatch, cuda):
@@ -332,7 +340,7 @@ def test_scr_step_at_baseline_size_vs_oracle(cuda):
         assert len(rr) == 100 and np.array_equal(rr, ol[1])
         assert [list(e["slots"]) for t, e in ev if t == "reservoir"][0] == list(ol[2])
         assert _buffers_equal(chk["agent"], chk["oa"])
-        assert chk["upd_err"] < 5e-2
+        assert chk["upd_err"] < 1e-2
 
 
 def test_aser_knn_path_at_baseline_size_properties(cuda):
