@@ -10,7 +10,12 @@ scaling, no data-path collective; one all_gather/all_reduce of scalars at the en
 
 Prints ONE JSON line on rank 0 (see the task's bench contract) including
   roofline     fp32-MFMA utilisation of the conv implicit-GEMM kernels, from HIP-event timing of every launch
-  cpu_baseline the oracle restatement of the same step timed on this box's host cores (rank 0, N=1 only).
+  cpu_baseline the oracle restatement of the same step timed on this box's host cores (rank 0, N=1 only)
+  also.aser    the second headline configuration of BASELINE.json's metric (configs[2]: ER + ASER retrieve / update, mem 5000,
+               k = 3): its own timed throughput, conv roofline fraction and kNN / buffer-path GB/s from the live HIP-event legs
+  accuracy     the "final avg accuracy" half of the metric: a short class-incremental Split-CIFAR100-shaped run (10 tasks x 10
+               classes, class-prototype images) per rank, evaluate() after every task, accuracy arrays all-gathered over the ranks
+               and summarised by experiment/metrics.py's formulas; at N=1 the CPU oracle runs the same stream for comparison.
 """
 import argparse
 import json
@@ -76,16 +81,21 @@ def flops_per_step(workload, hw, n_classes_in_buffer=100):
     return gemm, wgrad
 
 
+PMC_TRAFFIC_FILES = ("r2_scr_pmc_traffic.json", "r1_scr_pmc_traffic.json")
+
+
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/r1_scr_pmc_traffic.json: FETCH_SIZE
-    and WRITE_SIZE collected in separate --pmc runs of this same command, gfx950 FETCH_SIZE correction applied there);
-    null when the profile is not shipped.  Counters cannot be read live from inside the process."""
-    path = os.path.join(ROOT, "profiles", "r1_scr_pmc_traffic.json")
-    try:
-        with open(path) as f:
-            return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"]
-    except Exception:
-        return None
+    """(HBM bytes per launch of `kernel`, source file) from the committed rocprofv3 PMC passes (profiles/r*_scr_pmc_traffic.json:
+    FETCH_SIZE and WRITE_SIZE collected in separate --pmc runs of this same command, gfx950 FETCH_SIZE correction applied there);
+    (None, None) when no profile is shipped.  Hardware counters cannot be read from inside the process: this figure is a
+    committed measurement of an earlier run of the same command, NOT something this run measured."""
+    for name in PMC_TRAFFIC_FILES:
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                return json.load(f)["kernels"][kernel]["hbm_bytes_per_launch"], "profiles/" + name
+        except Exception:
+            continue
+    return None, None
 
 
 def build_agent(workload, seed, device):
@@ -115,15 +125,18 @@ def build_agent(workload, seed, device):
     return params, model, agent, hw, ncls
 
 
-def gpu_leg(args, rank, world, local):
+def gpu_leg(args, rank, world, local, workload=None, steps=None, warmup=None):
     from ocl_amd import dist as odist
     from ocl_amd import ops
+    workload = workload or args.workload
+    steps = steps or args.steps
+    warmup = args.warmup if warmup is None else warmup
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
-    params, model, agent, hw, ncls = build_agent(args.workload, args.seed + rank, device)
+    params, model, agent, hw, ncls = build_agent(workload, args.seed + rank, device)
     bs = params.batch
-    xw, yw = synth_u8(max(1, args.warmup) * bs, hw, ncls, 1 + rank)
-    xt, yt = synth_u8(args.steps * bs, hw, ncls, 2 + rank)
+    xw, yw = synth_u8(max(1, warmup) * bs, hw, ncls, 1 + rank)
+    xt, yt = synth_u8(steps * bs, hw, ncls, 2 + rank)
     xw_d, xt_d = torch.from_numpy(xw).to(device), torch.from_numpy(xt).to(device)     # resident in HBM before timing
     # warm-up (also builds kernel plans, allocates torch's caching pools)
     agent.train_learner(xw_d, yw)
@@ -136,14 +149,14 @@ def gpu_leg(args, rank, world, local):
     odist.barrier()
     elapsed = time.perf_counter() - t0
     elapsed = odist.max_over_ranks(elapsed, device)
-    total_steps = odist.sum_over_ranks(args.steps, device)
-    out = dict(elapsed=elapsed, total_steps=total_steps, hw=hw, bs=bs)
+    total_steps = odist.sum_over_ranks(steps, device)
+    out = dict(elapsed=elapsed, total_steps=total_steps, hw=hw, bs=bs, steps=steps)
 
     # ---- roofline leg: HIP events around every kernel launch, on the stream the kernels run on (rank 0) -----------
     # With profiling enabled the engine keeps the weight-gradient kernels on the same stream (no overlap), so each duration is
     # that of the kernel alone; `value` above comes from the overlapped product path.
     if rank == 0 and not args.no_roofline:
-        n_prof = min(args.steps, 20)
+        n_prof = min(steps, 20)
         xp, yp = synth_u8(n_prof * bs, hw, ncls, 3)
         xp_d = torch.from_numpy(xp).to(device)
         ops.prof_enable(True)
@@ -156,7 +169,8 @@ def gpu_leg(args, rank, world, local):
             cls[name] = dict(ms=ms, launches=n)
         ops.prof_enable(False)
         ops.prof_reset()
-        gemm_fl, wgrad_fl = flops_per_step(args.workload, hw)
+        gemm_fl, wgrad_fl = flops_per_step(workload, hw)
+        traffic, traffic_src = pmc_traffic("conv_gemm_kernel") if workload == "scr" else (None, None)
         g = cls["conv_gemm"]
         wg = cls["conv_wgrad"]
         out["roofline"] = dict(
@@ -164,7 +178,8 @@ def gpu_leg(args, rank, world, local):
             achieved=(gemm_fl * n_prof / (g["ms"] * 1e-3) / 1e12) if g["ms"] > 0 else None,
             peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
             frac=(gemm_fl * n_prof / (g["ms"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if g["ms"] > 0 else None,
-            traffic=pmc_traffic("conv_gemm_kernel"),
+            traffic=traffic,
+            traffic_source=(traffic_src + " (rocprofv3 --pmc passes of an earlier run of this command; not measured by this run)") if traffic_src else None,
             avg_launch_us=(g["ms"] * 1e3 / g["launches"]) if g["launches"] else None, launches_per_step=g["launches"] / n_prof,
             algorithmic_gflop_per_step=gemm_fl / 1e9,
             wgrad=dict(achieved=(wgrad_fl * n_prof / (wg["ms"] * 1e-3) / 1e12) if wg["ms"] > 0 else None,
@@ -172,13 +187,105 @@ def gpu_leg(args, rank, world, local):
                        avg_launch_us=(wg["ms"] * 1e3 / wg["launches"]) if wg["launches"] else None),
             # kNN / buffer path (SURVEY §8d algorithmic bytes per iteration: buffer gather + features + slot replacement [+ MIR's virtual
             # step]); latency-bound by construction, reported next to its kernel time
-            knn_buffer=dict(algorithmic_bytes_per_step=KNN_BUFFER_BYTES[args.workload],
-                            achieved_GBps=(KNN_BUFFER_BYTES[args.workload] / (cls["knn_buffer"]["ms"] / n_prof * 1e-3) / 1e9)
+            knn_buffer=dict(algorithmic_bytes_per_step=KNN_BUFFER_BYTES[workload],
+                            achieved_GBps=(KNN_BUFFER_BYTES[workload] / (cls["knn_buffer"]["ms"] / n_prof * 1e-3) / 1e9)
                             if cls["knn_buffer"]["ms"] > 0 else None, peak_GBps=8000.0,
                             launches_per_step=cls["knn_buffer"]["launches"] / n_prof),
             per_step_ms={k: v["ms"] / n_prof for k, v in cls.items()},
             launches_per_step_all={k: v["launches"] / n_prof for k, v in cls.items()})
     return out
+
+
+# ---- accuracy leg ("final avg accuracy" half of BASELINE.json's metric) -----------------------------------------------------
+ACC_CFG = dict(n_tasks=10, classes_per_task=10, n_train=20, n_test=10, blend=0.3)
+
+
+def accuracy_stream(seed, n_tasks, classes_per_task, n_train, n_test, blend, hw=32):
+    """Class-incremental Split-CIFAR100-shaped stream (no datasets on disk): per class a fixed uint8 prototype,
+    every image = blend * prototype + (1 - blend) * uniform noise; tasks of `classes_per_task` consecutive classes
+    (general_main.py --fix_order True), a test set per task."""
+    rng = np.random.default_rng(70000 + seed)
+    tasks, tests = [], []
+    for t in range(n_tasks):
+        classes = range(t * classes_per_task, (t + 1) * classes_per_task)
+        for store, n in ((tasks, n_train), (tests, n_test)):
+            xs, ys = [], []
+            for c in classes:
+                proto = np.random.default_rng(1234 + c).integers(0, 256, (hw, hw, 3)).astype(np.float32)
+                noise = rng.integers(0, 256, (n, hw, hw, 3)).astype(np.float32)
+                xs.append(np.clip(blend * proto[None] + (1 - blend) * noise, 0, 255).astype(np.uint8))
+                ys.append(np.full(n, c, dtype=np.int64))
+            store.append((np.concatenate(xs), np.concatenate(ys)))
+    return tasks, tests
+
+
+def summarise_accuracy(accs):
+    """experiment/metrics.py:5-44 over the gathered [n_run, T, T] arrays; with a single run only the means are defined."""
+    from ocl_amd.metrics import compute_performance
+    accs = np.asarray(accs)
+    if accs.shape[0] > 1:
+        names = ("avg_end_acc", "avg_end_fgt", "avg_acc", "avg_bwtp", "avg_fwt")
+        return {k: dict(mean=float(v[0]), ci95=float(v[1])) for k, v in zip(names, compute_performance(accs))}
+    end = accs[0, -1, :]
+    fgt = accs[0].max(axis=0) - end
+    return dict(avg_end_acc=dict(mean=float(end.mean()), ci95=None), avg_end_fgt=dict(mean=float(fgt.mean()), ci95=None))
+
+
+def accuracy_leg(args, rank, world, local):
+    """One short SCR run per rank (own seed: experiment/run.py:34 sharded one run per GPU), evaluate() with the NCM classifier
+    after every task, one all_gather of the [T, T] accuracy arrays (the only collective of the job)."""
+    from ocl_amd import dist as odist
+    from ocl_amd.run import single_run
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    c = ACC_CFG
+    seed = odist.run_seed(args.seed, rank)
+    tasks, tests = accuracy_stream(seed, c["n_tasks"], c["classes_per_task"], c["n_train"], c["n_test"], c["blend"])
+    out = {}
+    import ocl_amd.agents.scr as scr_mod
+    for tag, identity in (("hip", False), ("hip_identity_augmentation", True)):
+        params = make_params(dict(WORKLOADS["scr"], num_tasks=c["n_tasks"]))
+        orig = scr_mod.ScrAugment.__call__
+        if identity:   # the oracle's augmentation (kornia is absent, SURVEY §8c): the like-for-like comparison with the CPU side
+            scr_mod.ScrAugment.__call__ = lambda self, x: x
+        try:
+            t0 = time.perf_counter()
+            acc, t_train, n_img, _ = single_run(params, tasks, tests, seed)
+            wall = time.perf_counter() - t0
+        finally:
+            scr_mod.ScrAugment.__call__ = orig
+        accs, extras = odist.gather_runs(acc, extra=[t_train, n_img, wall], device=device)
+        out[tag] = dict(summarise_accuracy(accs), runs=int(accs.shape[0]), train_s=float(extras[:, 0].max()), wall_s=float(extras[:, 2].max()),
+                        end_acc_per_run=[float(a[-1].mean()) for a in accs])
+    out["stream"] = ("%d tasks x %d classes, %d train / %d test images per class, class prototype blended %.0f%% with uniform noise; "
+                     "SCR random/random, mem_size 5000, eps_mem_batch 100, temp 0.07, NCM classifier; seed = --seed + rank"
+                     % (c["n_tasks"], c["classes_per_task"], c["n_train"], c["n_test"], 100 * c["blend"]))
+    return out, (tasks, tests, seed)
+
+
+def accuracy_oracle(stream, threads):
+    """The same stream through the CPU oracle (identity augmentation), rank 0 at N = 1 only."""
+    from oracle import ocl_oracle as O
+    tasks, tests, seed = stream
+    c = ACC_CFG
+    cfg = dict(WORKLOADS["scr"], seed=seed, tasks=[[0]] * c["n_tasks"], n_train=0, n_test=0)
+    import random
+    np.random.seed(seed)
+    random.seed(seed)
+    torch.manual_seed(seed)
+    default_threads = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        t0 = time.perf_counter()
+        oa = O.OracleAgent(cfg)
+        accs = []
+        for (x, y) in tasks:
+            oa.train_learner(x, y)
+            accs.append(oa.evaluate(tests))
+        wall = time.perf_counter() - t0
+    finally:
+        torch.set_num_threads(default_threads)
+    return dict(summarise_accuracy(np.array(accs)[None]), wall_s=wall, threads=threads, kind="port (oracle restatement, identity augmentation)")
 
 
 def cpu_leg(args):
@@ -237,6 +344,9 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=150)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the ASER leg (also.aser) of the default SCR run")
+    ap.add_argument("--no-accuracy", action="store_true", help="skip the accuracy leg")
+    ap.add_argument("--also-steps", type=int, default=100)
     ap.add_argument("--single-stream", action="store_true",
                     help="keep the weight-gradient kernels on the main stream (OCL_SINGLE_STREAM=1): the configuration the roofline "
                          "leg measures kernels in, and the one profiles/*kernel_stats_single_stream* are taken in")
@@ -250,8 +360,13 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     import contextlib
+    also, acc_res, acc_stream = None, None, None
     with contextlib.redirect_stdout(sys.stderr):   # the agents print like the reference ("buffer has N slots"): stdout carries the JSON only
         res = gpu_leg(args, rank, world, local)
+        if args.workload == "scr" and not args.no_also:
+            also = gpu_leg(args, rank, world, local, workload="aser", steps=args.also_steps, warmup=10)
+        if not args.no_accuracy:
+            acc_res, acc_stream = accuracy_leg(args, rank, world, local)
     if rank != 0:
         return
     w = WORKLOADS[args.workload]
@@ -283,6 +398,23 @@ def main():
     if not args.no_cpu_baseline and world == 1:
         with contextlib.redirect_stdout(sys.stderr):
             line["cpu_baseline"] = cpu_leg(args)
+    if also is not None:
+        wa = WORKLOADS["aser"]
+        rf = also.get("roofline", {})
+        line["also"] = {"aser": {
+            "metric": "replay-step images/sec (ER + ASER retrieve / update, Split-CIFAR100-shaped synthetic stream, mem_size 5000, k 3)",
+            "workload": "BASELINE.json configs[2]: " + ", ".join("%s=%s" % kv for kv in sorted(wa.items())),
+            "value": also["total_steps"] * also["bs"] / also["elapsed"], "unit": "stream images/s", "steps": also["steps"],
+            "ms_per_step": also["elapsed"] / also["steps"] * 1e3, "images_through_network_per_step": 610,
+            "roofline": {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_us", "launches_per_step",
+                                                "algorithmic_gflop_per_step", "knn_buffer", "per_step_ms", "launches_per_step_all")} if rf else None}}
+    if acc_res is not None:
+        if world == 1 and not args.no_cpu_baseline:
+            with contextlib.redirect_stdout(sys.stderr):
+                acc_res["cpu_oracle"] = accuracy_oracle(acc_stream, line.get("cpu_baseline", {}).get("cores", 16))
+            acc_res["abs_diff_avg_end_acc_identity_vs_oracle"] = abs(acc_res["hip_identity_augmentation"]["avg_end_acc"]["mean"]
+                                                                     - acc_res["cpu_oracle"]["avg_end_acc"]["mean"])
+        line["accuracy"] = acc_res
     print(json.dumps(line))
 
 

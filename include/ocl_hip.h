@@ -134,7 +134,7 @@ int ocl_mir_scores(const float* logits_pre, const float* logits_post, const int6
 /* ---- GSS-Greedy: gradient-direction similarity ------------------------------------------------------
  * max_i cosine_similarity(mem[i], g) over k stored flat gradient vectors of n floats (utils/buffer/buffer_utils.py:51-56:
  * x1.x2 / max(|x1||x2|, eps); call sites utils/buffer/gss_greedy_update.py:79,121 `max(cosine_similarity(mem_grads, grad))`).
- * n % 4 == 0, 16-byte aligned rows.  workspace: ocl_cosine_max_workspace_bytes(k) bytes. out: one float. */
+ * workspace: ocl_cosine_max_workspace_bytes(k) bytes. out: one float. */
 int64_t ocl_cosine_max_workspace_bytes(int k);
 int ocl_cosine_max(const float* mem, int k, int64_t n, const float* g, float eps, float* out, void* workspace, void* stream);
 

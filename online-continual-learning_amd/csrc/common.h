@@ -51,6 +51,14 @@ struct ProfScope {
     }
 };
 
+// ---- asynchronous device-side errors ------------------------------------------------------------------
+// One host-mapped word per process (hipHostMalloc, mapped): a kernel that cannot complete correctly (the one-pass BatchNorm
+// backward whose grid-wide arrival timed out) stores a non-zero code there; the next engine entry point reads the word from the
+// host WITHOUT synchronising and fails with OCL_ERR_STATE -- the reporting model of a sticky asynchronous error.
+enum AsyncErr : unsigned { ASYNC_ERR_BN_BARRIER = 1u };
+unsigned* async_error_word_device();        // device-visible address (nullptr if the allocation failed)
+int check_async_error(const char* where);   // OCL_OK, or OCL_ERR_STATE with the message set and the word cleared
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
 

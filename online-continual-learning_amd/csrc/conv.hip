@@ -1558,6 +1558,7 @@ __global__ void __launch_bounds__(kBnFusedThreads) bn_bwd_fused_kernel(const BnB
         while (__hip_atomic_load(a.barrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < groups_total && ++spins < (1 << 22))
             __builtin_amdgcn_s_sleep(1);
         timed_out = spins >= (1 << 22);
+        if (timed_out && a.err) __hip_atomic_fetch_or(a.err, (unsigned)ASYNC_ERR_BN_BARRIER, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     __syncthreads();
     const double Md = (double)M;
@@ -1625,6 +1626,13 @@ int launch_bn_bwd(const BnBwdArgs& a, hipStream_t s) {
             hipDeviceProp_t prop;
             OCL_HIP(hipGetDevice(&dev));
             OCL_HIP(hipGetDeviceProperties(&prop, dev));
+            // residency: the grid never exceeds one workgroup per CU, and every instantiation must be admissible at that rate
+            // (checked once against the occupancy query); a time-out at run time is reported through the asynchronous error word
+            int b3 = 0, b6 = 0, b12 = 0;
+            OCL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b3, bn_bwd_fused_kernel<3>, kBnFusedThreads, 0));
+            OCL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b6, bn_bwd_fused_kernel<6>, kBnFusedThreads, 0));
+            OCL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b12, bn_bwd_fused_kernel<12>, kBnFusedThreads, 0));
+            if (std::min(b3, std::min(b6, b12)) < 1) g_bn_fused = 0;   // cannot be co-resident: two-kernel path
             g_num_cus = std::max(2, prop.multiProcessorCount);
         }
         // about 6 float4 per thread and tensor; never more workgroups than CUs (all must be resident), fewer for the small maps
@@ -1637,9 +1645,11 @@ int launch_bn_bwd(const BnBwdArgs& a, hipStream_t s) {
         const int64_t need = (a.m_per_group * C4 + S - 1) / S;
         if (need <= 12) {
             ProfScope ps(PROF_BN, s);
-            if (need <= 3) hipLaunchKernelGGL(bn_bwd_fused_kernel<3>, dim3(grid), dim3(kBnFusedThreads), 0, s, a);
-            else if (need <= 6) hipLaunchKernelGGL(bn_bwd_fused_kernel<6>, dim3(grid), dim3(kBnFusedThreads), 0, s, a);
-            else hipLaunchKernelGGL(bn_bwd_fused_kernel<12>, dim3(grid), dim3(kBnFusedThreads), 0, s, a);
+            BnBwdArgs af = a;
+            af.err = async_error_word_device();
+            if (need <= 3) hipLaunchKernelGGL(bn_bwd_fused_kernel<3>, dim3(grid), dim3(kBnFusedThreads), 0, s, af);
+            else if (need <= 6) hipLaunchKernelGGL(bn_bwd_fused_kernel<6>, dim3(grid), dim3(kBnFusedThreads), 0, s, af);
+            else hipLaunchKernelGGL(bn_bwd_fused_kernel<12>, dim3(grid), dim3(kBnFusedThreads), 0, s, af);
             OCL_LAUNCH_CHECK();
             return OCL_OK;
         }

@@ -806,6 +806,7 @@ extern "C" {
 int ocl_net_forward(ocl_net* n, const float* x, int N, int groups, uint32_t flags, const float* params_override, float* feat_out,
                     float* out, int slot, void* stream) {
     OCL_REQUIRE(n && n->bound, "net_forward: net not bound");
+    if (int arc = check_async_error("net_forward")) return arc;
     OCL_REQUIRE(x && N > 0 && N <= n->d.max_batch, "net_forward: n=%d (max_batch %d)", N, n->d.max_batch);
     OCL_REQUIRE(groups >= 1 && groups <= kGmax && N % groups == 0, "net_forward: groups=%d must divide n=%d (<= %d)", groups, N, kGmax);
     OCL_REQUIRE(slot >= 0 && slot < n->d.n_slots, "net_forward: slot %d", slot);
@@ -1091,6 +1092,7 @@ extern "C" {
 
 int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, void* stream) {
     OCL_REQUIRE(n && n->bound, "net_backward: net not bound");
+    if (int arc = check_async_error("net_backward")) return arc;
     OCL_REQUIRE(slot >= 0 && slot < n->d.n_slots && n->slot_valid[slot],
                 "net_backward: slot %d holds no train-mode forward tape (forward with OCL_FWD_TRAIN|OCL_FWD_SAVE_TAPE first)", slot);
     OCL_REQUIRE(dout, "net_backward: null dout");

@@ -20,6 +20,38 @@ int hip_fail(hipError_t e, const char* what, const char* file, int line) {
     return OCL_ERR_HIP;
 }
 
+// ---- asynchronous device-side errors ----------------------------------------------------------------
+static unsigned* g_async_host = nullptr;
+static unsigned* g_async_dev = nullptr;
+static std::once_flag g_async_once;
+
+unsigned* async_error_word_device() {
+    std::call_once(g_async_once, [] {
+        void* h = nullptr;
+        if (hipHostMalloc(&h, 64, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); return; }
+        memset(h, 0, 64);
+        void* d = nullptr;
+        if (hipHostGetDevicePointer(&d, h, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipHostFree(h); return; }
+        g_async_host = (unsigned*)h;
+        g_async_dev = (unsigned*)d;
+    });
+    return g_async_dev;
+}
+
+int check_async_error(const char* where) {
+    if (!g_async_host) return OCL_OK;
+    const unsigned code = __atomic_load_n(g_async_host, __ATOMIC_RELAXED);
+    if (code == 0) return OCL_OK;
+    __atomic_store_n(g_async_host, 0u, __ATOMIC_RELAXED);
+    if (code & ASYNC_ERR_BN_BARRIER)
+        set_error("%s: an earlier one-pass BatchNorm backward could not gather all of its workgroups (grid-wide arrival timed out: the "
+                  "GPU is shared with work that holds its compute units); the gradients of that backward are poisoned with NaN. "
+                  "Set OCL_BN_FUSED=0 to use the two-kernel BatchNorm backward.", where);
+    else
+        set_error("%s: asynchronous device error code %u", where, code);
+    return OCL_ERR_STATE;
+}
+
 // ---- profiling -------------------------------------------------------------------------------------
 struct EvPair {
     hipEvent_t a, b;

@@ -95,12 +95,14 @@ __global__ void __launch_bounds__(256) sgd_flat(float* __restrict__ p, const flo
 // Pass 1: every workgroup owns a contiguous range of the vector; g's chunk stays in registers while the k rows stream past
 // it; fp32 lane partials, fp64 from the wave reduction on, one fp64 atomic per (row, workgroup).  Pass 2: one wave finishes.
 constexpr int kCosChunk = 4;   // float4 per thread and pass
+// VEC: rows are 16-byte aligned (n % 4 == 0) -> float4 loads; otherwise scalar loads (any n)
+template <bool VEC>
 __global__ void __launch_bounds__(256) cosine_partial_kernel(const float* __restrict__ mem, int k, int64_t n,
                                                              const float* __restrict__ g, double* __restrict__ acc) {
     __shared__ double red[4];
-    const int64_t n4 = n >> 2;
-    const int64_t per = (n4 + gridDim.x - 1) / gridDim.x;
-    const int64_t beg = (int64_t)blockIdx.x * per, end = min(n4, beg + per);
+    const int64_t units = VEC ? (n >> 2) : n;
+    const int64_t per = (units + gridDim.x - 1) / gridDim.x;
+    const int64_t beg = (int64_t)blockIdx.x * per, end = min(units, beg + per);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     auto block_add = [&](double v, double* dst) {
         v = wave_sum_d(v);
@@ -109,26 +111,30 @@ __global__ void __launch_bounds__(256) cosine_partial_kernel(const float* __rest
         __syncthreads();
         if (threadIdx.x == 0) atomicAdd(dst, (red[0] + red[1]) + (red[2] + red[3]));
     };
-    const float4* g4 = (const float4*)g;
-    float sg = 0.f;
-    for (int64_t i = beg + threadIdx.x; i < end; i += 256) {
-        const float4 b = g4[i];
-        sg = fmaf(b.x, b.x, fmaf(b.y, b.y, fmaf(b.z, b.z, fmaf(b.w, b.w, sg))));
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0)
-        for (int64_t j = n4 << 2; j < n; ++j) sg = fmaf(g[j], g[j], sg);
-    block_add((double)sg, acc + 2 * k);
-    for (int r = 0; r < k; ++r) {
-        const float* row = mem + (int64_t)r * n;
-        const float4* m4 = (const float4*)row;   // rows are 16-B aligned when n % 4 == 0 (checked by the caller)
+    for (int r = -1; r < k; ++r) {   // r = -1: |g|^2
+        const float* row = r < 0 ? g : mem + (int64_t)r * n;
         float sd = 0.f, sm = 0.f;
-        for (int64_t i = beg + threadIdx.x; i < end; i += 256) {
-            const float4 a = m4[i], b = g4[i];
-            sd = fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, fmaf(a.w, b.w, sd))));
-            sm = fmaf(a.x, a.x, fmaf(a.y, a.y, fmaf(a.z, a.z, fmaf(a.w, a.w, sm))));
+        if (VEC) {
+            const float4* m4 = (const float4*)row;
+            const float4* g4 = (const float4*)g;
+            for (int64_t i = beg + threadIdx.x; i < end; i += 256) {
+                const float4 a = m4[i], b = g4[i];
+                sd = fmaf(a.x, b.x, fmaf(a.y, b.y, fmaf(a.z, b.z, fmaf(a.w, b.w, sd))));
+                sm = fmaf(a.x, a.x, fmaf(a.y, a.y, fmaf(a.z, a.z, fmaf(a.w, a.w, sm))));
+            }
+        } else {
+            for (int64_t i = beg + threadIdx.x; i < end; i += 256) {
+                const float a = row[i], b = g[i];
+                sd = fmaf(a, b, sd);
+                sm = fmaf(a, a, sm);
+            }
         }
-        block_add((double)sd, acc + 2 * r);
-        block_add((double)sm, acc + 2 * r + 1);
+        if (r < 0) {
+            block_add((double)sm, acc + 2 * k);
+        } else {
+            block_add((double)sd, acc + 2 * r);
+            block_add((double)sm, acc + 2 * r + 1);
+        }
     }
 }
 __global__ void __launch_bounds__(64) cosine_finish_kernel(const double* __restrict__ acc, int k, float eps, float* __restrict__ out) {
@@ -814,12 +820,14 @@ int64_t ocl_cosine_max_workspace_bytes(int k) { return (int64_t)(2 * (int64_t)k 
 
 int ocl_cosine_max(const float* mem, int k, int64_t n, const float* g, float eps, float* out, void* workspace, void* stream) {
     OCL_REQUIRE(mem && g && out && workspace && k > 0 && n > 0, "cosine_max: bad arguments");
-    OCL_REQUIRE(n % 4 == 0 && ((uintptr_t)mem % 16) == 0 && ((uintptr_t)g % 16) == 0, "cosine_max: vectors must be 16-byte aligned, n %% 4 == 0");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(PROF_KNN, s);
     OCL_HIP(hipMemsetAsync(workspace, 0, (size_t)ocl_cosine_max_workspace_bytes(k), s));
     const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(512, (n / 4 + 256 * kCosChunk - 1) / (256 * kCosChunk)));
-    hipLaunchKernelGGL(cosine_partial_kernel, dim3(blocks), dim3(256), 0, s, mem, k, n, g, (double*)workspace);
+    if (n % 4 == 0 && ((uintptr_t)mem % 16) == 0 && ((uintptr_t)g % 16) == 0)
+        hipLaunchKernelGGL(cosine_partial_kernel<true>, dim3(blocks), dim3(256), 0, s, mem, k, n, g, (double*)workspace);
+    else
+        hipLaunchKernelGGL(cosine_partial_kernel<false>, dim3(blocks), dim3(256), 0, s, mem, k, n, g, (double*)workspace);
     OCL_LAUNCH_CHECK();
     hipLaunchKernelGGL(cosine_finish_kernel, dim3(1), dim3(64), 0, s, (const double*)workspace, k, eps, out);
     OCL_LAUNCH_CHECK();

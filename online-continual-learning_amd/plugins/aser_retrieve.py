@@ -1,10 +1,15 @@
-"""utils/buffer/aser_retrieve.py:8-92 — ASER retrieval: class-balanced candidates, adversarial + cooperative kNN
-Shapley values, top-N.  Host RNG / set bookkeeping as in the reference; scoring and selection on the GPU with no
-device->host synchronisation."""
+"""ASER retrieval -- the `retrieve_methods['ASER']` plugin (reference: utils/buffer/aser_retrieve.py:8-92).
+
+Until the stream has seen more samples than the memory holds, retrieval is uniform.  Afterwards class-balanced memory samples are
+the candidates; each is scored by its kNN Shapley value w.r.t. the incoming batch (adversarial: high value = close to current
+samples of its own class) and w.r.t. a second class-balanced memory sample (cooperative), combined per `aser_type`
+("asv": max coop - min adv, "asvm": mean coop - mean adv, "neg_sv": -sum adv), and the best `eps_mem_batch` are returned.
+The two Shapley matrices share ONE eval-mode feature pass over batch + cooperative samples + candidates (the reference extracts the
+candidates' features twice); scoring, ranking and the final gather stay on the GPU, nothing is copied back to the host."""
 import torch
 
-from .. import ops
 from .. import debug
+from .. import ops
 from ..setup_elements import n_classes
 from ..utils import maybe_cuda
 from .aser_utils import compute_knn_sv, compute_knn_sv_pair
@@ -13,7 +18,6 @@ from .buffer_utils import ClassBalancedRandomSampling, random_retrieve
 
 class ASER_retrieve(object):
     def __init__(self, params, **kwargs):
-        super().__init__()
         self.num_retrieve = params.eps_mem_batch
         self.device = "cuda" if torch.cuda.is_available() else "cpu"
         self.k = params.k
@@ -22,64 +26,36 @@ class ASER_retrieve(object):
         self.n_smp_cls = int(params.n_smp_cls)
         self.out_dim = n_classes[params.data]
         self.is_aser_upt = params.update == "ASER"
-        ClassBalancedRandomSampling.class_index_cache = None
+        ClassBalancedRandomSampling.class_index_cache = None     # class-level state, reset per plugin instance (:19)
 
     def retrieve(self, buffer, **kwargs):
-        model = buffer.model
+        if buffer.n_seen_so_far <= self.mem_size:                 # memory not yet cycled once: uniform retrieval (:24-26)
+            return random_retrieve(buffer, self.num_retrieve)
+        return self._by_shapley_value(buffer, maybe_cuda(kwargs['x']), maybe_cuda(kwargs['y']))
 
-        if buffer.n_seen_so_far <= self.mem_size:
-            # Use random retrieval until buffer is filled
-            ret_x, ret_y = random_retrieve(buffer, self.num_retrieve)
-        else:
-            # Use ASER retrieval if buffer is filled
-            cur_x, cur_y = kwargs['x'], kwargs['y']
-            ret_x, ret_y = self._retrieve_by_knn_sv(model, buffer, cur_x, cur_y, self.num_retrieve)
-        return ret_x, ret_y
-
-    def _retrieve_by_knn_sv(self, model, buffer, cur_x, cur_y, num_retrieve):
-        """aser_retrieve.py:34-92."""
-        buffer_x, buffer_y = buffer.buffer_img, buffer.buffer_label
-        cur_x = maybe_cuda(cur_x)
-        cur_y = maybe_cuda(cur_y)
-
-        # Reset and update ClassBalancedRandomSampling cache if ASER update is not enabled
-        if not self.is_aser_upt:
-            ClassBalancedRandomSampling.update_cache(buffer.label_host, self.out_dim)
-
-        # Get candidate data for retrieval (i.e., cand <- class balanced subsamples from memory)
-        cand_x, cand_y, cand_ind = \
-            ClassBalancedRandomSampling.sample(buffer_x, buffer_y, self.n_smp_cls, device=self.device)
-
-        # Type 1 - Adversarial SV: eval <- current input
-        eval_adv_x, eval_adv_y = cur_x, cur_y
-        dbg = debug.on()
+    def _by_shapley_value(self, buffer, cur_x, cur_y):
+        sampler = ClassBalancedRandomSampling
+        if not self.is_aser_upt:   # without the ASER update nobody maintains the class cache: rebuild it from the labels (:42-43)
+            sampler.update_cache(buffer.label_host, self.out_dim)
+        cand_x, cand_y, cand_slots = sampler.sample(buffer.buffer_img, buffer.buffer_label, self.n_smp_cls, device=self.device)
+        trace = debug.on()
         order_adv = order_coop = None
-
-        if self.aser_type != "neg_sv":
-            # Type 2 - Cooperative SV: eval <- class balanced subsamples from memory excluding the candidates.  Sampled before
-            # the adversarial values are computed (nothing in between draws from an RNG), so that both Shapley matrices come
-            # from ONE feature pass over current input + cooperative samples + candidates.
-            excl_indices = set(cand_ind.tolist())
-            eval_coop_x, eval_coop_y, _ = \
-                ClassBalancedRandomSampling.sample(buffer_x, buffer_y, self.n_smp_cls,
-                                                   excl_indices=excl_indices, device=self.device)
-            sv_matrix_adv, sv_matrix_coop = compute_knn_sv_pair(model, eval_adv_x, eval_adv_y, eval_coop_x, eval_coop_y, cand_x, cand_y,
-                                                                self.k, want_order=dbg)
-            if dbg:
-                sv_matrix_adv, order_adv = sv_matrix_adv
-                sv_matrix_coop, order_coop = sv_matrix_coop
-            sv = ops.aser_score(sv_matrix_adv, sv_matrix_coop, self.aser_type)
+        if self.aser_type == "neg_sv":
+            adv = compute_knn_sv(buffer.model, cur_x, cur_y, cand_x, cand_y, self.k, device=self.device, want_order=trace)
+            if trace:
+                adv, order_adv = adv
+            coop = None
         else:
-            sv_matrix_adv = compute_knn_sv(model, eval_adv_x, eval_adv_y, cand_x, cand_y, self.k, device=self.device, want_order=dbg)
-            if dbg:
-                sv_matrix_adv, order_adv = sv_matrix_adv
-            sv = ops.aser_score(sv_matrix_adv, None, "neg_sv")
-
-        ret_ind = ops.argsort_desc(sv)[:num_retrieve].contiguous()
-        if debug.on():
-            debug.emit("aser_retrieve", cand_ind=cand_ind.numpy().copy(), sv=sv.cpu().numpy(), ret=cand_ind[ret_ind.cpu()].numpy(),
+            # the cooperative evaluation set is drawn before any scoring (no RNG draw lies between, so the streams are those of the
+            # reference's order :56-76) and both matrices come out of one feature pass
+            coop_x, coop_y, _ = sampler.sample(buffer.buffer_img, buffer.buffer_label, self.n_smp_cls, excl_indices=set(cand_slots.tolist()),
+                                               device=self.device)
+            adv, coop = compute_knn_sv_pair(buffer.model, cur_x, cur_y, coop_x, coop_y, cand_x, cand_y, self.k, want_order=trace)
+            if trace:
+                (adv, order_adv), (coop, order_coop) = adv, coop
+        score = ops.aser_score(adv, coop, self.aser_type)
+        best = ops.argsort_desc(score)[:self.num_retrieve].contiguous()
+        if trace:
+            debug.emit("aser_retrieve", cand_ind=cand_slots.numpy().copy(), sv=score.cpu().numpy(), ret=cand_slots[best.cpu()].numpy(),
                        order_adv=order_adv.cpu().numpy(), order_coop=None if order_coop is None else order_coop.cpu().numpy())
-
-        ret_x = ops.gather_rows(cand_x, ret_ind)
-        ret_y = ops.gather_rows(cand_y, ret_ind)
-        return ret_x, ret_y
+        return ops.gather_rows(cand_x, best), ops.gather_rows(cand_y, best)

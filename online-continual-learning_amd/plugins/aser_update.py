@@ -1,20 +1,24 @@
-"""utils/buffer/aser_update.py:8-112 — ASER update: reservoir fill, then kNN-SV ranked replacement of random
-candidates by the current batch."""
-import numpy as np
+"""ASER memory update -- the `update_methods['ASER']` plugin (reference: utils/buffer/aser_update.py:8-112).
+
+While the memory has free slots the stream fills it like a reservoir (and the class cache learns every new slot).  Once it is full,
+each incoming batch competes for slots: an evaluation set (class-balanced memory samples + the batch's minority-class items) scores
+a candidate set (random memory samples + the whole batch) with kNN Shapley values; the candidates are ranked by total value, the
+best `n_memory_candidates` keep / take a slot, and every batch item ranked among them replaces one of the memory candidates that fell
+out.  Host side: the RNG draws and the class-cache bookkeeping (same calls, same order as the reference); device side: feature
+extraction, the Shapley kernel, ranking, row moves.  One device->host copy per update (the ranking), which the class cache needs."""
 import torch
 
-from .. import ops
 from .. import debug
+from .. import ops
 from ..setup_elements import n_classes
-from ..utils import maybe_cuda, nonzero_indices
-from .aser_utils import compute_knn_sv, add_minority_class_input
-from .buffer_utils import ClassBalancedRandomSampling, random_retrieve, _host_labels
+from ..utils import maybe_cuda
+from .aser_utils import add_minority_class_input, compute_knn_sv
+from .buffer_utils import ClassBalancedRandomSampling, _host_labels, random_retrieve
 from .reservoir_update import Reservoir_update
 
 
 class ASER_update(object):
     def __init__(self, params, **kwargs):
-        super().__init__()
         self.device = "cuda" if torch.cuda.is_available() else "cpu"
         self.k = params.k
         self.mem_size = params.mem_size
@@ -23,98 +27,57 @@ class ASER_update(object):
         self.n_smp_cls = int(params.n_smp_cls)
         self.n_total_smp = int(params.n_smp_cls * self.out_dim)
         self.reservoir_update = Reservoir_update(params)
-        ClassBalancedRandomSampling.class_index_cache = None
+        ClassBalancedRandomSampling.class_index_cache = None     # class-level state, reset per plugin instance (:20)
 
+    # ---- entry point ---------------------------------------------------------------------------------------------------------
     def update(self, buffer, x, y, **kwargs):
-        model = buffer.model
-        y_host = _host_labels(y, kwargs.get("y_host"))
-
-        place_left = self.mem_size - buffer.current_index
-
-        # If buffer is not filled, use available space to store whole or part of batch
-        if place_left:
-            x_fit = x[:place_left]
-            y_fit = y[:place_left]
-            y_fit_host = y_host[:place_left]
-
-            ind = list(range(buffer.current_index, buffer.current_index + x_fit.size(0)))
-            ClassBalancedRandomSampling.update_cache(buffer.label_host, self.out_dim,
-                                                     new_y=y_fit_host, ind=ind, device=self.device)
-            self.reservoir_update.update(buffer, x_fit, y_fit, y_host=y_fit_host)
-
-        # If buffer is filled, update buffer by sv
+        labels = _host_labels(y, kwargs.get("y_host"))
+        free = self.mem_size - buffer.current_index
+        if free:
+            self._append(buffer, x[:free], y[:free], labels[:free])
         if buffer.current_index == self.mem_size:
-            # remove what is already in the buffer
-            cur_x, cur_y = x[place_left:], y[place_left:]
-            self._update_by_knn_sv(model, buffer, cur_x, cur_y, y_host[place_left:])
+            self._compete(buffer, x[free:], y[free:], labels[free:])
 
-    def _update_by_knn_sv(self, model, buffer, cur_x, cur_y, cur_y_host):
-        """aser_update.py:43-112."""
-        cur_x = maybe_cuda(cur_x).contiguous()
-        cur_y = maybe_cuda(cur_y).contiguous()
+    def _append(self, buffer, x, y, labels):
+        """Fill phase (:27-36): the class cache first (it reads the labels being overwritten), then the reservoir append."""
+        first = buffer.current_index
+        ClassBalancedRandomSampling.update_cache(buffer.label_host, self.out_dim, new_y=labels, ind=list(range(first, first + x.size(0))),
+                                                 device=self.device)
+        self.reservoir_update.update(buffer, x, y, y_host=labels)
 
-        # Find minority class samples from current input batch
-        minority_batch_x, minority_batch_y = add_minority_class_input(cur_x, cur_y, self.mem_size, self.out_dim,
-                                                                      cur_y_host=cur_y_host)
+    # ---- full memory: Shapley-ranked replacement (:43-112) ------------------------------------------------------------------------
+    def _compete(self, buffer, cur_x, cur_y, cur_labels):
+        cur_x, cur_y = maybe_cuda(cur_x).contiguous(), maybe_cuda(cur_y).contiguous()
+        # RNG draws in the reference's order: minority threshold (torch CPU), evaluation set (one randperm per class), candidates (numpy)
+        minor_x, minor_y = add_minority_class_input(cur_x, cur_y, self.mem_size, self.out_dim, cur_y_host=cur_labels)
+        eval_x, eval_y, eval_slots = ClassBalancedRandomSampling.sample(buffer.buffer_img, buffer.buffer_label, self.n_smp_cls, device=self.device)
+        mem_x, mem_y, mem_slots = random_retrieve(buffer, self.n_total_smp, set(eval_slots.tolist()), return_indices=True)
+        n_mem, n_cur = mem_x.size(0), cur_x.size(0)
 
-        # Evaluation set
-        eval_x, eval_y, eval_indices = \
-            ClassBalancedRandomSampling.sample(buffer.buffer_img, buffer.buffer_label, self.n_smp_cls,
-                                               device=self.device)
-
-        # Concatenate minority class samples from current input batch to evaluation set
-        eval_x = torch.cat((eval_x, minority_batch_x))
-        eval_y = torch.cat((eval_y, minority_batch_y))
-
-        # Candidate set
-        cand_excl_indices = set(eval_indices.tolist())
-        cand_x, cand_y, cand_ind = random_retrieve(buffer, self.n_total_smp, cand_excl_indices, return_indices=True)
-
-        # Concatenate current input batch to candidate set
-        cand_x = torch.cat((cand_x, cur_x))
-        cand_y = torch.cat((cand_y, cur_y))
-
-        dbg = debug.on()
-        sv_matrix = compute_knn_sv(model, eval_x, eval_y, cand_x, cand_y, self.k, device=self.device, want_order=dbg)
+        trace = debug.on()
+        values = compute_knn_sv(buffer.model, torch.cat((eval_x, minor_x)), torch.cat((eval_y, minor_y)), torch.cat((mem_x, cur_x)),
+                                torch.cat((mem_y, cur_y)), self.k, device=self.device, want_order=trace)
         knn_order = None
-        if dbg:
-            sv_matrix, knn_order = sv_matrix
-        sv = ops.col_reduce(sv_matrix, "sum")
+        if trace:
+            values, knn_order = values
+        total = ops.col_reduce(values, "sum")
+        ranking = ops.argsort_desc(total).cpu()          # the update's one device->host copy
 
-        n_cur = cur_x.size(0)
-        n_cand = cand_x.size(0)
-
-        # Number of previously buffered instances in candidate set
-        n_cand_buf = n_cand - n_cur
-
-        # the cache / replacement bookkeeping below is host-side Python in the reference as well:
-        # this is the step's one device->host synchronisation
-        sv_arg_sort = ops.argsort_desc(sv).cpu()
-
-        # Divide SV array into two segments
-        # - large: candidate args to be retained; small: candidate args to be discarded
-        sv_arg_large = sv_arg_sort[:n_cand_buf]
-        sv_arg_small = sv_arg_sort[n_cand_buf:]
-
-        # Extract args relevant to replacement operation
-        ind_cur = sv_arg_large[nonzero_indices(sv_arg_large >= n_cand_buf)] - n_cand_buf
-        arg_buffer = sv_arg_small[nonzero_indices(sv_arg_small < n_cand_buf)]
-        ind_buffer = cand_ind[arg_buffer]
-
+        # the n_mem best-valued candidates hold a slot afterwards: batch items among them move in, memory items outside move out
+        keep, drop = ranking[:n_mem], ranking[n_mem:]
+        entering = keep[keep >= n_mem] - n_mem            # positions in the batch
+        leaving = mem_slots[drop[drop < n_mem]]           # memory slots, paired with `entering` in ranking order
         buffer.n_seen_so_far += n_cur
-        if debug.on():
-            debug.emit("aser_update", eval_indices=eval_indices.numpy().copy(), cand_ind=cand_ind.numpy().copy(), sv=sv.cpu().numpy(),
-                       order=sv_arg_sort.numpy().copy(), ind_buffer=ind_buffer.numpy().copy(), ind_cur=ind_cur.numpy().copy(),
-                       n_minority=int(minority_batch_x.size(0)), knn_order=knn_order.cpu().numpy())
+        if trace:
+            debug.emit("aser_update", eval_indices=eval_slots.numpy().copy(), cand_ind=mem_slots.numpy().copy(), sv=total.cpu().numpy(),
+                       order=ranking.numpy().copy(), ind_buffer=leaving.numpy().copy(), ind_cur=entering.numpy().copy(),
+                       n_minority=int(minor_x.size(0)), knn_order=knn_order.cpu().numpy())
 
-        # perform overwrite op
-        y_upt_host = cur_y_host[ind_cur.numpy()]
-        ClassBalancedRandomSampling.update_cache(buffer.label_host, self.out_dim,
-                                                 new_y=y_upt_host, ind=ind_buffer.tolist(), device=self.device)
-        if ind_buffer.numel():
+        new_labels = cur_labels[entering.numpy()]
+        ClassBalancedRandomSampling.update_cache(buffer.label_host, self.out_dim, new_y=new_labels, ind=leaving.tolist(), device=self.device)
+        if leaving.numel():
             dev = buffer.buffer_img.device
-            ind_cur_dev = ops.upload(ind_cur, dev)
-            ind_buffer_dev = ops.upload(ind_buffer, dev)
-            ops.scatter_rows(buffer.buffer_img, ind_buffer_dev, ops.gather_rows(cur_x, ind_cur_dev))
-            ops.scatter_rows(buffer.buffer_label, ind_buffer_dev, ops.gather_rows(cur_y, ind_cur_dev))
-            buffer.label_host[ind_buffer.numpy()] = y_upt_host
+            src, dst = ops.upload(entering, dev), ops.upload(leaving, dev)
+            ops.scatter_rows(buffer.buffer_img, dst, ops.gather_rows(cur_x, src))
+            ops.scatter_rows(buffer.buffer_label, dst, ops.gather_rows(cur_y, src))
+            buffer.label_host[leaving.numpy()] = new_labels

@@ -79,34 +79,27 @@ def get_grad_vector(model):
 
 
 class ClassBalancedRandomSampling:
-    """buffer_utils.py:74-160.  Class-level caches, reset by the ASER plugins' constructors exactly as in the
-    reference.  All index bookkeeping and RNG (torch CPU generator: one randperm per non-empty class) stay on the
-    host; only the selected rows are gathered on the GPU."""
+    """Class-balanced draws from the memory (reference: utils/buffer/buffer_utils.py:74-160).  Two class-level tables, shared by the
+    ASER plugins and reset by their constructors exactly as in the reference: `class_index_cache` {label: set of slots} and
+    `class_num_cache` (slots per label).  Which sample of a class gets drawn depends on torch's CPU generator (one randperm per
+    non-empty class) AND on CPython's iteration order of the freshly built difference set, so both are kept as they are; only the
+    selected rows are gathered on the GPU."""
     class_index_cache = None
     class_num_cache = None
 
     @classmethod
     def sample(cls, buffer_x, buffer_y, n_smp_cls, excl_indices=None, device="cpu", label_host=None):
-        if excl_indices is None:
-            excl_indices = set()
-
+        """Up to n_smp_cls slots of every class present, excluding `excl_indices` -> (x, y, slot indices [host])."""
+        excluded = excl_indices if excl_indices is not None else set()
         picks = []
-
-        # Use cache to retrieve indices belonging to each class in buffer.  Same operations in the same order as the
-        # reference (set difference -> CPython iteration order of the NEW set; one torch.randperm per non-empty class
-        # on the CPU generator), but the selected indices are collected in a Python list and converted once: the
-        # reference's per-class torch.tensor(list(...))[perm][:n] + torch.cat cost ~1 ms per call at 100 classes.
-        randperm = torch.randperm
-        for ind_set in cls.class_index_cache.values():
-            if ind_set:
-                # Exclude some indices
-                valid_ind = ind_set - excl_indices
-                # Auxiliary indices for permutation
-                perm_ind = randperm(len(valid_ind))
-                # Apply permutation, and select indices
-                order = list(valid_ind)
-                for j in perm_ind[:n_smp_cls].tolist():
-                    picks.append(order[j])
+        for slots in cls.class_index_cache.values():          # dict insertion order = order in which classes first appeared
+            if not slots:
+                continue
+            eligible = slots - excluded                       # a NEW set: its iteration order is part of the observable behaviour
+            shuffle = torch.randperm(len(eligible))           # drawn even when nothing is eligible (len 0), as the reference does
+            members = list(eligible)
+            picks.extend(members[j] for j in shuffle[:n_smp_cls].tolist())
+        # one tensor conversion for the whole draw (the reference builds and concatenates one tensor per class: ~1 ms per call)
         sample_ind = torch.tensor(picks, dtype=torch.long)
 
         idx_dev = ops.upload(sample_ind, buffer_x.device)
@@ -118,31 +111,26 @@ class ClassBalancedRandomSampling:
 
     @classmethod
     def update_cache(cls, buffer_y_host, num_class, new_y=None, ind=None, device="cpu"):
-        """buffer_y_host: numpy mirror of buffer_label; new_y / ind: host integer sequences."""
+        """new_y / ind given (ASER update in use): slots `ind` are about to hold labels `new_y` -- move them between the class sets
+        (`buffer_y_host`, the numpy label mirror, still holds the labels being replaced).  Otherwise (ASER retrieval alone):
+        rebuild the index from the whole label array; the counts are not touched by this path in the reference either."""
         if cls.class_index_cache is None:
-            # Initialize caches
             cls.class_index_cache = defaultdict(set)
             cls.class_num_cache = torch.zeros(num_class, dtype=torch.long)
-
-        if new_y is not None:
-            # If ASER update is being used, keep updating existing caches
-            ind = [int(i) for i in ind]
-            new_y = [int(v) for v in new_y]
-            orig_y = [int(buffer_y_host[i]) for i in ind]
-            for i_int, ny_int, oy_int in zip(ind, new_y, orig_y):
-                # Update dictionary according to new class label of index i
-                if oy_int in cls.class_index_cache and i_int in cls.class_index_cache[oy_int]:
-                    cls.class_index_cache[oy_int].remove(i_int)
-                    cls.class_num_cache[oy_int] -= 1
-                cls.class_index_cache[ny_int].add(i_int)
-                cls.class_num_cache[ny_int] += 1
-        else:
-            # If only ASER retrieve is being used, reset cache and update it based on buffer
-            cls_ind_cache = defaultdict(set)
-            for i, c in enumerate(buffer_y_host):
-                cls_ind_cache[int(c)].add(i)
-            cls.class_index_cache = cls_ind_cache
-
+        if new_y is None:
+            rebuilt = defaultdict(set)
+            for slot, label in enumerate(buffer_y_host):
+                rebuilt[int(label)].add(slot)
+            cls.class_index_cache = rebuilt
+            return
+        for slot, label in zip(ind, new_y):
+            slot, label = int(slot), int(label)
+            previous = int(buffer_y_host[slot])
+            if previous in cls.class_index_cache and slot in cls.class_index_cache[previous]:
+                cls.class_index_cache[previous].remove(slot)
+                cls.class_num_cache[previous] -= 1
+            cls.class_index_cache[label].add(slot)
+            cls.class_num_cache[label] += 1
 
 class BufferClassTracker(object):
     """buffer_utils.py:163-203: per-buffer class -> set-of-slots index and per-class counts, maintained by the reservoir update

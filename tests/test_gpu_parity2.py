@@ -293,13 +293,27 @@ def test_mir_full_memory_free_gradient(cuda):
 # the per-step update error is ReLU sign flips
 # ---------------------------------------------------------------------------------------------------------------------
 
+def _double_state(sd):
+    st = O.OrderedDict()
+    for k, v in sd.items():
+        t = v.detach().clone()
+        if t.is_floating_point():
+            t = t.double()
+            if not (k.endswith("running_mean") or k.endswith("running_var")):
+                t.requires_grad_(True)
+        st[k] = t
+    return st
+
+
 def test_er_step_gradient_with_forced_relu_pattern_at_early_iterations(cuda):
-    """The free-running ER co-simulation shows its largest update errors (1e-3) at iterations 1-2, when the memory batch is
-    still smaller than the stream batch and BatchNorm statistics come from a handful of samples.  At exactly those states (the
-    oracle's weights after 1 and 2 iterations, the stream batch and the memory batch of that iteration as the two groups of one
-    pass) the gradient with the ReLU activation pattern teacher-forced to the engine's agrees to 2e-4 of each tensor's max, and
-    every element whose pattern differs from ATen's has |pre-activation| < 1e-5 of the layer's max: the free-running excess is
-    sign flips at ~0, nothing else."""
+    """The free-running ER co-simulation shows its largest update errors (1e-3) at iterations 1-2, when the memory batch is the
+    previous stream batch and BatchNorm statistics come from ten samples (near-constant channels: 1/std amplifies round-off).
+    At exactly those states (the oracle's weights after 1 and 2 iterations; the stream batch and the memory batch of that iteration
+    as the two groups of one pass) three gradients are computed with the SAME ReLU activation pattern (the engine's): the
+    engine's, ATen's in fp32, and ATen's in fp64 as ground truth.  The engine must be as close to the fp64 gradient as ATen's own
+    fp32 arithmetic is (within 3x, per tensor, floor 2e-4 of the tensor's max), and every element whose pattern differs from
+    ATen's has |pre-activation| < 1e-5 of the layer's max: what the free-running comparison sees is fp32 conditioning plus sign
+    flips at ~0, not an arithmetic difference."""
     from test_gpu_net import engine_masks
     from ocl_amd.loss import cross_entropy_mean
     cfg = dict(STEP_CASES["er_c10"], mem_size=30)
@@ -317,48 +331,48 @@ def test_er_step_gradient_with_forced_relu_pattern_at_early_iterations(cuda):
             idx = O.random_retrieve_indices(oa.buf, 10)
             _rng_set(st_rng)
             mx, my = oa.buf.img[idx], oa.buf.label[idx]
+            assert len(my) == len(by)
             groups = [(bx, by), (mx, my)]
             model.load_state_dict(sd)
             model.train()
-            if len(my) == len(by):
-                out = model.forward_views([bx.to(cuda), mx.to(cuda)])
-                loss = cross_entropy_mean(out[:10], by.to(cuda)) + cross_entropy_mean(out[10:], my.to(cuda))
-                n_tot = 20
-            else:       # unequal groups run as two passes in the product too; check the stream batch's pass
-                groups = [(bx, by)]
-                out = model.forward(bx.to(cuda))
-                loss = cross_entropy_mean(out, by.to(cuda))
-                n_tot = 10
+            out = model.forward_views([bx.to(cuda), mx.to(cuda)])
+            loss = cross_entropy_mean(out[:10], by.to(cuda)) + cross_entropy_mean(out[10:], my.to(cuda))
             agent.opt.zero_grad()
-            st = O.clone_state(sd)
-            names = [k for k in st if st[k].requires_grad]
             probe = O.OracleNet(O.clone_state(sd, requires_grad=False), head=None, training=True)
             probe.pre_act = {}
             with torch.no_grad():
                 probe.forward(bx)
-            shapes = {k: (n_tot,) + tuple(v.shape[1:]) for k, v in probe.pre_act.items()}
+            shapes = {k: (20,) + tuple(v.shape[1:]) for k, v in probe.pre_act.items()}
             masks = engine_masks(model, shapes, "")
             loss.backward()
-            net = O.OracleNet(st, head=None, training=True)
-            lref, off, n_mis, worst_amb = 0.0, 0, 0, 0.0
-            for gx, gy in groups:
-                net.mask_override = {k: v[off:off + len(gy)] for k, v in masks.items()}
-                net.pre_act = {}
-                lref = lref + O.ce_mean(net.forward(gx), gy)
-                for k, pa in net.pre_act.items():
-                    mis = (pa > 0).float() != net.mask_override[k]
-                    n_mis += int(mis.sum())
-                    if mis.any():
-                        worst_amb = max(worst_amb, float(pa[mis].abs().max() / pa.abs().max()))
-                off += len(gy)
-            lref.backward()
-            worst = 0.0
+            grads = {}
+            for tag, st, cast in (("f32", O.clone_state(sd), lambda t: t), ("f64", _double_state(sd), lambda t: t.double())):
+                net = O.OracleNet(st, head=None, training=True)
+                lref, off, n_mis, worst_amb = 0.0, 0, 0, 0.0
+                for gx, gy in groups:
+                    net.mask_override = {k: cast(v[off:off + len(gy)]) for k, v in masks.items()}
+                    net.pre_act = {}
+                    lref = lref + torch.nn.functional.cross_entropy(net.forward(cast(gx)), gy)
+                    for k, pa in net.pre_act.items():
+                        mis = (pa > 0) != (net.mask_override[k] > 0)
+                        n_mis += int(mis.sum())
+                        if mis.any():
+                            worst_amb = max(worst_amb, float(pa[mis].abs().max() / pa.abs().max()))
+                    off += len(gy)
+                lref.backward()
+                grads[tag] = ({k: st[k].grad.double() for k in st if st[k].requires_grad}, float(lref.detach()), n_mis, worst_amb)
+            g64, l64, _, _ = grads["f64"]
+            g32, l32, n_mis, worst_amb = grads["f32"]
+            worst_ratio, worst_h, worst_o = 0.0, 0.0, 0.0
             for k, p in model.named_parameters():
-                gref = st[k].grad
-                worst = max(worst, float(np.abs(p.grad.cpu().numpy() - gref.numpy()).max() / (1e-12 + float(gref.abs().max()))))
-            print("ER iteration %d: forced-pattern gradient err %.2e, %d pattern mismatches (worst ambiguity %.1e)" % (it, worst, n_mis, worst_amb))
-            assert abs(float(loss) - float(lref.detach())) < 1e-4
-            assert worst < 2e-4 and worst_amb < 1e-5
+                den = 1e-30 + float(g64[k].abs().max())
+                e_h = float((p.grad.cpu().double() - g64[k]).abs().max()) / den
+                e_o = float((g32[k] - g64[k]).abs().max()) / den
+                worst_h, worst_o = max(worst_h, e_h), max(worst_o, e_o)
+                assert e_h <= max(2e-4, 3 * e_o), (k, e_h, e_o)
+            print("ER iteration %d: error vs the fp64 gradient: engine %.2e, ATen fp32 %.2e; %d pattern mismatches (worst ambiguity %.1e)"
+                  % (it, worst_h, worst_o, n_mis, worst_amb))
+            assert abs(float(loss.detach()) - l64) < 1e-4 and worst_amb < 1e-5
         oa.train_learner(xs[it * 10:(it + 1) * 10], ys[it * 10:(it + 1) * 10])
 
 
@@ -389,15 +403,18 @@ def test_free_running_trajectory_inside_the_oracles_own_spread(cuda, name):
     drive (buffer labels, counters) must equal the oracle's exactly.  The weights follow a trajectory that amplifies fp32
     round-off: the oracle itself, run with 1 / 8 / 16 intra-op threads or from initial weights perturbed by ONE ulp, ends in
     states that differ from each other; the HIP run's distance from the reference oracle run must not exceed 5x the largest of
-    those self-distances (state digest) and its end accuracy must lie within the oracle's own accuracy range widened by one
-    test sample per task.  This is the statistical statement that replaces a bit-wise trajectory comparison."""
+    those self-distances (state digest), and its end accuracy must lie within [the largest accuracy spread the oracle shows for one
+    seed] + 3 binomial standard errors of the oracle's median.  This is the statistical statement that replaces a bit-wise
+    trajectory comparison: ER at lr 0.1 on ten-sample batches is chaotic (a 1-ulp change of the initial weights moves the end
+    accuracy of one seed by tens of points), SCR with the NCM classifier is not."""
     from ocl_amd.data import setup_test_loader
     base = dict(er_traj=dict(agent="ER", retrieve="random", update="random", data="cifar10", mem_size=60, eps_mem_batch=10,
                              tasks=[[0, 1], [2, 3], [4, 5]], n_train=50, n_test=50),
                 scr_traj=dict(agent="SCR", retrieve="random", update="random", data="cifar100", mem_size=60, eps_mem_batch=20,
                               tasks=[[3, 17], [40, 41], [7, 9]], n_train=40, n_test=50, temp=0.07, head="mlp"))[name]
     default_threads = torch.get_num_threads()
-    ratios = []
+    rows = []
+    n_test_total = base["n_test"] * sum(len(t) for t in base["tasks"])
     try:
         for seed in (101, 102, 103):
             cfg = dict(base, seed=seed)
@@ -419,17 +436,21 @@ def test_free_running_trajectory_inside_the_oracles_own_spread(cuda, name):
             assert np.array_equal(agent.buffer.buffer_label.cpu().numpy(), oa_ref.buf.label.numpy())
             assert [agent.buffer.current_index, agent.buffer.n_seen_so_far] == [oa_ref.buf.current_index, oa_ref.buf.n_seen_so_far]
             hip_dist = np.abs(digest_state(model.state_dict()) - dig_ref).max() / scale
-            one_sample = 1.0 / (base["n_test"] * len(base["tasks"][0]))
-            lo, hi = min(end_accs) - one_sample, max(end_accs) + one_sample
-            print("%s seed %d: oracle self-distance %.3e (threads 8 / 16, 1-ulp init), HIP distance %.3e; end acc HIP %.4f, oracle range [%.4f, %.4f]"
-                  % (name, seed, self_dist, hip_dist, acc_h[-1].mean(), min(end_accs), max(end_accs)))
+            print("%s seed %d: oracle self-distance %.3e (threads 8 / 16, +-1-ulp init), HIP distance %.3e; end acc HIP %.4f, oracle %s"
+                  % (name, seed, self_dist, hip_dist, acc_h[-1].mean(), np.round(end_accs, 4).tolist()))
             assert self_dist > 0, "the oracle did not move under a 1-ulp perturbation: the run is too short to say anything"
             assert hip_dist <= 5 * self_dist + 1e-6, (hip_dist, self_dist)
-            assert lo - 1e-12 <= acc_h[-1].mean() <= hi + 1e-12, (acc_h[-1], end_accs)
-            ratios.append(hip_dist / self_dist)
+            rows.append((acc_h[-1].mean(), end_accs, hip_dist / self_dist))
     finally:
         torch.set_num_threads(default_threads)
-    print(name, "HIP distance / oracle self-distance per seed:", np.round(ratios, 2))
+    # accuracy: the regime's own noise = the largest spread the oracle shows for one seed under rounding-level perturbations, plus
+    # three binomial standard errors of the test set
+    pooled = max(max(e) - min(e) for _, e, _ in rows)
+    for acc_hip, end_accs, _ in rows:
+        p = float(np.clip(np.median(end_accs), 0.02, 0.98))
+        tol = pooled + 3 * np.sqrt(p * (1 - p) / n_test_total)
+        assert abs(acc_hip - np.median(end_accs)) <= tol, (acc_hip, end_accs, tol)
+    print(name, "HIP distance / oracle self-distance per seed:", np.round([r[2] for r in rows], 2), "| pooled oracle accuracy spread %.4f" % pooled)
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -443,7 +464,9 @@ def test_cosim_gss(cuda):
     replacement branch at least once."""
     cfg = STEP_CASES["er_gss"]
     n_fill = n_repl = n_full = 0
-    gen = cosim(cfg, 6, cuda, sync_extra=lambda agent, oa: agent.buffer.update_method.buffer_score.copy_(oa.gss.score))
+    tasks, _ = make_stream(cfg)
+    stream = (np.concatenate([tasks[0][0], tasks[1][0]]), np.concatenate([tasks[0][1], tasks[1][1]]))   # 30 of class 0, then class 1
+    gen = cosim(cfg, 6, cuda, x_stream=stream, sync_extra=lambda agent, oa: agent.buffer.update_method.buffer_score.copy_(oa.gss.score))
     for it, ev, ol, chk in gen:
         assert chk["rng_equal"], "host RNG streams diverged at iteration %d" % it
         g, og = [e for t, e in ev if t == "gss"][0], ol["gss"]
