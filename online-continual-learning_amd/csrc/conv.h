@@ -50,11 +50,17 @@ struct ConvArgs {
     int TG, gpc, WS;            // taps per weight stage, stages per channel chunk, floats per stage buffer
     int flags;
     int n_splits;               // grid.y
+    // ---- conv_t_kernel (channels x pixels orientation, K-contiguous operands; plan.kind == 1) --------------------------
+    const float* wT;            // K-grouped weight pack [tap][Cin/4][WPT][4]
+    int C4tot, WPT;             // Cin/4 of the whole convolution; row stride (channels) of the pack
+    int Qc, Qpad;               // (tap, channel-quad) groups of one channel chunk; rounded up to whole rounds of 4
+    int QS, nstage, wres;       // groups per weight stage, stages per chunk; 1: all weights stay in LDS for the workgroup's lifetime
 };
 
 struct ConvPlan {
     ConvArgs a;
-    int W, MT, NT;              // MFMA tile width (16: 16x16x4, 32: 32x32x2) and tiles per wave
+    int kind;                   // 0: conv_gemm_kernel (pixels x channels tiles), 1: conv_t_kernel (channels x pixels, K-grouped operands)
+    int W, MT, NT;              // MFMA tile width (16: 16x16x4, 32: 32x32x2) and tiles per wave (kind 1: MT channel tiles, NT pixel tiles)
     int grid_x, grid_y;
     size_t lds_bytes;
 };
@@ -70,6 +76,8 @@ struct ConvGeomDesc {
     int WP;                     // weight pack row stride (0: the plan's own CoutP)
     int no_wreg;                // benchmarks: disable the register-resident-weights variant
     int force_W, force_MT, force_NT, force_bpc;   // 0 = planner's choice (benchmarks / tests)
+    int force_kind;             // 0 = planner's choice, 1 = conv_gemm_kernel, 2 = conv_t_kernel
+    int WPT;                    // row stride of the K-grouped pack (0: the plan's own CoutP)
 };
 
 int plan_conv(const ConvGeomDesc& g, ConvPlan* p);
@@ -122,10 +130,14 @@ int launch_wgrad_reduce(const WgradPlan& p, float* grad_oihw, int accumulate, hi
 // ---- weight packing -----------------------------------------------------------------------------------
 // fwd pack:   wf[t][ci][coP] = w[co][ci][t]          (ci padded with zero rows up to CinP)
 // dgrad pack: wd[t][co][ciP] = w[co][ci][t]
+// K-grouped packs (conv_t_kernel):
+// fwd:   wTf[t][ci/4][coP][ci%4] = w[co][ci][t]      dgrad: wTd[t][co/4][ciP][co%4] = w[co][ci][t]
 struct PackDesc {
     int64_t w_off;      // offset of the OIHW tensor in the flat parameter array
     int64_t f_off;      // offset in the pack arena (fwd), -1 = none
     int64_t d_off;      // offset in the pack arena (dgrad), -1 = none
+    int64_t tf_off;     // K-grouped fwd pack, -1 = none
+    int64_t td_off;     // K-grouped dgrad pack, -1 = none
     int Cout, Cin, ntaps, CinP, CoutP, CiP;
 };
 int launch_pack_weights(const float* params, float* arena, const PackDesc* descs_dev, int n_layers, int max_elems,

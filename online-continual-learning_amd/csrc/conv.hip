@@ -477,7 +477,325 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs a) {
     if (flags & EPI_STATS) flush_stats();
 }
 
+// =====================================================================================================
+// conv_t_kernel: channels x pixels orientation with K-grouped operands
+// =====================================================================================================
+// D[channel][pixel] tiles: the MFMA's A operand is the weight (row = output channel), B the input patch (column = output pixel).
+//  * K runs over (tap, channel quad) GROUPS q; a round of 4 MFMAs covers 4 groups, one per lane quarter g = lane >> 4, and MFMA
+//    j of the round multiplies channel 4*c4(q_g) + j.  Any one-to-one assignment of k slots works as long as A and B agree, and
+//    this one makes the 4 operands a lane needs for a round ONE 16-byte LDS read each: B from the pixel-major patch (channels
+//    contiguous), A from the K-grouped pack [q][channel][4].  Per round a wave issues 1 + NT + MT LDS reads for 4*MT*NT MFMAs
+//    (conv_gemm_kernel: 4*(MT+NT) 4-byte reads and their address arithmetic).
+//  * A lane's 4 accumulator registers are 4 CONSECUTIVE output channels of one pixel: the epilogue (statistics, folded BatchNorm,
+//    residual, mask, ReLU, accumulate) works on registers and stores 16-byte vectors straight to the NHWC tensor: no LDS
+//    transpose, no barriers after the MFMAs.
+//  * Weights of the small layers (<= kResidentBytes per channel split) are copied to LDS ONCE per persistent workgroup; the others
+//    stream through a double-buffered stage of QS groups, fetched one stage ahead into registers (as conv_gemm_kernel does).
+//  * BatchNorm statistics: fp32 per-lane partials over the workgroup's tiles, fp64 from the cross-lane reduction on, flushed with
+//    one fp64 atomic per channel per workgroup (8 replicas, as above).
+constexpr int kWPF = 4;                        // float4 weight-prefetch registers per thread (staged weights)
+constexpr size_t kResidentBytes = 80 * 1024;   // weights of one channel split kept in LDS for the workgroup's lifetime up to this
+
+template <int MT, int NT, int PF, bool RES>
+__global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    constexpr int BM = 64 * NT;                // pixels per workgroup tile (4 waves x NT pixel tiles of 16)
+    constexpr int COPW = 16 * MT;              // channels per workgroup (one channel split)
+    int* qoff = (int*)lds_raw;                 // [Qpad] patch offset (floats) of group q relative to a pixel's origin
+    int* qrow = qoff + a.Qpad;                 // [Qpad] row of the K-grouped pack (tap * C4tot + channel quad), -1: padding group
+    float* wl = (float*)(qrow + a.Qpad);       // resident: [Qpad][COPW][4]; staged: [2][QS][COPW][4]
+    float* patch = wl + (size_t)(RES ? a.Qpad : 2 * a.QS) * COPW * 4;   // [imgs][PR][PC][CP]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.y * COPW;
+    const int LP = a.LH * a.LW;
+    const int ntiles = a.groups * a.tiles_per_group;
+    if ((int)blockIdx.x >= ntiles) return;
+    const int kc4 = a.KC >> 2;
+    const int flags = a.flags;
+    {
+        const float inv_kc4 = 1.0f / (float)kc4;
+        for (int q = tid; q < a.Qpad; q += 256) {
+            int c4;
+            const int t = fdiv(q, kc4, inv_kc4, c4);
+            const bool ok = q < a.Qc;
+            qoff[q] = ok ? tap_sel(a.tpo, t) + 4 * c4 : 0;
+            qrow[q] = ok ? tap_sel(a.tw, t) * a.C4tot + c4 : -1;
+        }
+    }
+
+    const float inv_tpg = 1.0f / (float)a.tiles_per_group, inv_tpi = 1.0f / (float)a.tiles_per_img, inv_lw0 = 1.0f / (float)a.LW;
+    auto geom = [&](int tile) __attribute__((always_inline)) -> TileGeom {
+        TileGeom t;
+        int tg_, tp, rem;
+        t.grp = fdiv(tile, a.tiles_per_group, inv_tpg, tg_);
+        const int ti = fdiv(tg_, a.tiles_per_img, inv_tpi, tp);
+        t.img0 = t.grp * a.group_size + ti * a.imgs;
+        t.p0 = tp * a.ppi;
+        t.grp_end = min(a.N, (t.grp + 1) * a.group_size);
+        t.ly0 = fdiv(t.p0, a.LW, inv_lw0, rem);
+        const int pend = min(t.p0 + a.ppi, LP);
+        const int ly1 = fdiv(pend - 1, a.LW, inv_lw0, rem);
+        t.nrows = a.imgs > 1 ? min(a.imgs, t.grp_end - t.img0) * a.PR : (ly1 - t.ly0) * a.is + (a.max_dy - a.min_dy) + 1;
+        return t;
+    };
+
+    // ---- patch prefetch: as conv_gemm_kernel (units of one float4 along the channels, packed coordinates) ------------------
+    int pu_pos[PF];
+    {
+        int c4, pc;
+        const int pix = fdiv(tid, kc4, 1.0f / (float)kc4, c4);
+        int row = fdiv(pix, a.PC, 1.0f / (float)a.PC, pc);
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            int il = 0, pr = row;
+            if (a.imgs > 1) il = fdiv(row, a.PR, a.inv_PR, pr);
+            pu_pos[i] = (il << 24) | (pr << 16) | (pc << 8) | c4;
+            if (il >= 128 || pr >= 256) pu_pos[i] = 0x7fff0000;
+            c4 += a.d_c4;
+            pc += a.d_pc;
+            if (c4 >= kc4) { c4 -= kc4; pc += 1; }
+            row += a.d_row;
+            if (pc >= a.PC) { pc -= a.PC; row += 1; }
+        }
+    }
+    float4 pv[PF];
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in), rs_w = make_rsrc(a.wT);
+    auto load_patch = [&](const TileGeom& t, int c0) __attribute__((always_inline)) {
+        const int iy0 = t.ly0 * a.is + a.min_dy;
+        const int base = (((t.img0 * a.Hin + iy0) * a.Win + a.min_dx) * a.Cin + c0) * 4;
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int il = pu_pos[i] >> 24, pr = (pu_pos[i] >> 16) & 255, pc = (pu_pos[i] >> 8) & 255, c4 = pu_pos[i] & 255;
+            const int iy = iy0 + pr, ix = a.min_dx + pc;
+            const bool ok = (il * a.PR + pr < t.nrows) & (iy >= 0) & (iy < a.Hin) & (ix >= 0) & (ix < a.Win);
+            pv[i] = buf_load16(rs_in, ok ? base + (((il * a.Hin + pr) * a.Win + pc) * a.Cin + c4 * 4) * 4 : kOob);
+        }
+    };
+    auto store_patch = [&](const TileGeom& t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int il = pu_pos[i] >> 24, pr = (pu_pos[i] >> 16) & 255, pc = (pu_pos[i] >> 8) & 255, c4 = pu_pos[i] & 255;
+            const int row = il * a.PR + pr;
+            if (row < t.nrows) *(float4*)(patch + (row * a.PC + pc) * a.CP + c4 * 4) = pv[i];   // CP % 4 == 0: 16-byte aligned
+        }
+    };
+    TileGeom cur = geom(blockIdx.x);
+    load_patch(cur, 0);
+
+    // ---- weights ----------------------------------------------------------------------------------------------------------
+    __syncthreads();   // qoff / qrow visible
+    const int wcol_ok = a.WPT - n0;   // columns of this split that exist in the pack
+    if (RES) {
+        const int units = a.Qpad * COPW;
+        for (int u = tid; u < units; u += 256) {
+            const int q = u / COPW, c = u - q * COPW;
+            const int row = qrow[q];
+            const float4 v = buf_load16(rs_w, (row >= 0 && c < wcol_ok) ? ((row * a.WPT + n0 + c) * 4) * 4 : kOob);
+            *(float4*)(wl + (size_t)u * 4) = v;
+        }
+    }
+    // staged: stage s of chunk c0 covers groups [s*QS, s*QS + QS); unit u = tid + i*256 -> (group in stage, channel)
+    float4 wv[RES ? 1 : kWPF];
+    auto w_prefetch = [&](int s_, int c0_) __attribute__((always_inline)) {
+        const int q0 = s_ * a.QS;
+        const int c4base = c0_ >> 2;
+#pragma unroll
+        for (int i = 0; i < kWPF; ++i) {
+            const int u = tid + i * 256;
+            const int qq = u / COPW, c = u - qq * COPW;
+            const int q = q0 + qq;
+            const int row = (qq < a.QS && q < a.Qpad) ? qrow[q] : -1;
+            wv[i] = buf_load16(rs_w, (row >= 0 && c < wcol_ok) ? (((row + c4base) * a.WPT + n0 + c) * 4) * 4 : kOob);
+        }
+    };
+    auto w_commit = [&](int buf) __attribute__((always_inline)) {
+        float* dst = wl + (size_t)buf * a.QS * COPW * 4;
+#pragma unroll
+        for (int i = 0; i < kWPF; ++i) {
+            const int u = tid + i * 256;
+            if (u < a.QS * COPW) *(float4*)(dst + (size_t)u * 4) = wv[i];
+        }
+    };
+
+    const float inv_ppi = 1.0f / (float)a.ppi, inv_lw = 1.0f / (float)a.LW;
+    const int nchunks = a.Cin / a.KC;
+    float s1[MT][4], s2[MT][4];   // BatchNorm partial sums of this lane's channels over this workgroup's tiles
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s1[mt][e] = s2[mt][e] = 0.f;
+    int run_grp = -1;
+    auto flush_stats = [&]() __attribute__((always_inline)) {
+        // lanes with the same g hold the same channels for 16 different pixels: reduce over them, then over the 4 waves through
+        // LDS (`patch` is free here: the caller passed a barrier), then one fp64 atomic per channel and statistic
+        double* red = (double*)patch;   // [4 waves][2][COPW]
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                double x = (double)s1[mt][e], y = (double)s2[mt][e];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    x += __shfl_xor(x, o, 64);
+                    y += __shfl_xor(y, o, 64);
+                }
+                if (r16 == 0) {
+                    red[(wave * 2 + 0) * COPW + mt * 16 + 4 * g + e] = x;
+                    red[(wave * 2 + 1) * COPW + mt * 16 + 4 * g + e] = y;
+                }
+                s1[mt][e] = s2[mt][e] = 0.f;
+            }
+        __syncthreads();
+        if (tid < 2 * COPW && run_grp >= 0) {
+            const int which = tid / COPW, c = tid - which * COPW;
+            const int co = n0 + c;
+            if (co < a.Cout) {
+                const double v = (red[(0 * 2 + which) * COPW + c] + red[(1 * 2 + which) * COPW + c]) +
+                                 (red[(2 * 2 + which) * COPW + c] + red[(3 * 2 + which) * COPW + c]);
+                double* st_ = a.stats + (int64_t)(blockIdx.x % kStatReps) * a.stat_rep_stride;
+                atomicAdd(&st_[((int64_t)run_grp * 2 + which) * a.Cout + co], v);
+            }
+        }
+        __syncthreads();
+    };
+
+    int st = 0;
+    if (!RES) w_prefetch(0, 0);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int next_tile = tile + gridDim.x;
+        TileGeom nxt = cur;
+        if (next_tile < ntiles) nxt = geom(next_tile);
+        if ((flags & EPI_STATS) && cur.grp != run_grp) {   // block-uniform; a block's tiles come in ascending group order
+            if (run_grp >= 0) flush_stats();
+            run_grp = cur.grp;
+        }
+        // this lane's NT output pixels: LDS patch offset of the pixel's origin, output element offset (-1: not a pixel)
+        int pbase[NT], ooff[NT];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int r = wave * 16 * NT + nt * 16 + r16;
+            int pl, lx;
+            const int il = fdiv(r, a.ppi, inv_ppi, pl);
+            const int p = cur.p0 + pl;
+            const int n = cur.img0 + il;
+            const bool v = (il < a.imgs) & (n < cur.grp_end) & (p < LP);
+            const int ly = fdiv(p, a.LW, inv_lw, lx);
+            pbase[nt] = v ? ((il * a.PR + (ly - cur.ly0) * a.is) * a.PC + lx * a.is) * a.CP : 0;
+            ooff[nt] = v ? ((n * a.Hout + ly * a.os + a.oy0) * a.Wout + lx * a.os + a.ox0) * a.Cout : -1;
+        }
+        f32x4 acc[MT][NT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        auto rounds = [&](const float* wbase, int q0, int nq) __attribute__((always_inline)) {
+            const float* wb = wbase + (size_t)(g * COPW + r16) * 4;
+#pragma unroll 2
+            for (int rho = 0; rho < (nq >> 2); ++rho) {
+                const int po = qoff[q0 + 4 * rho + g];
+                float4 bv[NT], av[MT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bv[nt] = *(const float4*)(patch + pbase[nt] + po);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) av[mt] = *(const float4*)(wb + (size_t)rho * 4 * COPW * 4 + mt * 64);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].x, bv[nt].x, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].y, bv[nt].y, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].z, bv[nt].z, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].w, bv[nt].w, acc[mt][nt], 0, 0, 0);
+                    }
+            }
+        };
+
+        for (int chunk = 0; chunk < nchunks; ++chunk) {
+            const int c0 = chunk * a.KC;
+            __syncthreads();   // consumers of the previous patch are done
+            store_patch(cur);
+            if (chunk + 1 < nchunks) load_patch(cur, c0 + a.KC);
+            else if (next_tile < ntiles) load_patch(nxt, 0);
+            if (RES) {
+                __syncthreads();   // patch (and, the first time, the resident weights) visible
+                rounds(wl, 0, a.Qpad);
+            } else {
+                for (int s_ = 0; s_ < a.nstage; ++s_, ++st) {
+                    w_commit(st & 1);
+                    __syncthreads();   // stage st's weights (and the patch) visible; everyone is done with stage st-1
+                    {
+                        int ns = s_ + 1, nc0 = c0;
+                        if (ns >= a.nstage) { ns = 0; nc0 = c0 + a.KC; }
+                        if (nc0 >= a.Cin) nc0 = next_tile < ntiles ? 0 : -1;
+                        if (nc0 >= 0) w_prefetch(ns, nc0);
+                    }
+                    const int q0 = s_ * a.QS;
+                    rounds(wl + (size_t)(st & 1) * a.QS * COPW * 4, q0, min(a.QS, a.Qpad - q0));
+                }
+            }
+        }
+
+        // ---- epilogue from registers: lane (r16 = pixel, g) holds channels n0 + mt*16 + 4g .. +3 of its NT pixels -----------------
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const bool pv_ok = ooff[nt] >= 0;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int co = n0 + mt * 16 + 4 * g;
+                if (!pv_ok || co >= a.Cout) continue;
+                float4 v = make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
+                if (flags & EPI_STATS) {
+                    s1[mt][0] += v.x; s1[mt][1] += v.y; s1[mt][2] += v.z; s1[mt][3] += v.w;
+                    s2[mt][0] = fmaf(v.x, v.x, s2[mt][0]); s2[mt][1] = fmaf(v.y, v.y, s2[mt][1]);
+                    s2[mt][2] = fmaf(v.z, v.z, s2[mt][2]); s2[mt][3] = fmaf(v.w, v.w, s2[mt][3]);
+                }
+                float* op = a.out + (int64_t)ooff[nt] + co;
+                if (flags & EPI_AFFINE) {
+                    const float4 sc = *(const float4*)(a.scale + co), sh = *(const float4*)(a.shift + co);
+                    v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+                }
+                if (flags & EPI_RES) {
+                    const float4 r = *(const float4*)(a.res + (int64_t)ooff[nt] + co);
+                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                }
+                if (flags & EPI_RESMASK) {
+                    const float4 r = *(const float4*)(a.res + (int64_t)ooff[nt] + co);
+                    const float4 m = *(const float4*)(a.resmask + (int64_t)ooff[nt] + co);
+                    v.x += m.x > 0.f ? r.x : 0.f; v.y += m.y > 0.f ? r.y : 0.f; v.z += m.z > 0.f ? r.z : 0.f; v.w += m.w > 0.f ? r.w : 0.f;
+                }
+                if (flags & EPI_ACCUM) {
+                    const float4 o = *(const float4*)op;
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                }
+                if (flags & EPI_RELU) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+                *(float4*)op = v;
+            }
+        }
+        cur = nxt;
+    }
+    if ((flags & EPI_STATS) && run_grp >= 0) flush_stats();
+}
+
+#define OCL_CONVT_TILINGS(X) X(1, 1) X(2, 1) X(3, 1) X(4, 1) X(5, 1) X(1, 2) X(2, 2) X(3, 2) X(4, 2) X(5, 2)
 typedef void (*conv_fn_t)(const ConvArgs);
+static conv_fn_t convt_fn(int MT, int NT, int PF, int res) {
+#define OCL_CASE(M, N)                                                                              \
+    if (MT == M && NT == N) {                                                                       \
+        if (PF == 4) return res ? conv_t_kernel<M, N, 4, true> : conv_t_kernel<M, N, 4, false>;     \
+        if (PF == 8) return res ? conv_t_kernel<M, N, 8, true> : conv_t_kernel<M, N, 8, false>;     \
+    }
+    OCL_CONVT_TILINGS(OCL_CASE)
+#undef OCL_CASE
+    return nullptr;
+}
+static int convt_pf_for(int units) { return units <= 1024 ? 4 : 8; }
+
 // instantiated tilings (chosen from the kbench sweeps, profiles/): MFMA width x (MT, NT) x patch-prefetch depth
 #define OCL_CONV_TILINGS16(X) X(16, 1, 1) X(16, 1, 2) X(16, 1, 3) X(16, 1, 5) X(16, 2, 1) X(16, 2, 2) X(16, 2, 3) X(16, 4, 2)
 #define OCL_CONV_TILINGS32(X) X(32, 1, 1) X(32, 1, 2) X(32, 1, 3) X(32, 2, 1) X(32, 2, 2)
@@ -575,6 +893,104 @@ static size_t conv_tile_layout(const ConvGeomDesc& g, ConvArgs& a, int W, int MT
     return bytes;
 }
 
+// ---- conv_t_kernel layout: fills the tile-dependent fields for (MT channel tiles, NT pixel tiles); returns LDS bytes (0: no fit)
+static size_t convt_layout(const ConvGeomDesc& g, ConvArgs& a, int MT, int NT) {
+    const int nt16 = cdiv(g.Cout, 16);
+    const int splits = cdiv(nt16, MT);
+    const int COPW = 16 * MT;
+    a.n_splits = splits;
+    a.CoutP = splits * COPW;
+    a.group_size = g.N / g.groups;
+    const int LP = g.LH * g.LW;
+    const int BM = 64 * NT;
+    if (LP >= BM) {
+        a.imgs = 1; a.ppi = BM; a.tiles_per_img = cdiv(LP, BM);
+    } else {
+        a.imgs = std::min(BM / LP, a.group_size); a.ppi = LP; a.tiles_per_img = 1;
+    }
+    a.PC = (g.LW - 1) * g.is + (a.max_dx - a.min_dx) + 1;
+    const int rows_l = (a.imgs == 1 && LP >= BM) ? std::min(g.LH, (BM + g.LW - 2) / g.LW + 1) : g.LH;
+    a.PR = (rows_l - 1) * g.is + (a.max_dy - a.min_dy) + 1;
+    a.C4tot = g.Cin / 4;
+    size_t bytes = 0;
+    for (;;) {
+        for (int KC = g.Cin; KC >= 4; KC -= 4) {
+            if (g.Cin % KC) continue;
+            a.KC = KC;
+            a.CP = ((KC / 4) & 1) ? KC : KC + 4;     // 16-byte pixel slots, an odd number of them per pixel: b128 reads of 16 pixels spread over all banks
+            a.Qc = g.ntaps * (KC / 4);
+            a.Qpad = (int)round_up(a.Qc, 4);
+            const size_t w_all = (size_t)a.Qpad * COPW * 16;
+            a.wres = (KC == g.Cin && w_all <= kResidentBytes) ? 1 : 0;
+            a.QS = a.wres ? a.Qpad : std::min(a.Qpad, ((256 * kWPF) / COPW) & ~3);
+            a.nstage = cdiv(a.Qpad, a.QS);
+            const size_t patch_b = std::max((size_t)a.imgs * a.PR * a.PC * a.CP * 4, (size_t)8 * COPW * 8);
+            bytes = (size_t)2 * a.Qpad * 4 + (a.wres ? w_all : (size_t)2 * a.QS * COPW * 16) + patch_b;
+            const bool units_ok = a.imgs * a.PR * a.PC * (KC / 4) <= 256 * kConvPatchPF;
+            if (units_ok && bytes <= kLdsLimit - 2048 && (bytes <= 100 * 1024 || KC <= 20)) goto found;
+        }
+        if (a.imgs > 1) {   // shrink the tile (fewer images per workgroup) and retry
+            a.imgs -= 1;
+            continue;
+        }
+        return 0;
+    }
+found:
+    if (a.imgs > 127 || a.PR >= 256 || a.PC >= 256 || a.KC / 4 >= 256) return 0;
+    a.tiles_per_group = cdiv(a.group_size, a.imgs) * a.tiles_per_img;
+    return bytes;
+}
+
+static int conv_kind_default() {
+    static const int k = [] {
+        const char* e = getenv("OCL_CONV_T");
+        return e ? atoi(e) : 1;
+    }();
+    return k;
+}
+
+static int plan_conv_t(const ConvGeomDesc& g, ConvPlan* p) {
+    ConvArgs& a = p->a;
+    const int nt16 = cdiv(g.Cout, 16);
+    const int LPx = g.LH * g.LW;
+    const int64_t tiles64 = (int64_t)g.groups * (LPx >= 64 ? (int64_t)(g.N / g.groups) * cdiv(LPx, 64)
+                                                            : cdiv(g.N / g.groups, std::max(1, 64 / LPx)));
+    // channel tiles per workgroup: all of them up to 5 (a lane's A reads are reused NT times, its B reads MT times); fewer when
+    // the layer has too few pixel tiles to give every CU a workgroup
+    int MT = std::min(5, nt16);
+    if (nt16 > 5) MT = cdiv(nt16, cdiv(nt16, 5));                    // balanced splits (10 tiles -> 2 x 5)
+    while (MT > 1 && tiles64 * cdiv(nt16, MT) < 256) --MT;
+    if (nt16 > MT) MT = cdiv(nt16, cdiv(nt16, MT));
+    int NT = tiles64 * cdiv(nt16, MT) >= 2048 ? 2 : 1;
+    if (g.force_MT) MT = g.force_MT;
+    if (g.force_NT) NT = g.force_NT;
+    if (MT < 1 || MT > 5 || NT < 1 || NT > 2 || MT > nt16) return OCL_ERR_ARG;
+    size_t lds = convt_layout(g, a, MT, NT);
+    if (!lds && NT == 2 && !g.force_NT) { NT = 1; lds = convt_layout(g, a, MT, NT); }
+    if (!lds) return OCL_ERR_ARG;
+    p->kind = 1;
+    p->W = 16; p->MT = MT; p->NT = NT;
+    p->lds_bytes = lds;
+    a.WPT = g.WPT > 0 ? g.WPT : a.CoutP;
+    a.WP = a.WPT;
+    for (int t = 0; t < 9; ++t) a.tpo[t] = t < a.ntaps ? ((a.tdy[t] - a.min_dy) * a.PC + (a.tdx[t] - a.min_dx)) * a.CP : 0;
+    {
+        const int kc4 = a.KC / 4;
+        a.d_c4 = 256 % kc4;
+        const int d_pix = 256 / kc4;
+        a.d_pc = d_pix % a.PC;
+        a.d_row = d_pix / a.PC;
+        a.inv_PR = 1.0f / (float)a.PR;
+    }
+    a.groups = g.groups;
+    const int ntiles = g.groups * a.tiles_per_group;
+    int bpc = (int)std::min<size_t>(2, kLdsLimit / (lds + 512));
+    if (g.force_bpc) bpc = g.force_bpc;
+    p->grid_x = std::max(1, std::min(ntiles, (256 * std::max(1, bpc)) / a.n_splits));
+    p->grid_y = a.n_splits;
+    return OCL_OK;
+}
+
 int plan_conv(const ConvGeomDesc& g, ConvPlan* p) {
     memset(p, 0, sizeof(*p));
     ConvArgs& a = p->a;
@@ -592,6 +1008,16 @@ int plan_conv(const ConvGeomDesc& g, ConvPlan* p) {
         a.tdy[t] = g.tdy[t]; a.tdx[t] = g.tdx[t]; a.tw[t] = g.tw[t];
         a.min_dy = std::min(a.min_dy, g.tdy[t]); a.max_dy = std::max(a.max_dy, g.tdy[t]);
         a.min_dx = std::min(a.min_dx, g.tdx[t]); a.max_dx = std::max(a.max_dx, g.tdx[t]);
+    }
+    const int want_kind = g.force_kind ? g.force_kind - 1 : conv_kind_default();
+    if (want_kind == 1 && !g.force_W) {
+        if (plan_conv_t(g, p) == OCL_OK) return OCL_OK;
+        if (g.force_kind == 2) { set_error("plan_conv: no conv_t tiling for MT=%d NT=%d", g.force_MT, g.force_NT); return OCL_ERR_ARG; }
+        // fall through to conv_gemm_kernel with a clean plan
+        ConvArgs keep = a;
+        memset(p, 0, sizeof(*p));
+        a = keep;
+        a.n_splits = a.CoutP = a.group_size = a.imgs = a.ppi = a.tiles_per_img = a.PC = a.PR = a.KC = a.CP = 0;
     }
     // ---- tile choice ---------------------------------------------------------------------------------------------
     // Rules distilled from the kbench sweeps on MI355X (profiles/r1_kbench_conv_sweep*.txt):
@@ -678,6 +1104,7 @@ void geom_fwd(const ConvShape& c, int N, int groups, ConvGeomDesc* g) {
     g->Hout = c.Ho; g->Wout = c.Wo; g->Cout = c.Cout;
     g->LH = c.Ho; g->LW = c.Wo; g->os = 1; g->oy0 = 0; g->ox0 = 0; g->is = c.stride;
     g->WP = c.CoutP;
+    g->WPT = c.CoutP;
     const int pad = c.k == 3 ? 1 : 0;
     g->ntaps = c.k * c.k;
     for (int t = 0; t < g->ntaps; ++t) {
@@ -696,6 +1123,7 @@ void geom_dgrad(const ConvShape& c, int N, std::vector<ConvGeomDesc>* out) {
     g.Hout = c.Hin; g.Wout = c.Win; g.Cout = c.Cin;
     g.is = 1;
     g.WP = c.CiP;
+    g.WPT = c.CiP;
     if (c.stride == 1) {
         g.LH = c.Hin; g.LW = c.Win; g.os = 1;
         const int pad = c.k == 3 ? 1 : 0;
@@ -738,7 +1166,8 @@ void geom_dgrad(const ConvShape& c, int N, std::vector<ConvGeomDesc>* out) {
 
 int launch_conv(const ConvPlan& p, hipStream_t s) {
     const int pfu = conv_pf_for(p.a.imgs * p.a.PR * p.a.PC * (p.a.KC / 4));
-    conv_fn_t fn = p.a.wreg ? conv_fn_wreg(pfu) : conv_fn(p.W, p.MT, p.NT, pfu);
+    conv_fn_t fn = p.kind == 1 ? convt_fn(p.MT, p.NT, convt_pf_for(p.a.imgs * p.a.PR * p.a.PC * (p.a.KC / 4)), p.a.wres)
+                               : p.a.wreg ? conv_fn_wreg(pfu) : conv_fn(p.W, p.MT, p.NT, pfu);
     if (!fn) {
         set_error("launch_conv: no kernel for W=%d MT=%d NT=%d", p.W, p.MT, p.NT);
         return OCL_ERR_STATE;
@@ -1132,6 +1561,8 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const float* __restri
         const float v = params[d.w_off + e];
         if (d.f_off >= 0) arena[d.f_off + ((int64_t)t * d.CinP + ci) * d.CoutP + co] = v;
         if (d.d_off >= 0) arena[d.d_off + ((int64_t)t * d.Cout + co) * d.CiP + ci] = v;
+        if (d.tf_off >= 0) arena[d.tf_off + ((((int64_t)t * (d.CinP >> 2) + (ci >> 2)) * d.CoutP + co) << 2) + (ci & 3)] = v;
+        if (d.td_off >= 0) arena[d.td_off + ((((int64_t)t * (d.Cout >> 2) + (co >> 2)) * d.CiP + ci) << 2) + (co & 3)] = v;
     }
 }
 
@@ -1822,6 +2253,11 @@ int conv_kernels_init() {
                 OCL_HIP(hipFuncSetAttribute((const void*)wgrad_fn(m, n, pf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     for (int pf = 4; pf <= 8; pf += 2)
         OCL_HIP(hipFuncSetAttribute((const void*)conv_fn_wreg(pf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+    for (int m = 1; m <= 5; ++m)
+        for (int n = 1; n <= 2; ++n)
+            for (int pf = 4; pf <= 8; pf += 4)
+                for (int res = 0; res < 2; ++res)
+                    OCL_HIP(hipFuncSetAttribute((const void*)convt_fn(m, n, pf, res), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     done = true;
     return OCL_OK;
 }

@@ -110,12 +110,30 @@ static double max_diff(const float* a, const float* b, size_t n) {
     return m;
 }
 
+// K-grouped pack [tap][Cin/4][WP][4] of the same weights as the row pack [tap][Cin][WP] (9 taps)
+static float* make_packT(const float* w_dev, int Cin, int WP) {
+    const size_t n = (size_t)9 * Cin * WP;
+    std::vector<float> h(n), t(n);
+    CK(hipMemcpy(h.data(), w_dev, n * 4, hipMemcpyDeviceToHost));
+    for (int tap = 0; tap < 9; ++tap)
+        for (int ci = 0; ci < Cin; ++ci)
+            for (int co = 0; co < WP; ++co)
+                t[((((size_t)tap * (Cin / 4) + ci / 4) * WP + co) << 2) + (ci & 3)] = h[((size_t)tap * Cin + ci) * WP + co];
+    float* d;
+    CK(hipMalloc(&d, n * 4));
+    CK(hipMemcpy(d, t.data(), n * 4, hipMemcpyHostToDevice));
+    return d;
+}
+
 static void bench_geom(const char* lname, const char* kind, ConvGeomDesc g, const float* in, const float* w, float* out,
                        float* out_ref, double* stats, int flags, double flops, size_t out_elems, bool sweep) {
     ConvPlan p0;
+    g.force_kind = 1;   // reference result: conv_gemm_kernel
     OK(plan_conv(g, &p0));
+    g.WPT = g.WP;
+    float* wT = make_packT(w, g.Cin, g.WP);
     auto run = [&](ConvPlan p, float* o) {
-        p.a.in = in; p.a.w = w; p.a.out = o; p.a.flags = flags; p.a.stats = stats; p.a.stat_rep_stride = 8 * 2 * 1024;
+        p.a.in = in; p.a.w = w; p.a.wT = wT; p.a.out = o; p.a.flags = flags; p.a.stats = stats; p.a.stat_rep_stride = 8 * 2 * 1024;
         OK(launch_conv(p, 0));
     };
     CK(hipMemset(out_ref, 0, out_elems * 4));
@@ -135,7 +153,48 @@ static void bench_geom(const char* lname, const char* kind, ConvGeomDesc g, cons
         const double t = time_us([&] { run(pn, out); });
         printf("    (weights staged through LDS instead of registers: %7.1f us, maxdiff vs register variant %.2e)\n", t, d);
     }
+    {   // conv_t_kernel: planner's choice and (sweep) every admissible (MT, NT)
+        double* stats2;
+        CK(hipMalloc(&stats2, kStatReps * 8 * 2 * 1024 * 8));
+        for (int mt = 0; mt <= (sweep ? 5 : 0); ++mt)
+            for (int nt = (mt ? 1 : 0); nt <= (mt ? 2 : 0); ++nt) {
+                ConvGeomDesc gt = g;
+                gt.force_kind = 2; gt.force_MT = mt; gt.force_NT = nt;
+                ConvPlan pt;
+                if (plan_conv(gt, &pt) != OCL_OK) continue;
+                CK(hipMemset(out, 0, out_elems * 4));
+                CK(hipMemset(stats2, 0, kStatReps * 8 * 2 * 1024 * 8));
+                CK(hipMemset(stats, 0, kStatReps * 8 * 2 * 1024 * 8));
+                run(p0, out_ref);
+                double* keep = stats;
+                stats = stats2;
+                run(pt, out);
+                stats = keep;
+                const double d = max_diff(out, out_ref, out_elems);
+                double ds = 0.0;
+                if (flags & EPI_STATS) {   // statistics: sum the replicas of both runs
+                    std::vector<double> a(kStatReps * 8 * 2 * 1024), b(a.size());
+                    CK(hipMemcpy(a.data(), stats, a.size() * 8, hipMemcpyDeviceToHost));
+                    CK(hipMemcpy(b.data(), stats2, b.size() * 8, hipMemcpyDeviceToHost));
+                    for (int i = 0; i < g.groups * 2 * g.Cout; ++i) {
+                        double x = 0, y = 0;
+                        for (int r = 0; r < kStatReps; ++r) { x += a[(size_t)r * 8 * 2 * 1024 + i]; y += b[(size_t)r * 8 * 2 * 1024 + i]; }
+                        ds = fmax(ds, fabs(x - y) / (1.0 + fabs(x)));
+                    }
+                }
+                double* keep2 = stats;
+                stats = stats2;
+                const double t = time_us([&] { run(pt, out); });
+                stats = keep2;
+                printf("    conv_t%s MT=%d NT=%d grid=%5dx%d lds=%6zu KC=%3d Q=%3d QS=%3d res=%d  %7.1f us %6.1f TF/s  maxdiff=%.2e statdiff=%.1e%s\n",
+                       mt ? "      " : " (auto)", pt.MT, pt.NT, pt.grid_x, pt.grid_y, pt.lds_bytes, pt.a.KC, pt.a.Qc, pt.a.QS, pt.a.wres, t,
+                       flops / t * 1e-6, d, ds, (d > 1e-3 || ds > 1e-6) ? "  <-- MISMATCH" : "");
+            }
+        CK(hipFree(stats2));
+    }
+    CK(hipFree(wT));
     if (!sweep) return;
+    g.force_kind = 1;
     const int MTs[3] = {1, 2, 4};
     const int ntile16 = (g.Cout + 15) / 16;
     for (int W = 16; W <= 32; W += 16)
@@ -143,6 +202,7 @@ static void bench_geom(const char* lname, const char* kind, ConvGeomDesc g, cons
         for (int NT = 1; NT <= std::min(5, ntile16); ++NT)
           for (int bpc = 1; bpc <= 2; ++bpc) {
             ConvGeomDesc gf = g;
+            gf.force_kind = 1;
             gf.force_W = W;
             gf.force_MT = MTs[mi];
             gf.force_NT = NT;

@@ -36,6 +36,7 @@ struct ConvInfo : ConvShape {
     int w_t;          // weight tensor index
     int bn;           // following BatchNorm
     int64_t f_off, d_off;  // pack arena offsets (floats)
+    int64_t tf_off, td_off;  // K-grouped packs (conv_t_kernel)
     int64_t y_off;    // raw output inside a slot (floats)
 };
 struct BlockInfo {
@@ -254,13 +255,20 @@ static int build_layout(ocl_net* n) {
         cv.CoutP = pack_width(cv.Cout);
         cv.f_off = pk;
         pk += (int64_t)cv.k * cv.k * cv.CinT * cv.CoutP;
+        pk = align_up(pk, 64);
+        cv.tf_off = pk;
+        pk += (int64_t)cv.k * cv.k * cv.CinT * cv.CoutP;
         if (cv.Cin != 3) {
             cv.CiP = pack_width(cv.Cin);
             cv.d_off = pk;
             pk += (int64_t)cv.k * cv.k * cv.Cout * cv.CiP;
+            pk = align_up(pk, 64);
+            cv.td_off = pk;
+            pk += (int64_t)cv.k * cv.k * cv.Cout * cv.CiP;
         } else {
             cv.CiP = 0;
             cv.d_off = -1;
+            cv.td_off = -1;
         }
         pk = align_up(pk, 64);
     }
@@ -416,6 +424,8 @@ static int upload_descs(ocl_net* n, hipStream_t s) {
         pd[i].w_off = n->tensors[c.w_t].off;
         pd[i].f_off = c.f_off;
         pd[i].d_off = c.d_off;
+        pd[i].tf_off = c.tf_off;
+        pd[i].td_off = c.td_off;
         pd[i].Cout = c.Cout;
         pd[i].Cin = c.Cin;
         pd[i].ntaps = c.k * c.k;
@@ -445,11 +455,12 @@ static const BnFoldDesc* fold_descs(const ocl_net* n) {
     return (const BnFoldDesc*)(n->ws + n->off_descs + align_up((int64_t)(n->convs.size() * sizeof(PackDesc)), 64));
 }
 
-static int run_conv(ocl_net* n, ConvPlan p, const float* in, const float* w, float* out, int flags, double* stats,
+static int run_conv(ocl_net* n, ConvPlan p, const float* in, const float* w, const float* wT, float* out, int flags, double* stats,
                     const float* scale, const float* shift, const float* res, const float* resmask, hipStream_t s) {
     p.a.stat_rep_stride = n->stats_rep_stride;
     p.a.in = in;
     p.a.w = w;
+    p.a.wT = wT;
     p.a.out = out;
     p.a.flags = flags;
     p.a.stats = stats;
@@ -743,7 +754,7 @@ static int trunk_forward_train(ocl_net* n, PlanSet* ps, const float* P, float* S
     };
     auto conv_stats = [&](int conv_i, const float* in, hipStream_t st) -> int {
         const ConvInfo& c = n->convs[conv_i];
-        return run_conv(n, ps->fwd[conv_i], in, pack + c.f_off, at(c.y_off, c), EPI_STATS, stats + n->bns[c.bn].arena_off, nullptr,
+        return run_conv(n, ps->fwd[conv_i], in, pack + c.f_off, pack + c.tf_off, at(c.y_off, c), EPI_STATS, stats + n->bns[c.bn].arena_off, nullptr,
                         nullptr, nullptr, nullptr, st);
     };
     const ConvInfo& c0 = n->convs[0];
@@ -878,7 +889,7 @@ int ocl_net_forward(ocl_net* n, const float* x, int N, int groups, uint32_t flag
             const ConvInfo& c = n->convs[conv_i];
             const BnInfo& b = n->bns[c.bn];
             int fl = EPI_AFFINE | (res ? EPI_RES : 0) | (relu ? EPI_RELU : 0);
-            return run_conv(n, ps->fwd[conv_i], in, pack + c.f_off, o, fl, nullptr, fold + b.stat_off, fold + b.stat_off + b.C, res,
+            return run_conv(n, ps->fwd[conv_i], in, pack + c.f_off, pack + c.tf_off, o, fl, nullptr, fold + b.stat_off, fold + b.stat_off + b.C, res,
                             nullptr, s);
         };
         float* bufs[4] = {n->gbuf(0), n->gbuf(1), n->gbuf(2), n->gbuf(3)};
@@ -1017,7 +1028,7 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
         const ConvInfo& c = n->convs[conv_i];
         for (auto& p : ps->dgrad[conv_i]) {
             int fl = extra_flags | (res ? (resmask ? EPI_RESMASK : EPI_RES) : 0);
-            int r = run_conv(n, p, dy, pack + c.d_off, dx, fl, nullptr, nullptr, nullptr, res, resmask, s);
+            int r = run_conv(n, p, dy, pack + c.d_off, pack + c.td_off, dx, fl, nullptr, nullptr, nullptr, res, resmask, s);
             if (r) return r;
         }
         return OCL_OK;

@@ -543,8 +543,10 @@ def test_eval_mode_gradient_vs_oracle(cuda):
                 assert torch.equal(sd2[k].cpu(), sd[k]), "eval-mode tape touched %s" % k
     stack = torch.stack([grads[0], grads[1], -grads[0] + 0.5 * grads[1]])
     got = float(ops.cosine_max(stack, grads[1]).cpu())
-    ref = float(max(O.cosine_similarity(stack.cpu(), grads[1].cpu().unsqueeze(0))))
-    assert abs(got - ref) < 1e-5 and abs(got - 1.0) < 1e-5
+    ref32 = float(max(O.cosine_similarity(stack.cpu(), grads[1].cpu().unsqueeze(0))))
+    ref64 = float(max(O.cosine_similarity(stack.cpu().double(), grads[1].cpu().double().unsqueeze(0))))
+    # the kernel accumulates the 10^6-term dot products in fp64; torch.mm / norm in fp32 lose ~2e-5 on a vector against itself
+    assert abs(got - ref64) < 1e-6 and abs(got - ref32) < 1e-4 and abs(got - 1.0) < 1e-6
 
 
 # ---------------------------------------------------------------------------------------------------------------------
