@@ -55,6 +55,9 @@ struct ConvArgs {
     int C4tot, WPT;             // Cin/4 of the whole convolution; row stride (channels) of the pack
     int Qc, Qpad;               // (tap, channel-quad) groups of one channel chunk; rounded up to whole rounds of 4
     int QS, nstage, wres;       // groups per weight stage, stages per chunk; 1: all weights stay in LDS for the workgroup's lifetime
+    int aligned;                // 1: every tile starts at a lattice row and holds whole rows / whole images: a lane's pixel geometry is tile-invariant
+    unsigned m_tpg, m_tpi, m_lw, m_ppi, m_kc4, m_pc, m_pr;   // ceil(2^32 / d) of the plan's divisors (exact quotients by one v_mul_hi)
+    unsigned long long* trace;  // measurement only (kbench): per workgroup 64 s_memtime stamps of wave 0 at the phase boundaries
 };
 
 struct ConvPlan {

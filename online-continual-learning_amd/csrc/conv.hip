@@ -493,15 +493,23 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs a) {
 //    stream through a double-buffered stage of QS groups, fetched one stage ahead into registers (as conv_gemm_kernel does).
 //  * BatchNorm statistics: fp32 per-lane partials over the workgroup's tiles, fp64 from the cross-lane reduction on, flushed with
 //    one fp64 atomic per channel per workgroup (8 replicas, as above).
+// x / d for a plan constant d through its precomputed M = ceil(2^32 / d): exact for x * d < 2^32 (checked by the planner)
+__device__ __forceinline__ int mdiv(int x, unsigned M, int d, int& rem) {
+    const int q = d == 1 ? x : (int)__umulhi((unsigned)x, M);
+    rem = x - q * d;
+    return q;
+}
 constexpr int kWPF = 4;                        // float4 weight-prefetch registers per thread (staged weights)
 constexpr size_t kResidentBytes = 80 * 1024;   // weights of one channel split kept in LDS for the workgroup's lifetime up to this
+
+constexpr int kMaxWgTiles = 64;                // tile descriptors a workgroup keeps in LDS
 
 template <int MT, int NT, int PF, bool RES>
 __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    constexpr int BM = 64 * NT;                // pixels per workgroup tile (4 waves x NT pixel tiles of 16)
     constexpr int COPW = 16 * MT;              // channels per workgroup (one channel split)
-    int* qoff = (int*)lds_raw;                 // [Qpad] patch offset (floats) of group q relative to a pixel's origin
+    int* tdesc = (int*)lds_raw;                // [kMaxWgTiles][8] per-tile geometry of this workgroup's tile range
+    int* qoff = tdesc + kMaxWgTiles * 8;       // [Qpad] patch offset (floats) of group q relative to a pixel's origin
     int* qrow = qoff + a.Qpad;                 // [Qpad] row of the K-grouped pack (tap * C4tot + channel quad), -1: padding group
     float* wl = (float*)(qrow + a.Qpad);       // resident: [Qpad][COPW][4]; staged: [2][QS][COPW][4]
     float* patch = wl + (size_t)(RES ? a.Qpad : 2 * a.QS) * COPW * 4;   // [imgs][PR][PC][CP]
@@ -510,49 +518,66 @@ __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
     const int r16 = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.y * COPW;
     const int LP = a.LH * a.LW;
-    const int ntiles = a.groups * a.tiles_per_group;
-    if ((int)blockIdx.x >= ntiles) return;
+    const int ntiles_all = a.groups * a.tiles_per_group;
+    // contiguous tile range of this workgroup: neighbouring tiles share halo rows (L2) and one BatchNorm group
+    const int t_begin = (int)(((int64_t)blockIdx.x * ntiles_all) / gridDim.x), t_end = (int)(((int64_t)(blockIdx.x + 1) * ntiles_all) / gridDim.x);
+    const int nwt = t_end - t_begin;
+    if (nwt <= 0) return;
     const int kc4 = a.KC >> 2;
     const int flags = a.flags;
-    {
-        const float inv_kc4 = 1.0f / (float)kc4;
-        for (int q = tid; q < a.Qpad; q += 256) {
-            int c4;
-            const int t = fdiv(q, kc4, inv_kc4, c4);
-            const bool ok = q < a.Qc;
-            qoff[q] = ok ? tap_sel(a.tpo, t) + 4 * c4 : 0;
-            qrow[q] = ok ? tap_sel(a.tw, t) * a.C4tot + c4 : -1;
-        }
+    int tr_n = 0;
+    auto stamp = [&]() __attribute__((always_inline)) {
+        if (a.trace && tid == 0 && tr_n < 64) a.trace[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 64 + tr_n++] = __builtin_amdgcn_s_memtime();
+    };
+    stamp();   // 0: start
+    // ---- tables: K groups, and the geometry of every tile of this workgroup (computed in parallel, read back as plain data) ------
+    for (int q = tid; q < a.Qpad; q += 256) {
+        int c4;
+        const int t = mdiv(q, a.m_kc4, kc4, c4);
+        const bool ok = q < a.Qc;
+        qoff[q] = ok ? tap_sel(a.tpo, t) + 4 * c4 : 0;
+        qrow[q] = ok ? tap_sel(a.tw, t) * a.C4tot + c4 : -1;
+    }
+    if (tid < nwt) {
+        const int tile = t_begin + tid;
+        int tg_, tp, rem;
+        const int grp = mdiv(tile, a.m_tpg, a.tiles_per_group, tg_);
+        const int ti = mdiv(tg_, a.m_tpi, a.tiles_per_img, tp);
+        const int img0 = grp * a.group_size + ti * a.imgs;
+        const int p0 = tp * a.ppi;
+        const int grp_end = min(a.N, (grp + 1) * a.group_size);
+        const int ly0 = mdiv(p0, a.m_lw, a.LW, rem);
+        const int pend = min(p0 + a.ppi, LP);
+        const int ly1 = mdiv(pend - 1, a.m_lw, a.LW, rem);
+        const int nimg = min(a.imgs, grp_end - img0);
+        const int nrows = a.imgs > 1 ? nimg * a.PR : (ly1 - ly0) * a.is + (a.max_dy - a.min_dy) + 1;
+        const int iy0 = ly0 * a.is + a.min_dy;
+        int* d = tdesc + tid * 8;
+        d[0] = (((img0 * a.Hin + iy0) * a.Win + a.min_dx) * a.Cin) * 4;                         // input byte offset of the patch origin
+        d[1] = iy0;
+        d[2] = nrows;
+        d[3] = ((img0 * a.Hout + ly0 * a.os + a.oy0) * a.Wout + a.ox0) * a.Cout;                  // output element offset of the tile origin
+        d[4] = nimg;
+        d[5] = grp;
+        d[6] = p0;
+        d[7] = img0 | (ly0 << 20);
     }
 
-    const float inv_tpg = 1.0f / (float)a.tiles_per_group, inv_tpi = 1.0f / (float)a.tiles_per_img, inv_lw0 = 1.0f / (float)a.LW;
-    auto geom = [&](int tile) __attribute__((always_inline)) -> TileGeom {
-        TileGeom t;
-        int tg_, tp, rem;
-        t.grp = fdiv(tile, a.tiles_per_group, inv_tpg, tg_);
-        const int ti = fdiv(tg_, a.tiles_per_img, inv_tpi, tp);
-        t.img0 = t.grp * a.group_size + ti * a.imgs;
-        t.p0 = tp * a.ppi;
-        t.grp_end = min(a.N, (t.grp + 1) * a.group_size);
-        t.ly0 = fdiv(t.p0, a.LW, inv_lw0, rem);
-        const int pend = min(t.p0 + a.ppi, LP);
-        const int ly1 = fdiv(pend - 1, a.LW, inv_lw0, rem);
-        t.nrows = a.imgs > 1 ? min(a.imgs, t.grp_end - t.img0) * a.PR : (ly1 - t.ly0) * a.is + (a.max_dy - a.min_dy) + 1;
-        return t;
-    };
-
-    // ---- patch prefetch: as conv_gemm_kernel (units of one float4 along the channels, packed coordinates) ------------------
-    int pu_pos[PF];
+    // ---- per-thread patch units (float4 along the channels): tile-invariant pieces ------------------------------------------------
+    int pu_goff[PF], pu_lds[PF], pu_rp[PF];   // global byte offset from the patch origin; LDS float offset; row | pr << 16 (row = il*PR + pr)
     {
         int c4, pc;
-        const int pix = fdiv(tid, kc4, 1.0f / (float)kc4, c4);
-        int row = fdiv(pix, a.PC, 1.0f / (float)a.PC, pc);
+        const int pix = mdiv(tid, a.m_kc4, kc4, c4);
+        int row = mdiv(pix, a.m_pc, a.PC, pc);
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
             int il = 0, pr = row;
-            if (a.imgs > 1) il = fdiv(row, a.PR, a.inv_PR, pr);
-            pu_pos[i] = (il << 24) | (pr << 16) | (pc << 8) | c4;
-            if (il >= 128 || pr >= 256) pu_pos[i] = 0x7fff0000;
+            if (a.imgs > 1) il = mdiv(row, a.m_pr, a.PR, pr);
+            const int ix = a.min_dx + pc;
+            const bool xok = (ix >= 0) & (ix < a.Win);            // columns of the halo outside the image: zeros (never loaded, still stored)
+            pu_goff[i] = xok ? (((il * a.Hin + pr) * a.Win + pc) * a.Cin + c4 * 4) * 4 : -1;
+            pu_lds[i] = (row * a.PC + pc) * a.CP + c4 * 4;
+            pu_rp[i] = ((il < 128) & (pr < 256)) ? (row | (pr << 16)) : 0x7fff;   // row 0x7fff: past every tile's last row
             c4 += a.d_c4;
             pc += a.d_pc;
             if (c4 >= kc4) { c4 -= kc4; pc += 1; }
@@ -562,38 +587,42 @@ __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
     }
     float4 pv[PF];
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in), rs_w = make_rsrc(a.wT);
-    auto load_patch = [&](const TileGeom& t, int c0) __attribute__((always_inline)) {
-        const int iy0 = t.ly0 * a.is + a.min_dy;
-        const int base = (((t.img0 * a.Hin + iy0) * a.Win + a.min_dx) * a.Cin + c0) * 4;
+    __syncthreads();   // tables visible
+    auto load_patch = [&](int k, int c0) __attribute__((always_inline)) {
+        const int4 d = *(const int4*)(tdesc + k * 8);   // in_base, iy0, nrows, obase
+        const int base = d.x + c0 * 4;
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
-            const int il = pu_pos[i] >> 24, pr = (pu_pos[i] >> 16) & 255, pc = (pu_pos[i] >> 8) & 255, c4 = pu_pos[i] & 255;
-            const int iy = iy0 + pr, ix = a.min_dx + pc;
-            const bool ok = (il * a.PR + pr < t.nrows) & (iy >= 0) & (iy < a.Hin) & (ix >= 0) & (ix < a.Win);
-            pv[i] = buf_load16(rs_in, ok ? base + (((il * a.Hin + pr) * a.Win + pc) * a.Cin + c4 * 4) * 4 : kOob);
+            const int row = pu_rp[i] & 0xffff, pr = pu_rp[i] >> 16;
+            const bool ok = (row < d.z) & ((unsigned)(d.y + pr) < (unsigned)a.Hin) & (pu_goff[i] >= 0);
+            pv[i] = buf_load16(rs_in, ok ? base + pu_goff[i] : kOob);
         }
     };
-    auto store_patch = [&](const TileGeom& t) __attribute__((always_inline)) {
+    auto store_patch = [&](int nrows) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            const int il = pu_pos[i] >> 24, pr = (pu_pos[i] >> 16) & 255, pc = (pu_pos[i] >> 8) & 255, c4 = pu_pos[i] & 255;
-            const int row = il * a.PR + pr;
-            if (row < t.nrows) *(float4*)(patch + (row * a.PC + pc) * a.CP + c4 * 4) = pv[i];   // CP % 4 == 0: 16-byte aligned
-        }
+        for (int i = 0; i < PF; ++i)
+            if ((pu_rp[i] & 0xffff) < nrows) *(float4*)(patch + pu_lds[i]) = pv[i];   // CP % 4 == 0: 16-byte aligned
     };
-    TileGeom cur = geom(blockIdx.x);
-    load_patch(cur, 0);
+    load_patch(0, 0);
 
     // ---- weights ----------------------------------------------------------------------------------------------------------
-    __syncthreads();   // qoff / qrow visible
     const int wcol_ok = a.WPT - n0;   // columns of this split that exist in the pack
-    if (RES) {
+    if (RES) {   // 8 loads in flight per thread
         const int units = a.Qpad * COPW;
-        for (int u = tid; u < units; u += 256) {
-            const int q = u / COPW, c = u - q * COPW;
-            const int row = qrow[q];
-            const float4 v = buf_load16(rs_w, (row >= 0 && c < wcol_ok) ? ((row * a.WPT + n0 + c) * 4) * 4 : kOob);
-            *(float4*)(wl + (size_t)u * 4) = v;
+        for (int u0 = tid; u0 < units; u0 += 256 * 8) {
+            float4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int u = u0 + i * 256;
+                const int q = min(u, units - 1) / COPW, c = min(u, units - 1) - q * COPW;
+                const int row = qrow[q];
+                v[i] = buf_load16(rs_w, (u < units && row >= 0 && c < wcol_ok) ? ((row * a.WPT + n0 + c) * 4) * 4 : kOob);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int u = u0 + i * 256;
+                if (u < units) *(float4*)(wl + (size_t)u * 4) = v[i];
+            }
         }
     }
     // staged: stage s of chunk c0 covers groups [s*QS, s*QS + QS); unit u = tid + i*256 -> (group in stage, channel)
@@ -602,7 +631,7 @@ __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
         const int q0 = s_ * a.QS;
         const int c4base = c0_ >> 2;
 #pragma unroll
-        for (int i = 0; i < kWPF; ++i) {
+        for (int i = 0; i < (RES ? 1 : kWPF); ++i) {
             const int u = tid + i * 256;
             const int qq = u / COPW, c = u - qq * COPW;
             const int q = q0 + qq;
@@ -613,13 +642,12 @@ __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
     auto w_commit = [&](int buf) __attribute__((always_inline)) {
         float* dst = wl + (size_t)buf * a.QS * COPW * 4;
 #pragma unroll
-        for (int i = 0; i < kWPF; ++i) {
+        for (int i = 0; i < (RES ? 1 : kWPF); ++i) {
             const int u = tid + i * 256;
             if (u < a.QS * COPW) *(float4*)(dst + (size_t)u * 4) = wv[i];
         }
     };
 
-    const float inv_ppi = 1.0f / (float)a.ppi, inv_lw = 1.0f / (float)a.LW;
     const int nchunks = a.Cin / a.KC;
     float s1[MT][4], s2[MT][4];   // BatchNorm partial sums of this lane's channels over this workgroup's tiles
 #pragma unroll
@@ -628,23 +656,23 @@ __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
         for (int e = 0; e < 4; ++e) s1[mt][e] = s2[mt][e] = 0.f;
     int run_grp = -1;
     auto flush_stats = [&]() __attribute__((always_inline)) {
-        // lanes with the same g hold the same channels for 16 different pixels: reduce over them, then over the 4 waves through
-        // LDS (`patch` is free here: the caller passed a barrier), then one fp64 atomic per channel and statistic
+        // lanes with the same g hold the same channels for 16 different pixels: fp32 butterfly over them (a lane's partial covers at
+        // most a few dozen values), then fp64: the 4 waves through LDS (`patch` is free here: a barrier precedes), one atomic per channel
         double* red = (double*)patch;   // [4 waves][2][COPW]
         __syncthreads();
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                double x = (double)s1[mt][e], y = (double)s2[mt][e];
+                float x = s1[mt][e], y = s2[mt][e];
 #pragma unroll
                 for (int o = 1; o < 16; o <<= 1) {
                     x += __shfl_xor(x, o, 64);
                     y += __shfl_xor(y, o, 64);
                 }
                 if (r16 == 0) {
-                    red[(wave * 2 + 0) * COPW + mt * 16 + 4 * g + e] = x;
-                    red[(wave * 2 + 1) * COPW + mt * 16 + 4 * g + e] = y;
+                    red[(wave * 2 + 0) * COPW + mt * 16 + 4 * g + e] = (double)x;
+                    red[(wave * 2 + 1) * COPW + mt * 16 + 4 * g + e] = (double)y;
                 }
                 s1[mt][e] = s2[mt][e] = 0.f;
             }
@@ -662,29 +690,53 @@ __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
         __syncthreads();
     };
 
+    // the lane's NT pixels relative to the tile origin (aligned plans: tile-invariant)
+    int loc_p[NT], loc_o[NT], loc_il[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int r = wave * 16 * NT + nt * 16 + r16;
+        int pl, lx;
+        const int il = mdiv(r, a.m_ppi, a.ppi, pl);
+        const int ly = mdiv(pl, a.m_lw, a.LW, lx);
+        loc_il[nt] = il;
+        loc_p[nt] = ((il * a.PR + ly * a.is) * a.PC + lx * a.is) * a.CP;
+        loc_o[nt] = ((il * a.Hout + ly * a.os) * a.Wout + lx * a.os) * a.Cout;
+    }
+
     int st = 0;
     if (!RES) w_prefetch(0, 0);
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int next_tile = tile + gridDim.x;
-        TileGeom nxt = cur;
-        if (next_tile < ntiles) nxt = geom(next_tile);
-        if ((flags & EPI_STATS) && cur.grp != run_grp) {   // block-uniform; a block's tiles come in ascending group order
+    stamp();   // 1: set-up done (resident weights issued)
+    for (int k = 0; k < nwt; ++k) {
+        const int4 d0 = *(const int4*)(tdesc + k * 8);       // in_base, iy0, nrows, obase
+        const int4 d1 = *(const int4*)(tdesc + k * 8 + 4);   // nimg, grp, p0, img0 | ly0 << 20
+        if ((flags & EPI_STATS) && d1.y != run_grp) {   // block-uniform; the tile range is in ascending group order
             if (run_grp >= 0) flush_stats();
-            run_grp = cur.grp;
+            run_grp = d1.y;
         }
         // this lane's NT output pixels: LDS patch offset of the pixel's origin, output element offset (-1: not a pixel)
         int pbase[NT], ooff[NT];
+        if (a.aligned) {
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int r = wave * 16 * NT + nt * 16 + r16;
-            int pl, lx;
-            const int il = fdiv(r, a.ppi, inv_ppi, pl);
-            const int p = cur.p0 + pl;
-            const int n = cur.img0 + il;
-            const bool v = (il < a.imgs) & (n < cur.grp_end) & (p < LP);
-            const int ly = fdiv(p, a.LW, inv_lw, lx);
-            pbase[nt] = v ? ((il * a.PR + (ly - cur.ly0) * a.is) * a.PC + lx * a.is) * a.CP : 0;
-            ooff[nt] = v ? ((n * a.Hout + ly * a.os + a.oy0) * a.Wout + lx * a.os + a.ox0) * a.Cout : -1;
+            for (int nt = 0; nt < NT; ++nt) {
+                const bool v = loc_il[nt] < d1.x;
+                pbase[nt] = v ? loc_p[nt] : 0;
+                ooff[nt] = v ? d0.w + loc_o[nt] : -1;
+            }
+        } else {
+            const int img0 = d1.w & 0xfffff, ly0 = d1.w >> 20;
+            const int grp_end = min(a.N, (d1.y + 1) * a.group_size);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int r = wave * 16 * NT + nt * 16 + r16;
+                int pl, lx;
+                const int il = mdiv(r, a.m_ppi, a.ppi, pl);
+                const int p = d1.z + pl;
+                const int n = img0 + il;
+                const bool v = (il < a.imgs) & (n < grp_end) & (p < LP);
+                const int ly = mdiv(p, a.m_lw, a.LW, lx);
+                pbase[nt] = v ? ((il * a.PR + (ly - ly0) * a.is) * a.PC + lx * a.is) * a.CP : 0;
+                ooff[nt] = v ? ((n * a.Hout + ly * a.os + a.oy0) * a.Wout + lx * a.os + a.ox0) * a.Cout : -1;
+            }
         }
         f32x4 acc[MT][NT];
 #pragma unroll
@@ -692,37 +744,54 @@ __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+        // operands of round rho+1 are read from LDS while the MFMAs of round rho issue (two register sets)
         auto rounds = [&](const float* wbase, int q0, int nq) __attribute__((always_inline)) {
             const float* wb = wbase + (size_t)(g * COPW + r16) * 4;
-#pragma unroll 2
-            for (int rho = 0; rho < (nq >> 2); ++rho) {
+            const int nr = nq >> 2;
+            float4 bv[2][NT], av[2][MT];
+            auto fetch = [&](int rho, int set) __attribute__((always_inline)) {
                 const int po = qoff[q0 + 4 * rho + g];
-                float4 bv[NT], av[MT];
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bv[nt] = *(const float4*)(patch + pbase[nt] + po);
+                for (int nt = 0; nt < NT; ++nt) bv[set][nt] = *(const float4*)(patch + pbase[nt] + po);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) av[mt] = *(const float4*)(wb + (size_t)rho * 4 * COPW * 4 + mt * 64);
+                for (int mt = 0; mt < MT; ++mt) av[set][mt] = *(const float4*)(wb + (size_t)rho * 4 * COPW * 4 + mt * 64);
+            };
+            auto fma4 = [&](int set) __attribute__((always_inline)) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].x, bv[nt].x, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].y, bv[nt].y, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].z, bv[nt].z, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[mt].w, bv[nt].w, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][mt].x, bv[set][nt].x, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][mt].y, bv[set][nt].y, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][mt].z, bv[set][nt].z, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][mt].w, bv[set][nt].w, acc[mt][nt], 0, 0, 0);
                     }
+            };
+            fetch(0, 0);
+            int rho = 0;
+            for (; rho + 2 <= nr; rho += 2) {
+                fetch(rho + 1, 1);
+                fma4(0);
+                if (rho + 2 < nr) fetch(rho + 2, 0);
+                fma4(1);
             }
+            if (rho < nr) fma4(0);
         };
 
         for (int chunk = 0; chunk < nchunks; ++chunk) {
             const int c0 = chunk * a.KC;
+            stamp();   // tile + 0: tile set-up done
             __syncthreads();   // consumers of the previous patch are done
-            store_patch(cur);
-            if (chunk + 1 < nchunks) load_patch(cur, c0 + a.KC);
-            else if (next_tile < ntiles) load_patch(nxt, 0);
+            stamp();   // tile + 1: barrier passed
+            store_patch(d0.z);
+            stamp();   // tile + 2: patch arrived and written to LDS
+            if (chunk + 1 < nchunks) load_patch(k, c0 + a.KC);
+            else if (k + 1 < nwt) load_patch(k + 1, 0);
             if (RES) {
                 __syncthreads();   // patch (and, the first time, the resident weights) visible
+                stamp();   // tile + 3: second barrier passed
                 rounds(wl, 0, a.Qpad);
+                stamp();   // tile + 4: MFMAs issued
             } else {
                 for (int s_ = 0; s_ < a.nstage; ++s_, ++st) {
                     w_commit(st & 1);
@@ -730,7 +799,7 @@ __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
                     {
                         int ns = s_ + 1, nc0 = c0;
                         if (ns >= a.nstage) { ns = 0; nc0 = c0 + a.KC; }
-                        if (nc0 >= a.Cin) nc0 = next_tile < ntiles ? 0 : -1;
+                        if (nc0 >= a.Cin) nc0 = k + 1 < nwt ? 0 : -1;
                         if (nc0 >= 0) w_prefetch(ns, nc0);
                     }
                     const int q0 = s_ * a.QS;
@@ -740,6 +809,24 @@ __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
         }
 
         // ---- epilogue from registers: lane (r16 = pixel, g) holds channels n0 + mt*16 + 4g .. +3 of its NT pixels -----------------
+        // the two flag sets of a training step (forward: statistics only; plain data gradient: nothing) run without per-store branches
+        if (flags == EPI_STATS || flags == 0) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const bool pv_ok = ooff[nt] >= 0;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const int co = n0 + mt * 16 + 4 * g;
+                    if (pv_ok && co < a.Cout) {
+                        const float4 v = make_float4(acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]);
+                        s1[mt][0] += v.x; s1[mt][1] += v.y; s1[mt][2] += v.z; s1[mt][3] += v.w;
+                        s2[mt][0] = fmaf(v.x, v.x, s2[mt][0]); s2[mt][1] = fmaf(v.y, v.y, s2[mt][1]);
+                        s2[mt][2] = fmaf(v.z, v.z, s2[mt][2]); s2[mt][3] = fmaf(v.w, v.w, s2[mt][3]);
+                        *(float4*)(a.out + (int64_t)ooff[nt] + co) = v;
+                    }
+                }
+            }
+        } else
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const bool pv_ok = ooff[nt] >= 0;
@@ -777,9 +864,10 @@ __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
                 *(float4*)op = v;
             }
         }
-        cur = nxt;
+        stamp();   // tile + 5: epilogue issued
     }
     if ((flags & EPI_STATS) && run_grp >= 0) flush_stats();
+    stamp();
 }
 
 #define OCL_CONVT_TILINGS(X) X(1, 1) X(2, 1) X(3, 1) X(4, 1) X(5, 1) X(1, 2) X(2, 2) X(3, 2) X(4, 2) X(5, 2)
@@ -925,7 +1013,7 @@ static size_t convt_layout(const ConvGeomDesc& g, ConvArgs& a, int MT, int NT) {
             a.QS = a.wres ? a.Qpad : std::min(a.Qpad, ((256 * kWPF) / COPW) & ~3);
             a.nstage = cdiv(a.Qpad, a.QS);
             const size_t patch_b = std::max((size_t)a.imgs * a.PR * a.PC * a.CP * 4, (size_t)8 * COPW * 8);
-            bytes = (size_t)2 * a.Qpad * 4 + (a.wres ? w_all : (size_t)2 * a.QS * COPW * 16) + patch_b;
+            bytes = (size_t)kMaxWgTiles * 32 + (size_t)2 * a.Qpad * 4 + (a.wres ? w_all : (size_t)2 * a.QS * COPW * 16) + patch_b;
             const bool units_ok = a.imgs * a.PR * a.PC * (KC / 4) <= 256 * kConvPatchPF;
             if (units_ok && bytes <= kLdsLimit - 2048 && (bytes <= 100 * 1024 || KC <= 20)) goto found;
         }
@@ -983,10 +1071,24 @@ static int plan_conv_t(const ConvGeomDesc& g, ConvPlan* p) {
         a.inv_PR = 1.0f / (float)a.PR;
     }
     a.groups = g.groups;
+    {
+        const int BMp = 64 * NT, LPp = g.LH * g.LW;
+        a.aligned = a.imgs > 1 ? 1 : ((BMp % g.LW == 0 && LPp % BMp == 0) ? 1 : 0);
+    }
     const int ntiles = g.groups * a.tiles_per_group;
+    {
+        auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); };
+        a.m_tpg = magic(a.tiles_per_group); a.m_tpi = magic(a.tiles_per_img); a.m_lw = magic(a.LW); a.m_ppi = magic(a.ppi);
+        a.m_kc4 = magic(a.KC / 4); a.m_pc = magic(a.PC); a.m_pr = magic(a.PR);
+        // exactness of x / d by one multiply-high needs x * d < 2^32: the largest dividends are tile and pixel indices
+        const int64_t xmax = std::max<int64_t>(std::max<int64_t>(ntiles, (int64_t)g.LH * g.LW + 64 * NT), 4096);
+        const int64_t dmax = std::max(std::max(a.tiles_per_group, a.tiles_per_img), std::max(std::max(a.LW, a.ppi), std::max(a.PC, a.PR)));
+        if (xmax * dmax >= (1ll << 32)) return OCL_ERR_ARG;
+    }
     int bpc = (int)std::min<size_t>(2, kLdsLimit / (lds + 512));
     if (g.force_bpc) bpc = g.force_bpc;
     p->grid_x = std::max(1, std::min(ntiles, (256 * std::max(1, bpc)) / a.n_splits));
+    p->grid_x = std::max(p->grid_x, cdiv(ntiles, kMaxWgTiles));   // a workgroup keeps at most kMaxWgTiles tile descriptors
     p->grid_y = a.n_splits;
     return OCL_OK;
 }

@@ -186,9 +186,35 @@ static void bench_geom(const char* lname, const char* kind, ConvGeomDesc g, cons
                 stats = stats2;
                 const double t = time_us([&] { run(pt, out); });
                 stats = keep2;
+                if (mt == 0 && pt.a.wres && getenv("KBENCH_TRACE")) {   // phase timeline of wave 0 of a few workgroups (s_memtime cycles)
+                    const int nwg = pt.grid_x * pt.grid_y;
+                    unsigned long long* tr;
+                    CK(hipMalloc(&tr, (size_t)nwg * 64 * 8));
+                    CK(hipMemset(tr, 0, (size_t)nwg * 64 * 8));
+                    ConvPlan ptt = pt;
+                    ptt.a.trace = tr;
+                    stats = stats2;
+                    run(ptt, out);
+                    stats = keep2;
+                    CK(hipDeviceSynchronize());
+                    std::vector<unsigned long long> h((size_t)nwg * 64);
+                    CK(hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost));
+                    unsigned long long t0 = ~0ull, t1 = 0;
+                    for (int w = 0; w < nwg; ++w) { t0 = std::min(t0, h[(size_t)w * 64]); for (int e = 0; e < 64; ++e) t1 = std::max(t1, h[(size_t)w * 64 + e]); }
+                    printf("      trace: kernel span %llu cycles; per workgroup [start-offset | setup | per tile: wait-barrier1, patch-wait+store, barrier2, mfma, epilogue, next-setup ...]\n", t1 - t0);
+                    for (int w : {0, 1, nwg / 2, nwg - 1}) {
+                        const unsigned long long* r = &h[(size_t)w * 64];
+                        printf("      wg %4d: +%6llu | %5llu |", w, r[0] - t0, r[1] - r[0]);
+                        for (int e = 2; e + 5 < 64 && r[e + 5]; e += 6)
+                            printf(" %4llu %5llu %4llu %5llu %5llu %4llu |", r[e + 1] - r[e], r[e + 2] - r[e + 1], r[e + 3] - r[e + 2], r[e + 4] - r[e + 3],
+                                   r[e + 5] - r[e + 4], r[e + 6] ? r[e + 6] - r[e + 5] : 0ull);
+                        printf("\n");
+                    }
+                    CK(hipFree(tr));
+                }
                 printf("    conv_t%s MT=%d NT=%d grid=%5dx%d lds=%6zu KC=%3d Q=%3d QS=%3d res=%d  %7.1f us %6.1f TF/s  maxdiff=%.2e statdiff=%.1e%s\n",
                        mt ? "      " : " (auto)", pt.MT, pt.NT, pt.grid_x, pt.grid_y, pt.lds_bytes, pt.a.KC, pt.a.Qc, pt.a.QS, pt.a.wres, t,
-                       flops / t * 1e-6, d, ds, (d > 1e-3 || ds > 1e-6) ? "  <-- MISMATCH" : "");
+                       flops / t * 1e-6, d, ds, (d > 1e-3 || ds > 1e-3) ? "  <-- MISMATCH" : "");
             }
         CK(hipFree(stats2));
     }
