@@ -9,3 +9,5 @@ The directory name contains a hyphen, so the package is imported as `ocl_amd` th
 at the repository root (ocl_amd.py).
 """
 __version__ = "0.1.0"
+
+from . import name_match  # noqa: E402,F401  (the plugin registries: `ocl_amd.name_match.agents[...]` as INTEGRATION.md uses them)

@@ -30,26 +30,49 @@ class ScrAugment(object):
         self.p_jitter, self.p_gray = p_jitter, p_gray
 
     def sample_params(self, n):
-        u = torch.rand(n, 12)
+        """Crop boxes the way torchvision / kornia draw them (RandomResizedCrop.get_params; kornia 0.4.1 random_crop_size_generator):
+        up to 10 attempts of (area ~ U(scale) * H * W, log-ratio ~ U(log ratio)), integer width / height, the first attempt that
+        fits inside the image wins; if none fits, the centre crop with the aspect ratio clamped into `ratio`.  The position is
+        uniform over the placements that keep the box inside the image.  All draws come from the torch CPU generator."""
         h, w = float(self.h), float(self.w)
-        area = (self.scale[0] + (self.scale[1] - self.scale[0]) * u[:, 0]) * h * w
-        logr = math.log(self.ratio[0]) + (math.log(self.ratio[1]) - math.log(self.ratio[0])) * u[:, 1]
+        tries = 10
+        u = torch.rand(n, 2 * tries + 10)
+        area = (self.scale[0] + (self.scale[1] - self.scale[0]) * u[:, :tries]) * h * w
+        logr = math.log(self.ratio[0]) + (math.log(self.ratio[1]) - math.log(self.ratio[0])) * u[:, tries:2 * tries]
         r = torch.exp(logr)
-        cw = torch.sqrt(area * r).clamp(1.0, w)
-        ch = torch.sqrt(area / r).clamp(1.0, h)
-        y0 = u[:, 2] * (h - ch)
-        x0 = u[:, 3] * (w - cw)
+        cw_try = torch.round(torch.sqrt(area * r))
+        ch_try = torch.round(torch.sqrt(area / r))
+        fits = (cw_try > 0) & (cw_try <= w) & (ch_try > 0) & (ch_try <= h)
+        first = torch.where(fits.any(1), fits.float().argmax(1), torch.zeros(n, dtype=torch.long))
+        cw = cw_try.gather(1, first[:, None]).squeeze(1)
+        ch = ch_try.gather(1, first[:, None]).squeeze(1)
+        none = ~fits.any(1)
+        if none.any():   # fallback: centre crop, aspect ratio clamped (torchvision get_params)
+            in_ratio = w / h
+            if in_ratio < self.ratio[0]:
+                fw, fh = w, round(w / self.ratio[0])
+            elif in_ratio > self.ratio[1]:
+                fw, fh = round(h * self.ratio[1]), h
+            else:
+                fw, fh = w, h
+            cw = torch.where(none, torch.full_like(cw, float(fw)), cw)
+            ch = torch.where(none, torch.full_like(ch, float(fh)), ch)
+        e = u[:, 2 * tries:]
+        y0 = torch.floor(e[:, 0] * (h - ch + 1)).clamp(max=h - 1)
+        x0 = torch.floor(e[:, 1] * (w - cw + 1)).clamp(max=w - 1)
+        y0 = torch.where(none, torch.floor((h - ch) / 2), y0)
+        x0 = torch.where(none, torch.floor((w - cw) / 2), x0)
         b, c, s, hue = self.jitter
         p = torch.empty(n, ops.AUG_NPARAM)
         p[:, 0], p[:, 1], p[:, 2], p[:, 3] = y0, x0, ch, cw
-        p[:, 4] = (u[:, 4] < 0.5).float()
-        p[:, 5] = (u[:, 5] < self.p_jitter).float()
-        p[:, 6] = 1.0 - b + 2 * b * u[:, 6]
-        p[:, 7] = 1.0 - c + 2 * c * u[:, 7]
-        p[:, 8] = 1.0 - s + 2 * s * u[:, 8]
-        p[:, 9] = -hue + 2 * hue * u[:, 9]
-        p[:, 10] = torch.floor(u[:, 10] * 24).clamp(0, 23)
-        p[:, 11] = (u[:, 11] < self.p_gray).float()
+        p[:, 4] = (e[:, 2] < 0.5).float()
+        p[:, 5] = (e[:, 3] < self.p_jitter).float()
+        p[:, 6] = 1.0 - b + 2 * b * e[:, 4]
+        p[:, 7] = 1.0 - c + 2 * c * e[:, 5]
+        p[:, 8] = 1.0 - s + 2 * s * e[:, 6]
+        p[:, 9] = -hue + 2 * hue * e[:, 7]
+        p[:, 10] = torch.floor(e[:, 8] * 24).clamp(0, 23)
+        p[:, 11] = (e[:, 9] < self.p_gray).float()
         return p
 
     def __call__(self, x):

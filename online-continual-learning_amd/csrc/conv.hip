@@ -502,6 +502,14 @@ __device__ __forceinline__ int mdiv(int x, unsigned M, int d, int& rem) {
 constexpr int kWPF = 4;                        // float4 weight-prefetch registers per thread (staged weights)
 constexpr size_t kResidentBytes = 80 * 1024;   // weights of one channel split kept in LDS for the workgroup's lifetime up to this
 
+// sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15), result in every lane: four v_add_f32 with DPP operands, no LDS traffic
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));   // row_half_mirror
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));   // row_mirror
+    return v;
+}
 constexpr int kMaxWgTiles = 64;                // tile descriptors a workgroup keeps in LDS
 
 template <int MT, int NT, int PF, bool RES>
@@ -607,23 +615,19 @@ __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
 
     // ---- weights ----------------------------------------------------------------------------------------------------------
     const int wcol_ok = a.WPT - n0;   // columns of this split that exist in the pack
-    if (RES) {   // 8 loads in flight per thread
+    if (RES) {
+        // global -> LDS without registers (buffer_load ... lds): a wave instruction fills 64 consecutive 16-byte units (LDS address =
+        // wave-uniform base + lane * 16, global address per lane); everything is in flight at once, one wait at the end.  Padding
+        // groups / channels past the pack address the descriptor's out-of-range area, which reads as zeros.
         const int units = a.Qpad * COPW;
-        for (int u0 = tid; u0 < units; u0 += 256 * 8) {
-            float4 v[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int u = u0 + i * 256;
-                const int q = min(u, units - 1) / COPW, c = min(u, units - 1) - q * COPW;
-                const int row = qrow[q];
-                v[i] = buf_load16(rs_w, (u < units && row >= 0 && c < wcol_ok) ? ((row * a.WPT + n0 + c) * 4) * 4 : kOob);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int u = u0 + i * 256;
-                if (u < units) *(float4*)(wl + (size_t)u * 4) = v[i];
-            }
+        for (int u0 = wave * 64; u0 < units; u0 += 256) {
+            const int u = u0 + lane;
+            const int q = min(u, units - 1) / COPW, c = min(u, units - 1) - q * COPW;
+            const int row = qrow[q];
+            const int off = (u < units && row >= 0 && c < wcol_ok) ? ((row * a.WPT + n0 + c) * 4) * 4 : kOob;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(wl + (size_t)u0 * 4), 16, off, 0, 0, 0);
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     // staged: stage s of chunk c0 covers groups [s*QS, s*QS + QS); unit u = tid + i*256 -> (group in stage, channel)
     float4 wv[RES ? 1 : kWPF];
@@ -664,12 +668,7 @@ __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float x = s1[mt][e], y = s2[mt][e];
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    x += __shfl_xor(x, o, 64);
-                    y += __shfl_xor(y, o, 64);
-                }
+                const float x = row16_sum(s1[mt][e]), y = row16_sum(s2[mt][e]);
                 if (r16 == 0) {
                     red[(wave * 2 + 0) * COPW + mt * 16 + 4 * g + e] = (double)x;
                     red[(wave * 2 + 1) * COPW + mt * 16 + 4 * g + e] = (double)y;
@@ -1047,7 +1046,7 @@ static int plan_conv_t(const ConvGeomDesc& g, ConvPlan* p) {
     // the layer has too few pixel tiles to give every CU a workgroup
     int MT = std::min(5, nt16);
     if (nt16 > 5) MT = cdiv(nt16, cdiv(nt16, 5));                    // balanced splits (10 tiles -> 2 x 5)
-    while (MT > 1 && tiles64 * cdiv(nt16, MT) < 256) --MT;
+    while (MT > 1 && tiles64 * cdiv(nt16, MT) < 200) --MT;   // kbench sweep: 4x55 workgroups of 3 channel tiles beat 5x55 of 2 on layer 4
     if (nt16 > MT) MT = cdiv(nt16, cdiv(nt16, MT));
     int NT = tiles64 * cdiv(nt16, MT) >= 2048 ? 2 : 1;
     if (g.force_MT) MT = g.force_MT;

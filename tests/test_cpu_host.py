@@ -129,18 +129,47 @@ def test_product_fails_loudly_without_gpu_and_never_imports_the_oracle():
 
 
 def test_scr_augment_parameter_ranges():
+    """The crop boxes follow torchvision's RandomResizedCrop.get_params (10 attempts, integer sizes, centre-crop fallback): every
+    box lies inside the image; for accepted attempts area / (H*W) is in [scale] and the aspect ratio in [3/4, 4/3] up to the integer
+    rounding of the sides; the statistics of the accepted draws match a direct Monte-Carlo of the same rule; jitter factors, flip
+    and grayscale probabilities are the pipeline's (agents/scr.py:18-24)."""
     from ocl_amd.agents.scr import ScrAugment
     torch.manual_seed(0)
-    p = ScrAugment((32, 32)).sample_params(500).numpy()
-    assert p.shape == (500, 12)
-    assert (p[:, 2] >= 1).all() and (p[:, 2] <= 32).all() and (p[:, 3] >= 1).all() and (p[:, 3] <= 32).all()
-    assert (p[:, 0] >= 0).all() and (p[:, 0] + p[:, 2] <= 32 + 1e-4).all()
-    assert (p[:, 1] >= 0).all() and (p[:, 1] + p[:, 3] <= 32 + 1e-4).all()
-    assert 0.12 < (p[:, 2] * p[:, 3] / 1024).min() and (p[:, 2] * p[:, 3] / 1024).max() <= 1.0 + 1e-5
-    assert set(np.unique(p[:, 4])) <= {0.0, 1.0} and 0.3 < p[:, 4].mean() < 0.7
-    assert 0.7 < p[:, 5].mean() < 0.9 and 0.1 < p[:, 11].mean() < 0.3
+    n = 4000
+    p = ScrAugment((32, 32)).sample_params(n).numpy()
+    assert p.shape == (n, 12)
+    y0, x0, ch, cw = p[:, 0], p[:, 1], p[:, 2], p[:, 3]
+    assert (ch == np.round(ch)).all() and (cw == np.round(cw)).all() and (y0 == np.round(y0)).all() and (x0 == np.round(x0)).all()
+    assert (ch >= 1).all() and (ch <= 32).all() and (cw >= 1).all() and (cw <= 32).all()
+    assert (y0 >= 0).all() and (y0 + ch <= 32).all() and (x0 >= 0).all() and (x0 + cw <= 32).all()
+    frac = ch * cw / 1024.0
+    ratio = cw / ch
+    assert 0.17 < frac.min() and frac.max() <= 1.0             # scale (0.2, 1): rounding the sides moves the area by a few percent
+    assert 0.68 < ratio.min() and ratio.max() < 1.45
+    # Monte-Carlo of the rule itself (numpy): first fitting attempt of 10
+    rng = np.random.default_rng(1)
+    m = 40000
+    a = rng.uniform(0.2, 1.0, (m, 10)) * 1024
+    r = np.exp(rng.uniform(np.log(3 / 4), np.log(4 / 3), (m, 10)))
+    w_, h_ = np.round(np.sqrt(a * r)), np.round(np.sqrt(a / r))
+    ok = (w_ <= 32) & (h_ <= 32) & (w_ > 0) & (h_ > 0)
+    first = ok.argmax(1)
+    wm, hm = w_[np.arange(m), first], h_[np.arange(m), first]
+    assert ok.any(1).mean() > 0.999
+    assert abs(frac.mean() - (wm * hm / 1024).mean()) < 0.01 and abs(ratio.mean() - (wm / hm).mean()) < 0.01
+    assert abs(np.median(frac) - np.median(wm * hm / 1024)) < 0.02
+    # position: uniform over the admissible placements
+    free = 32 - cw
+    sel = free >= 8
+    assert abs((x0[sel] / free[sel]).mean() - 0.5) < 0.03
+    assert set(np.unique(p[:, 4])) <= {0.0, 1.0} and 0.45 < p[:, 4].mean() < 0.55
+    assert 0.77 < p[:, 5].mean() < 0.83 and 0.17 < p[:, 11].mean() < 0.23
     assert (p[:, 6:9] >= 0.6 - 1e-6).all() and (p[:, 6:9] <= 1.4 + 1e-6).all() and (np.abs(p[:, 9]) <= 0.1 + 1e-6).all()
     assert (p[:, 10] >= 0).all() and (p[:, 10] <= 23).all()
+    # the fallback: a 2:1 image cannot take a 3/4..4/3 box of 99 % of its area -> centre crop with the ratio clamped
+    torch.manual_seed(1)
+    q = ScrAugment((16, 64), scale=(0.99, 1.0)).sample_params(50).numpy()
+    assert (q[:, 3] == round(16 * 4 / 3)).all() and (q[:, 2] == 16).all() and (q[:, 1] == np.floor((64 - q[:, 3]) / 2)).all()
 
 
 def test_metrics_match_hand_computation():
@@ -150,3 +179,53 @@ def test_metrics_match_hand_computation():
     assert abs(end[0] - np.mean([0.65, 0.6])) < 1e-12
     assert abs(fgt[0] - np.mean([(0.4 + 0.0) / 2, (0.1 + 0.0) / 2])) < 1e-12
     assert abs(fwt[0] - np.mean([0.0, 0.1])) < 1e-12
+
+
+def test_reference_driver_with_the_integration_patch_reaches_the_hip_boundary():
+    """INTEGRATION.md §1 applied in memory to the REAL reference (utils/name_match.py, utils/setup_elements.py,
+    experiment/run.py): `multiple_run` (experiment/run.py:17-87) builds its data stream, then model / optimiser / agent through
+    the patched registries -- i.e. this repository's classes -- and stops exactly where the product must stop without an
+    MI355X: at the replay memory's device check (no CPU path).  Runs only where /root/reference exists (the build container)."""
+    import importlib
+    import sys
+    from oracle import ref_import as R
+    if not R.available():
+        pytest.skip("reference tree not present on this machine")
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: the wiring is exercised end to end by tests/test_gpu_parity2.py instead")
+    import ocl_amd
+    saved = {k: sys.modules.get(k) for k in list(sys.modules) if k.split(".")[0] in ("utils", "experiment", "continuum", "agents", "models")}
+    nm = R.activate()
+    try:
+        import torchvision.datasets as tvd
+        rng = np.random.default_rng(0)
+        tvd.SYNTHETIC = lambda name, train: (rng.integers(0, 256, (200 if train else 50, 32, 32, 3), dtype=np.uint8),
+                                             np.repeat(np.arange(10), 20 if train else 5))
+        # ---- the three edits of INTEGRATION.md §1 ----
+        nm.agents.update({k: ocl_amd.name_match.agents[k] for k in ('ER', 'SCR')})
+        nm.retrieve_methods.update({k: ocl_amd.name_match.retrieve_methods[k] for k in ('random', 'MIR', 'ASER', 'match', 'mem_match')})
+        nm.update_methods.update({k: ocl_amd.name_match.update_methods[k] for k in ('random', 'GSS', 'ASER')})
+        import utils.setup_elements as se
+        from ocl_amd.setup_elements import setup_architecture, setup_opt
+        se.setup_architecture, se.setup_opt = setup_architecture, setup_opt
+        import experiment.run as run
+        run = importlib.reload(run)                      # `from utils.setup_elements import ...` re-evaluated after the edit
+        from ocl_amd.data import setup_test_loader
+        run.setup_test_loader = setup_test_loader
+        assert run.agents is nm.agents and run.agents['ER'] is ocl_amd.name_match.agents['ER']
+        assert run.setup_architecture is setup_architecture
+        params = R.default_params(agent="ER", retrieve="random", update="random", data="cifar10", cl_type="nc", num_tasks=5, num_runs=1,
+                                  mem_size=50, online=True, cuda=True, fix_order=True)
+        with R.quiet() as out:
+            with pytest.raises(RuntimeError) as ei:
+                run.multiple_run(params)
+        assert "no CPU path" in str(ei.value) or "MI355X" in str(ei.value)
+        assert "Setting up data stream" in out.getvalue()          # the reference's own driver ran up to the agent construction
+        tb = ei.traceback
+        assert any("experiment/run.py" in str(e.path) for e in tb) and any("online-continual-learning_amd" in str(e.path) for e in tb)
+    finally:
+        import torchvision.datasets as tvd
+        tvd.SYNTHETIC = None
+        for k in [k for k in sys.modules if k.split(".")[0] in ("utils", "experiment", "continuum", "agents", "models")]:
+            del sys.modules[k]
+        sys.modules.update({k: v for k, v in saved.items() if v is not None})

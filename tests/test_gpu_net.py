@@ -196,7 +196,9 @@ def test_gradient_accumulation_and_zero_grad_semantics(cuda):
     opt.step()
     pref = torch.cat([st[k].detach().reshape(-1) for k in names]).numpy()
     assert np.abs(m.flat_params().cpu().numpy() - pref).max() < 5e-3 * np.abs(pref).max()
-    # zero_grad then ONE backward overwrites
+    # zero_grad then ONE backward overwrites.  Both sides start this phase from the SAME weights (the oracle's): the two updates
+    # above differ by ReLU sign flips, and a gradient taken at slightly different weights is a different question
+    m.load_state_dict({k: v.detach() for k, v in st.items()})
     O.zero_grad(st, names)
     O.ce_mean(O.OracleNet(st, training=True).forward(torch.from_numpy(xa)), torch.from_numpy(ya)).backward()
     opt.zero_grad()
