@@ -571,6 +571,50 @@ __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
         d[7] = img0 | (ly0 << 20);
     }
 
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in), rs_w = make_rsrc(a.wT);
+    stamp();   // P1: tables written
+    __syncthreads();   // tables visible
+    stamp();   // P2: barrier
+    // ---- weights ----------------------------------------------------------------------------------------------------------
+    const int wcol_ok = a.WPT - n0;   // columns of this split that exist in the pack
+    if (RES) {
+        // global -> LDS without registers (buffer_load ... lds): a wave instruction fills 64 consecutive 16-byte units (LDS address =
+        // wave-uniform base + lane * 16, global address per lane); everything is in flight at once, one wait at the end.  Padding
+        // groups / channels past the pack address the descriptor's out-of-range area, which reads as zeros.
+        const int units = a.Qpad * COPW;
+#pragma unroll 4
+        for (int u0 = wave * 64; u0 < units; u0 += 256) {
+            const int u = u0 + lane;
+            const int q = min(u, units - 1) / COPW, c = min(u, units - 1) - q * COPW;
+            const int row = qrow[q];
+            const int off = (u < units && row >= 0 && c < wcol_ok) ? ((row * a.WPT + n0 + c) * 4) * 4 : kOob;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(wl + (size_t)u0 * 4), 16, off, 0, 0, 0);
+        }
+    }
+    stamp();   // P3: weight DMA issued
+    // staged: stage s of chunk c0 covers groups [s*QS, s*QS + QS); unit u = tid + i*256 -> (group in stage, channel)
+    float4 wv[RES ? 1 : kWPF];
+    auto w_prefetch = [&](int s_, int c0_) __attribute__((always_inline)) {
+        const int q0 = s_ * a.QS;
+        const int c4base = c0_ >> 2;
+#pragma unroll
+        for (int i = 0; i < (RES ? 1 : kWPF); ++i) {
+            const int u = tid + i * 256;
+            const int qq = u / COPW, c = u - qq * COPW;
+            const int q = q0 + qq;
+            const int row = (qq < a.QS && q < a.Qpad) ? qrow[q] : -1;
+            wv[i] = buf_load16(rs_w, (row >= 0 && c < wcol_ok) ? (((row + c4base) * a.WPT + n0 + c) * 4) * 4 : kOob);
+        }
+    };
+    auto w_commit = [&](int buf) __attribute__((always_inline)) {
+        float* dst = wl + (size_t)buf * a.QS * COPW * 4;
+#pragma unroll
+        for (int i = 0; i < (RES ? 1 : kWPF); ++i) {
+            const int u = tid + i * 256;
+            if (u < a.QS * COPW) *(float4*)(dst + (size_t)u * 4) = wv[i];
+        }
+    };
+
     // ---- per-thread patch units (float4 along the channels): tile-invariant pieces ------------------------------------------------
     int pu_goff[PF], pu_lds[PF], pu_rp[PF];   // global byte offset from the patch origin; LDS float offset; row | pr << 16 (row = il*PR + pr)
     {
@@ -594,8 +638,6 @@ __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
         }
     }
     float4 pv[PF];
-    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in), rs_w = make_rsrc(a.wT);
-    __syncthreads();   // tables visible
     auto load_patch = [&](int k, int c0) __attribute__((always_inline)) {
         const int4 d = *(const int4*)(tdesc + k * 8);   // in_base, iy0, nrows, obase
         const int base = d.x + c0 * 4;
@@ -612,45 +654,7 @@ __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
             if ((pu_rp[i] & 0xffff) < nrows) *(float4*)(patch + pu_lds[i]) = pv[i];   // CP % 4 == 0: 16-byte aligned
     };
     load_patch(0, 0);
-
-    // ---- weights ----------------------------------------------------------------------------------------------------------
-    const int wcol_ok = a.WPT - n0;   // columns of this split that exist in the pack
-    if (RES) {
-        // global -> LDS without registers (buffer_load ... lds): a wave instruction fills 64 consecutive 16-byte units (LDS address =
-        // wave-uniform base + lane * 16, global address per lane); everything is in flight at once, one wait at the end.  Padding
-        // groups / channels past the pack address the descriptor's out-of-range area, which reads as zeros.
-        const int units = a.Qpad * COPW;
-        for (int u0 = wave * 64; u0 < units; u0 += 256) {
-            const int u = u0 + lane;
-            const int q = min(u, units - 1) / COPW, c = min(u, units - 1) - q * COPW;
-            const int row = qrow[q];
-            const int off = (u < units && row >= 0 && c < wcol_ok) ? ((row * a.WPT + n0 + c) * 4) * 4 : kOob;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(wl + (size_t)u0 * 4), 16, off, 0, 0, 0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    // staged: stage s of chunk c0 covers groups [s*QS, s*QS + QS); unit u = tid + i*256 -> (group in stage, channel)
-    float4 wv[RES ? 1 : kWPF];
-    auto w_prefetch = [&](int s_, int c0_) __attribute__((always_inline)) {
-        const int q0 = s_ * a.QS;
-        const int c4base = c0_ >> 2;
-#pragma unroll
-        for (int i = 0; i < (RES ? 1 : kWPF); ++i) {
-            const int u = tid + i * 256;
-            const int qq = u / COPW, c = u - qq * COPW;
-            const int q = q0 + qq;
-            const int row = (qq < a.QS && q < a.Qpad) ? qrow[q] : -1;
-            wv[i] = buf_load16(rs_w, (row >= 0 && c < wcol_ok) ? (((row + c4base) * a.WPT + n0 + c) * 4) * 4 : kOob);
-        }
-    };
-    auto w_commit = [&](int buf) __attribute__((always_inline)) {
-        float* dst = wl + (size_t)buf * a.QS * COPW * 4;
-#pragma unroll
-        for (int i = 0; i < (RES ? 1 : kWPF); ++i) {
-            const int u = tid + i * 256;
-            if (u < a.QS * COPW) *(float4*)(dst + (size_t)u * 4) = wv[i];
-        }
-    };
+    stamp();   // P4: first patch requested
 
     const int nchunks = a.Cin / a.KC;
     float s1[MT][4], s2[MT][4];   // BatchNorm partial sums of this lane's channels over this workgroup's tiles
@@ -704,7 +708,10 @@ __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
 
     int st = 0;
     if (!RES) w_prefetch(0, 0);
-    stamp();   // 1: set-up done (resident weights issued)
+    // the resident weights (LDS-DMA) were in flight during the per-lane set-up above; every wave waits for ITS OWN DMA writes here
+    // (a barrier does not wait for vector-memory operations), the barriers of the first tile publish them
+    if (RES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    stamp();   // P5: set-up done
     for (int k = 0; k < nwt; ++k) {
         const int4 d0 = *(const int4*)(tdesc + k * 8);       // in_base, iy0, nrows, obase
         const int4 d1 = *(const int4*)(tdesc + k * 8 + 4);   // nimg, grp, p0, img0 | ly0 << 20

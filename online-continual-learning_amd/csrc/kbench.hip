@@ -204,8 +204,9 @@ static void bench_geom(const char* lname, const char* kind, ConvGeomDesc g, cons
                     printf("      trace: kernel span %llu cycles; per workgroup [start-offset | setup | per tile: wait-barrier1, patch-wait+store, barrier2, mfma, epilogue, next-setup ...]\n", t1 - t0);
                     for (int w : {0, 1, nwg / 2, nwg - 1}) {
                         const unsigned long long* r = &h[(size_t)w * 64];
-                        printf("      wg %4d: +%6llu | %5llu |", w, r[0] - t0, r[1] - r[0]);
-                        for (int e = 2; e + 5 < 64 && r[e + 5]; e += 6)
+                        printf("      wg %4d: +%6llu | tables %4llu barrier %4llu patch-issue %4llu dma-issue %4llu wait+rest %5llu |", w, r[0] - t0, r[1] - r[0],
+                               r[2] - r[1], r[3] - r[2], r[4] - r[3], r[5] - r[4]);
+                        for (int e = 6; e + 5 < 64 && r[e + 5]; e += 6)
                             printf(" %4llu %5llu %4llu %5llu %5llu %4llu |", r[e + 1] - r[e], r[e + 2] - r[e + 1], r[e + 3] - r[e + 2], r[e + 4] - r[e + 3],
                                    r[e + 5] - r[e + 4], r[e + 6] ? r[e + 6] - r[e + 5] : 0ull);
                         printf("\n");

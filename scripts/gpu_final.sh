@@ -7,11 +7,13 @@ L=gpurun_out/${T}_info.log; : > $L
 timeout 900 python -m pytest tests/ -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/${T}_tests.log 2>&1; echo "tests rc=$?" >> $L
 timeout 300 python __graft_entry__.py smoke > gpurun_out/${T}_smoke.log 2>&1; echo "smoke rc=$?" >> $L
 timeout 900 python bench.py > gpurun_out/${T}_bench_scr.log 2>&1; echo "bench rc=$?" >> $L
-for w in aser er mir; do timeout 600 python bench.py --workload $w --steps 100 --warmup 10 --no-cpu-baseline > gpurun_out/${T}_bench_$w.log 2>&1; echo "bench $w rc=$?" >> $L; done
-timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${T}_prof -o scr -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-roofline > gpurun_out/${T}_prof.log 2>&1; echo "prof rc=$?" >> $L
-timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${T}_prof1 -o scr -- python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-roofline --single-stream > gpurun_out/${T}_prof1.log 2>&1; echo "prof single-stream rc=$?" >> $L
+Q="--no-cpu-baseline --no-also --no-accuracy"
+for w in aser er mir; do timeout 600 python bench.py --workload $w --steps 100 --warmup 10 $Q > gpurun_out/${T}_bench_$w.log 2>&1; echo "bench $w rc=$?" >> $L; done
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${T}_prof -o scr -- python bench.py --steps 50 --warmup 10 $Q --no-roofline > gpurun_out/${T}_prof.log 2>&1; echo "prof rc=$?" >> $L
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${T}_prof1 -o scr -- python bench.py --steps 50 --warmup 10 $Q --no-roofline --single-stream > gpurun_out/${T}_prof1.log 2>&1; echo "prof single-stream rc=$?" >> $L
+timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/${T}_prof2 -o aser -- python bench.py --workload aser --steps 50 --warmup 10 $Q --no-roofline --single-stream > gpurun_out/${T}_prof2.log 2>&1; echo "prof aser single-stream rc=$?" >> $L
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/${T}_pmc_$c -o p -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-roofline --single-stream > gpurun_out/${T}_pmc_$c.log 2>&1; echo "pmc $c rc=$?" >> $L
+  timeout 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/${T}_pmc_$c -o p -- python bench.py --steps 10 --warmup 3 $Q --no-roofline --single-stream > gpurun_out/${T}_pmc_$c.log 2>&1; echo "pmc $c rc=$?" >> $L
 done
 python - "$T" <<'PY'
 import csv, collections, json, glob, sys
