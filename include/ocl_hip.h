@@ -224,15 +224,6 @@ int ocl_net_backward(ocl_net* net, int slot, const float* dout, int accumulate, 
  * 2: conv2 data gradient, 3: bn1 backward, 4: conv1 data gradient, 5: block input gradient complete; 990: after the
  * head; -1: off).  debug_copy what: 0 raw conv output (NHWC) of conv `index`; 1 output of block `index`; 2 gradient
  * scratch buffer `index`; 3 gradient buffer by role (0..4 = gA..gE) at the last stop; 4 activation a1 of block `index`; 5 stem output. */
-/* Schedule of a two-view (groups == 2) train-mode pass.  mode 0 (default): one chain of launches over both views (weight
- * gradients of batches >= 48 on a second stream).  mode 1: one chain per view on two streams, each captured at its third use
- * with the same (batch size, flags, slot, parameter array) and replayed with one hipGraphLaunch; caller-owned pointers never
- * enter a graph.  mode 2: the same two chains with eager launches.  mode -1: take OCL_DUAL_CHAIN from the environment
- * (default 0).  Measurement runs (ocl_prof_enable, OCL_SINGLE_STREAM=1) and debug stops always use mode 0.
- * Stats: graph launches and captures so far. */
-int ocl_net_graph_enable(ocl_net* net, int mode);
-int ocl_net_graph_stats(const ocl_net* net, int64_t* launches, int64_t* captures);
-
 int ocl_net_debug_stop(ocl_net* net, int stage);
 int ocl_net_debug_copy(ocl_net* net, int slot, int what, int index, float* dst, int64_t max_floats,
                        int64_t* n_written, void* stream);

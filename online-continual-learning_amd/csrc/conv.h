@@ -170,27 +170,6 @@ struct BnFwdArgs {
 };
 int launch_bn_fwd(const BnFwdArgs& a, hipStream_t s);
 
-// running_mean / running_var / num_batches_tracked of every BatchNorm from the batch statistics of n_chains forward chains (one
-// update per chain, in chain order: what n_chains consecutive forward calls do); stats arenas as written by the conv epilogues
-constexpr int kBnRunMax = 24;
-struct BnRunDesc {
-    int stat_off;    // running_mean offset in `running` (running_var follows at +C)
-    int C;
-    int arena_off;   // offset of this BatchNorm inside a statistics arena (doubles), group 0
-    int M;           // elements per channel in one chain
-};
-struct BnRunArgs {
-    const double* stats[2];
-    int64_t rep_stride;
-    int n_chains, n_bn;
-    float momentum;
-    float* running;
-    int64_t* nbt;
-    BnRunDesc d[kBnRunMax];
-};
-int launch_bn_running_update(const BnRunArgs& a, hipStream_t s);
-int launch_add_inplace(float* dst, const float* src, int64_t n, hipStream_t s);   // dst += src
-
 // eval-mode fold: scale = gamma/sqrt(rv+eps), shift = beta - rm*scale for every BN at once
 struct BnFoldDesc {
     int64_t gamma_off, beta_off, stat_off, out_off;

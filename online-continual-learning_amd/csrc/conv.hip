@@ -1789,56 +1789,6 @@ int launch_bn_fwd(const BnFwdArgs& a, hipStream_t s) {
     return OCL_OK;
 }
 
-__global__ void __launch_bounds__(256) bn_running_update_kernel(const BnRunArgs a) {
-    const BnRunDesc d = a.d[blockIdx.x];
-    const double M = (double)d.M;
-    for (int c = threadIdx.x; c < d.C; c += 256) {
-        float rm = a.running[d.stat_off + c], rv = a.running[d.stat_off + d.C + c];
-        for (int ch = 0; ch < a.n_chains; ++ch) {
-            double s1 = 0.0, s2 = 0.0;
-            for (int r = 0; r < kStatReps; ++r) {
-                s1 += a.stats[ch][r * a.rep_stride + d.arena_off + c];
-                s2 += a.stats[ch][r * a.rep_stride + d.arena_off + d.C + c];
-            }
-            const double mean = s1 / M;
-            double var = s2 / M - mean * mean;
-            if (var < 0.0) var = 0.0;
-            const double unb = M > 1.0 ? var * M / (M - 1.0) : var;
-            rm = a.momentum * (float)mean + (1.f - a.momentum) * rm;
-            rv = a.momentum * (float)unb + (1.f - a.momentum) * rv;
-        }
-        a.running[d.stat_off + c] = rm;
-        a.running[d.stat_off + d.C + c] = rv;
-    }
-    if (threadIdx.x == 0 && a.nbt) a.nbt[blockIdx.x] += a.n_chains;
-}
-int launch_bn_running_update(const BnRunArgs& a, hipStream_t s) {
-    ProfScope ps(PROF_BN, s);
-    hipLaunchKernelGGL(bn_running_update_kernel, dim3(a.n_bn), dim3(256), 0, s, a);
-    OCL_LAUNCH_CHECK();
-    return OCL_OK;
-}
-
-__global__ void __launch_bounds__(256) add_inplace_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n4, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n4) {
-        float4 a = ((float4*)dst)[i];
-        const float4 b = ((const float4*)src)[i];
-        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-        ((float4*)dst)[i] = a;
-    }
-    if (i == 0)
-        for (int64_t j = n4 * 4; j < n; ++j) dst[j] += src[j];
-}
-int launch_add_inplace(float* dst, const float* src, int64_t n, hipStream_t s) {
-    if (n <= 0) return OCL_OK;
-    ProfScope ps(PROF_BN, s);
-    const int64_t n4 = n / 4;
-    hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)std::max<int64_t>(1, (n4 + 255) / 256)), dim3(256), 0, s, dst, src, n4, n);
-    OCL_LAUNCH_CHECK();
-    return OCL_OK;
-}
-
 __global__ void __launch_bounds__(256) bn_fold_kernel(const float* __restrict__ params, const float* __restrict__ running,
                                                       float* __restrict__ out, const BnFoldDesc* __restrict__ descs, float eps) {
     const BnFoldDesc d = descs[blockIdx.x];

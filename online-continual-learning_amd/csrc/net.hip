@@ -96,17 +96,12 @@ struct ocl_net {
     std::vector<bool> slot_valid, slot_frozen;
     std::map<std::pair<int, int>, PlanSet> plans;
 
-    // scratch of the second chain (dual-chain passes, see ocl_net_forward) + its gradient staging array
-    int64_t off_g2[5] = {0, 0, 0, 0, 0}, off_dy2[6] = {0, 0, 0, 0, 0, 0};
-    int64_t off_partial2 = 0, off_stats2 = 0, off_bsums2 = 0, off_grad2 = 0;
-    int64_t trunk_params = 0;   // the trunk's tensors occupy [0, trunk_params) of the flat parameter array
-
     float* slotf(int slot) const { return (float*)(ws + slot_base + (int64_t)slot * slot_bytes); }
-    float* gbuf(int i, int ch = 0) const { return (float*)(ws + (ch ? off_g2[i] : off_g[i])); }
-    float* dybuf(int i, int ch = 0) const { return (float*)(ws + (ch ? off_dy2[i] : off_dy[i])); }
-    float* partialbuf(int ch) const { return (float*)(ws + (ch ? off_partial2 : off_partial)); }
-    double* statsbuf(int ch) const { return (double*)(ws + (ch ? off_stats2 : off_stats)); }
-    double* bsumsbuf(int ch) const { return (double*)(ws + (ch ? off_bsums2 : off_bsums)); }
+    float* gbuf(int i) const { return (float*)(ws + off_g[i]); }
+    float* dybuf(int i) const { return (float*)(ws + off_dy[i]); }
+    float* partialbuf() const { return (float*)(ws + off_partial); }
+    double* statsbuf() const { return (double*)(ws + off_stats); }
+    double* bsumsbuf() const { return (double*)(ws + off_bsums); }
 
     // second stream for the weight gradients + events (created on first backward)
     hipStream_t s2 = nullptr;
@@ -117,28 +112,6 @@ struct ocl_net {
     int dy_next = 0;
     size_t ev_next = 0;
 
-    // hipGraph cache: the launch sequence of a forward / backward depends only on the key below (all other pointers are
-    // engine-owned or bound once), so from the kGraphWarmCalls-th call with the same key on it is replayed as one graph
-    // launch: ~0.1 us of host time per kernel node instead of 4-5 us per hipLaunchKernel (measured, kbench launch).
-    struct GraphKey {
-        int kind, N, groups, slot, aux;
-        uint32_t flags;
-        const float* P;
-        bool operator<(const GraphKey& o) const {
-            return std::tie(kind, N, groups, slot, aux, flags, P) < std::tie(o.kind, o.N, o.groups, o.slot, o.aux, o.flags, o.P);
-        }
-    };
-    struct GraphEntry {
-        hipGraphExec_t exec = nullptr;
-        int hits = 0;
-        bool failed = false;
-        uint64_t last_use = 0;
-    };
-    std::map<GraphKey, GraphEntry> graphs;
-    uint64_t graph_clock = 0;
-    hipStream_t sc = nullptr;   // capture stream (the caller's stream may be the legacy default stream, which cannot capture)
-    int64_t graph_launches = 0, graph_captures = 0;
-    int dual_mode = -1;   // -1: default (environment), 0: single chain, 1: dual chain replayed as graphs, 2: dual chain, eager launches
 };
 
 // -----------------------------------------------------------------------------------------------------
@@ -351,20 +324,6 @@ static int build_layout(ocl_net* n) {
     n->off_descs = takeb((int64_t)(n->convs.size() * sizeof(PackDesc) + n->bns.size() * sizeof(BnFoldDesc) + 256));
     n->head_floats = N * ((int64_t)n->feat_dim * 3 + n->out_dim * 2 + 64);
     n->off_head = takeb(n->head_floats * 4);
-    for (int i = 0; i < 5; ++i) n->off_g2[i] = takeb(max_act * 4);
-    for (int i = 0; i < ocl_net::kDyRing; ++i) n->off_dy2[i] = takeb(max_act * 4);
-    n->off_partial2 = takeb(n->partial_floats * 4);
-    n->off_stats2 = takeb(n->stats_doubles * 8);
-    n->off_bsums2 = takeb(n->bsums_doubles * 8);
-    n->off_grad2 = takeb(n->n_params * 4);
-    {   // conv / BatchNorm tensors were added first: they form a prefix of the flat array
-        int64_t end = 0, sum = 0;
-        for (auto& cv : n->convs) { end = std::max(end, n->tensors[cv.w_t].off + n->tensors[cv.w_t].numel); sum += n->tensors[cv.w_t].numel; }
-        for (auto& b : n->bns) {
-            for (int t : {b.gamma_t, b.beta_t}) { end = std::max(end, n->tensors[t].off + n->tensors[t].numel); sum += n->tensors[t].numel; }
-        }
-        n->trunk_params = end == sum ? end : 0;   // 0 disables the dual-chain backward
-    }
     n->slot_base = w;
     n->slot_bytes = align_up(n->slot_floats * 4, 256);
     w += n->slot_bytes * d.n_slots;
@@ -502,29 +461,8 @@ static int head_forward(ocl_net* n, const float* P, float* feat, float* h1, floa
     return rc;
 }
 
-// -----------------------------------------------------------------------------------------------------
-// hipGraph replay of a launch sequence
-// -----------------------------------------------------------------------------------------------------
-static const int kGraphWarmCalls = 2;     // eager calls with a key before it is captured (lazy allocations, plans, rare shapes)
-static const size_t kMaxGraphs = 48;
-
-// Dual-chain mode (see ocl_net_forward): OCL_DUAL_CHAIN = 0 (default) single chain, 1 two chains replayed as graphs, 2 two chains
-// with eager launches; ocl_net_graph_enable() overrides the environment per net.  Measured on the SCR step (N = 220): 2.70 ms with
-// one chain (+ the weight-gradient stream), 2.93 ms with two chains, graphs or not -- the half-size launches of the two chains slow
-// each other down by more than the interleaving recovers, so this stays an opt-in experiment.
 static const int kTwoStreamMinBatch = 48;
 static const int kSideExtraMinBatch = 96;   // projection shortcut / head weight gradients on the side stream (MIR's 50-image passes lose 3 %)
-static const int kDualMinHalf = 8;
-static int dual_mode(const ocl_net* n) {
-    static const int env = [] {
-        const char* e = getenv("OCL_DUAL_CHAIN");
-        return e ? atoi(e) : 0;
-    }();
-    if (prof_on() || n->dbg_stop >= 0 || n->trunk_params == 0) return 0;
-    static const bool env_single = [] { const char* e = getenv("OCL_SINGLE_STREAM"); return e && e[0] == '1'; }();
-    if (env_single) return 0;
-    return n->dual_mode >= 0 ? n->dual_mode : env;
-}
 
 static int ensure_side_stream(ocl_net* n) {
     if (n->s2) return OCL_OK;
@@ -553,76 +491,6 @@ static int side_join(ocl_net* n, hipStream_t s) {
     OCL_HIP(hipEventRecord(e, n->s2));
     OCL_HIP(hipStreamWaitEvent(s, e, 0));
     return OCL_OK;
-}
-
-// body(stream, capturing): issues the launches.  Returns through *replayed whether a graph ran instead of the eager body.
-template <class F>
-static int run_cached(ocl_net* n, const ocl_net::GraphKey& key, hipStream_t s, bool enabled, F&& body) {
-    if (!enabled) return body(s, false);
-    ocl_net::GraphEntry& e = n->graphs[key];
-    e.last_use = ++n->graph_clock;
-    if (e.exec) {
-        OCL_HIP(hipGraphLaunch(e.exec, s));
-        ++n->graph_launches;
-        return OCL_OK;
-    }
-    if (e.failed || ++e.hits <= kGraphWarmCalls) {
-        if (n->graphs.size() > 4 * kMaxGraphs) {   // keys that never repeat (fresh parameter pointers): forget the cold ones
-            for (auto it = n->graphs.begin(); it != n->graphs.end();)
-                it = (!it->second.exec && it->second.last_use + 2 * kMaxGraphs < n->graph_clock) ? n->graphs.erase(it) : std::next(it);
-        }
-        return body(s, false);
-    }
-    int rc = ensure_side_stream(n);
-    if (rc != OCL_OK) return rc;
-    if (!n->sc) OCL_HIP(hipStreamCreateWithFlags(&n->sc, hipStreamNonBlocking));
-    hipError_t he = hipStreamBeginCapture(n->sc, hipStreamCaptureModeThreadLocal);
-    if (he != hipSuccess) {
-        (void)hipGetLastError();
-        e.failed = true;
-        return body(s, false);
-    }
-    rc = body(n->sc, true);
-    hipGraph_t g = nullptr;
-    he = hipStreamEndCapture(n->sc, &g);
-    if (rc != OCL_OK || he != hipSuccess || !g) {
-        (void)hipGetLastError();
-        if (g) (void)hipGraphDestroy(g);
-        e.failed = true;
-        if (rc != OCL_OK) return rc;
-        return body(s, false);
-    }
-    hipGraphExec_t ex = nullptr;
-    he = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(g);
-    if (he != hipSuccess || !ex) {
-        (void)hipGetLastError();
-        e.failed = true;
-        return body(s, false);
-    }
-    e.exec = ex;
-    ++n->graph_captures;
-    size_t live = 0;
-    for (auto& kv : n->graphs) live += kv.second.exec != nullptr;
-    if (live > kMaxGraphs) {   // drop the least recently used executable
-        auto victim = n->graphs.end();
-        for (auto it = n->graphs.begin(); it != n->graphs.end(); ++it)
-            if (it->second.exec && it->second.exec != ex && (victim == n->graphs.end() || it->second.last_use < victim->second.last_use))
-                victim = it;
-        if (victim != n->graphs.end()) {
-            (void)hipGraphExecDestroy(victim->second.exec);
-            n->graphs.erase(victim);
-        }
-    }
-    OCL_HIP(hipGraphLaunch(ex, s));
-    ++n->graph_launches;
-    return OCL_OK;
-}
-
-static void drop_graphs(ocl_net* n) {
-    for (auto& kv : n->graphs)
-        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
-    n->graphs.clear();
 }
 
 // =====================================================================================================
@@ -654,9 +522,7 @@ void ocl_net_destroy(ocl_net* net) {
         if (net->ev_done[i]) (void)hipEventDestroy(net->ev_done[i]);
     if (net->ev_join) (void)hipEventDestroy(net->ev_join);
     if (net->ev_fork) (void)hipEventDestroy(net->ev_fork);
-    drop_graphs(net);
     if (net->s2) (void)hipStreamDestroy(net->s2);
-    if (net->sc) (void)hipStreamDestroy(net->sc);
     delete net;
 }
 
@@ -707,7 +573,6 @@ int ocl_net_bind(ocl_net* net, float* params, float* grads, float* running, int6
     net->bound = true;
     net->descs_uploaded = false;
     net->pack_src = nullptr;
-    drop_graphs(net);   // they hold the previous binding's pointers
     for (size_t i = 0; i < net->slot_valid.size(); ++i) net->slot_valid[i] = false;
     return OCL_OK;
 }
@@ -715,14 +580,15 @@ int ocl_net_bind(ocl_net* net, float* params, float* grads, float* running, int6
 }  // extern "C"
 
 // -----------------------------------------------------------------------------------------------------
-// Train-mode trunk, one chain: images [img0, img0+Nc) of the batch as G BatchNorm groups (group indices g0..g0+G-1 of the saved
-// statistics), on scratch set `ch`, every launch on `st`.  upd: update the running statistics inside the BatchNorm kernels
-// (single chain); a dual-chain pass updates them afterwards, in group order, from both chains' statistics.
+// Train-mode trunk: images [0, Nc) of the batch as G BatchNorm groups, every launch on `st`.  upd: update the running statistics
+// inside the BatchNorm kernels (once per group, in group order = the reference's separate forward calls).  side: the projection
+// shortcuts run on the engine's second stream.  frozen: BatchNorm normalises with the running statistics (eval-mode tape).
 // -----------------------------------------------------------------------------------------------------
-static int trunk_forward_train(ocl_net* n, PlanSet* ps, const float* P, float* S, int img0, int Nc, int G, int g0, int ch, bool upd,
-                               float* feat, hipStream_t st, bool side = false, bool frozen = false) {
+static int trunk_forward_train(ocl_net* n, PlanSet* ps, const float* P, float* S, int Nc, int G, bool upd, float* feat, hipStream_t st,
+                               bool side = false, bool frozen = false) {
+    const int img0 = 0, g0 = 0;
     float* pack = (float*)(n->ws + n->off_pack);
-    double* stats = n->statsbuf(ch);
+    double* stats = n->statsbuf();
     int rc = OCL_OK;
     OCL_HIP(hipMemsetAsync(stats, 0, n->stats_doubles * 8, st));
     auto at = [&](int64_t off, const ConvInfo& c) { return S + off + (int64_t)img0 * c.Ho * c.Wo * c.Cout; };
@@ -773,7 +639,7 @@ static int trunk_forward_train(ocl_net* n, PlanSet* ps, const float* P, float* S
             hipStream_t ss = side ? n->s2 : st;
             if (side && (rc = side_wait(n, st))) return rc;       // `cur` (and the zeroed statistics) are ready
             if ((rc = conv_stats(b.convs, cur, ss))) return rc;
-            float* sc = n->gbuf(0, ch);
+            float* sc = n->gbuf(0);
             if ((rc = bn_fwd(b.convs, at(cs.y_off, cs), sc, nullptr, 0, ss))) return rc;
             res = sc;
         }
@@ -785,31 +651,6 @@ static int trunk_forward_train(ocl_net* n, PlanSet* ps, const float* P, float* S
         cur = z;
     }
     return launch_avgpool_fwd(cur, feat, Nc, n->Hf, n->Wf, n->convs[n->blocks.back().conv2].Cout, st);
-}
-
-// running_mean / running_var / num_batches_tracked of every BatchNorm after a dual-chain forward: one update per chain, chain 0
-// first (the reference forwards view 1, then view 2)
-static int running_update(ocl_net* n, int Nc, hipStream_t s) {
-    BnRunArgs a;
-    memset(&a, 0, sizeof(a));
-    OCL_REQUIRE((int)n->bns.size() <= kBnRunMax, "running_update: %zu BatchNorms", n->bns.size());
-    a.stats[0] = n->statsbuf(0);
-    a.stats[1] = n->statsbuf(1);
-    a.n_chains = 2;
-    a.rep_stride = n->stats_rep_stride;
-    a.momentum = 0.1f;
-    a.running = n->running;
-    a.nbt = n->nbt;
-    a.n_bn = (int)n->bns.size();
-    for (auto& c : n->convs) {
-        const BnInfo& b = n->bns[c.bn];
-        BnRunDesc& d = a.d[c.bn];
-        d.stat_off = (int)b.stat_off;
-        d.C = b.C;
-        d.arena_off = (int)b.arena_off;
-        d.M = Nc * c.Ho * c.Wo;
-    }
-    return launch_bn_running_update(a, s);
 }
 
 extern "C" {
@@ -832,15 +673,8 @@ int ocl_net_forward(ocl_net* n, const float* x, int N, int groups, uint32_t flag
         if (rc != OCL_OK) return rc;
     }
     const float* P = params_override ? params_override : n->params;
-    // Two chains (opt-in, see dual_mode): the two views of an SCR step (groups == 2) share nothing but the weights until the
-    // projection head, and almost every launch of the trunk is a single round of workgroups followed by a full drain.  Each view
-    // can run as its own chain of launches on its own stream and scratch buffers, so that one chain's drains and ramps are
-    // filled by the other's kernels; each chain is a plain sequence, replayed as one hipGraph (graphs with parallel branches
-    // leave the fast path on ROCm 7.2, two single-chain graphs on two streams do not).
-    const int dm = dual_mode(n);
-    const bool dual = train && !frozen && groups == 2 && dm != 0 && N / 2 >= kDualMinHalf;
     PlanSet* ps = nullptr;
-    int rc = get_plans(n, dual ? N / 2 : N, (train && !dual) ? groups : 1, &ps);
+    int rc = get_plans(n, N, train ? groups : 1, &ps);
     if (rc != OCL_OK) return rc;
     float* pack = (float*)(n->ws + n->off_pack);
     int max_elems = 0;
@@ -858,30 +692,12 @@ int ocl_net_forward(ocl_net* n, const float* x, int N, int groups, uint32_t flag
     const bool feat_direct = feat_out && !out && !(flags & OCL_FWD_SAVE_TAPE);   // features only (ASER scoring, NCM): no copy
     float* feat = feat_direct ? feat_out : S + n->feat_off;
     const bool upd = (flags & OCL_FWD_UPDATE_RUNNING) != 0;
-    if (train && dual) {
-        if ((rc = ensure_side_stream(n))) return rc;
-        const int Nc = N / 2;
-        float* featS = S + n->feat_off;   // graphs hold engine pointers only
-        OCL_HIP(hipEventRecord(n->ev_fork, s));
-        OCL_HIP(hipStreamWaitEvent(n->s2, n->ev_fork, 0));
-        for (int ch = 0; ch < 2; ++ch) {
-            ocl_net::GraphKey key{2, Nc, 1, slot, ch, flags, P};
-            auto body = [&](hipStream_t st, bool) -> int {
-                return trunk_forward_train(n, ps, P, S, ch * Nc, Nc, 1, ch, ch, false, featS + (int64_t)ch * Nc * n->feat_dim, st);
-            };
-            if ((rc = run_cached(n, key, ch ? n->s2 : s, dm == 1, body))) return rc;
-        }
-        OCL_HIP(hipEventRecord(n->ev_join, n->s2));
-        OCL_HIP(hipStreamWaitEvent(s, n->ev_join, 0));
-        if (upd && (rc = running_update(n, Nc, s))) return rc;
-        if (feat_direct) OCL_HIP(hipMemcpyAsync(feat_out, featS, (size_t)N * n->feat_dim * 4, hipMemcpyDeviceToDevice, s));
-        feat = featS;
-    } else if (train) {
+    if (train) {
         static const bool env_single = [] { const char* e = getenv("OCL_SINGLE_STREAM"); return e && e[0] == '1'; }();
         static const bool env_noextra = [] { const char* e = getenv("OCL_SIDE_EXTRA"); return e && e[0] == '0'; }();
         const bool side = n->dbg_stop < 0 && N >= kSideExtraMinBatch && !prof_on() && !env_single && !env_noextra;
         if (side && (rc = ensure_side_stream(n))) return rc;
-        if ((rc = trunk_forward_train(n, ps, P, S, 0, N, groups, 0, 0, upd && !frozen, feat, s, side, frozen))) return rc;
+        if ((rc = trunk_forward_train(n, ps, P, S, N, groups, upd && !frozen, feat, s, side, frozen))) return rc;
     } else {
         float* fold = (float*)(n->ws + n->off_fold);
         if ((rc = launch_bn_fold(P, n->running, fold, fold_descs(n), (int)n->bns.size(), 1e-5f, s))) return rc;
@@ -931,24 +747,23 @@ int ocl_net_forward(ocl_net* n, const float* x, int N, int groups, uint32_t flag
 }  // extern "C"
 
 // -----------------------------------------------------------------------------------------------------
-// Backward of the trunk, one chain: images [img0, img0+Nc) (G groups from group index g0) from dL/dfeat (this chain's rows) to the
-// parameter gradients in Gr (overwritten or accumulated).  side != null: the weight gradients go to that stream behind events
-// (single-chain passes of large batches); null: everything on `s`, in order (dual-chain passes, small batches, measurements).
+// Backward of the trunk: from dL/dfeat to the parameter gradients in Gr (overwritten or accumulated).  side != null: the weight
+// gradients go to that stream behind events (large batches); null: everything on `s`, in order (small batches, measurements).
 // -----------------------------------------------------------------------------------------------------
-static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, float* S, int img0, int Nc, int G, int g0, int ch,
-                          int accumulate, const float* dfeat, hipStream_t s, hipStream_t side, bool ch_shared = false,
-                          bool frozen = false) {
+static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, float* S, int Nc, int G, int accumulate, const float* dfeat,
+                          hipStream_t s, hipStream_t side, bool frozen = false) {
+    const int img0 = 0, g0 = 0;
     float* pack = (float*)(n->ws + n->off_pack);
-    float* partial = n->partialbuf(ch);
-    double* bsums = n->bsumsbuf(ch);
+    float* partial = n->partialbuf();
+    double* bsums = n->bsumsbuf();
     int rc = OCL_OK;
     OCL_HIP(hipMemsetAsync(bsums, 0, n->bsums_doubles * 8, s));
     auto T = [&](int t) { return P + n->tensors[t].off; };
     auto GT = [&](int t) { return Gr + n->tensors[t].off; };
     auto at = [&](int64_t off, const ConvInfo& c) { return S + off + (int64_t)img0 * c.Ho * c.Wo * c.Cout; };
-    float* gA = n->gbuf(0, ch);  // grad wrt current block output
-    float* gD = n->gbuf(3, ch);
-    float* gE = n->gbuf(4, ch);
+    float* gA = n->gbuf(0);  // grad wrt current block output
+    float* gD = n->gbuf(3);
+    float* gE = n->gbuf(4);
     float* gB = nullptr;         // dL/dy of the main-path BatchNorm being processed (ring slot)
     float* gC = nullptr;         // dL/dy of the projection-shortcut BatchNorm
     const int Clast = n->convs[n->blocks.back().conv2].Cout;
@@ -966,7 +781,7 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
             n->ev_done_pending[r] = false;
         }
         *slot_out = r;
-        return n->dybuf(r, ch);
+        return n->dybuf(r);
     };
     auto publish = [&]() -> int {   // everything the main stream has written so far is visible to the wgrad stream
         return two_streams ? side_wait(n, s) : OCL_OK;
@@ -1001,9 +816,8 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
         }
         // sums are addressed [set][G][2][C] inside conv_a's arena of kGmax*2*C doubles: two sets need 2*G <= kGmax
         a.sums = bsums + n->bns[ca.bn].arena_off;
-        // one-pass kernel (one BatchNorm, <= 2 groups); not for the two-chain schedule (two such kernels at once could each hold CUs
-        // the other waits for)
-        if (conv_b < 0 && G <= 2 && !ch_shared) {
+        // one-pass kernel (one BatchNorm, <= 2 groups)
+        if (conv_b < 0 && G <= 2) {
             a.fsums = bsums + n->bns[ca.bn].fused_off;
             a.barrier = (unsigned*)(a.fsums + (int64_t)8 * 2 * 2 * ca.Cout);
         }
@@ -1109,11 +923,9 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
     OCL_REQUIRE(dout, "net_backward: null dout");
     hipStream_t s = (hipStream_t)stream;
     const int N = n->slot_n[slot], G = n->slot_groups[slot];
-    const int dm = dual_mode(n);
     const bool frozen = n->slot_frozen[slot];
-    const bool dual = G == 2 && dm != 0 && N / 2 >= kDualMinHalf && !frozen;
     PlanSet* ps = nullptr;
-    int rc = get_plans(n, dual ? N / 2 : N, dual ? 1 : G, &ps);
+    int rc = get_plans(n, N, G, &ps);
     if (rc != OCL_OK) return rc;
     n->slot_valid[slot] = false;  // a tape is consumed once (activation buffers are not preserved past this point)
     float* S = n->slotf(slot);
@@ -1146,7 +958,7 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
     // 10-20 images are latency-bound: the event traffic costs more than the overlap returns there.  Debug stops and measurement
     // runs (ocl_prof_enable, OCL_SINGLE_STREAM=1: per-kernel durations of the kernel alone) stay on one stream as well.
     static const bool env_single = [] { const char* e = getenv("OCL_SINGLE_STREAM"); return e && e[0] == '1'; }();
-    const bool two_streams = !dual && n->dbg_stop < 0 && N >= kTwoStreamMinBatch && !prof_on() && !env_single;
+    const bool two_streams = n->dbg_stop < 0 && N >= kTwoStreamMinBatch && !prof_on() && !env_single;
     if (two_streams && (rc = ensure_side_stream(n))) return rc;
     auto lin_bwd = [&](const float* dy, int ncol, const float* xin, int kin, int tw, int tb, float* dx) -> int {
         // y = x W^T + b, W [ncol, kin]
@@ -1180,40 +992,7 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
         }
     }
     // ---- trunk ------------------------------------------------------------------------------------
-    if (dual) {
-        // One chain per view (see ocl_net_forward).  Chain 0 writes the caller's gradient array, chain 1 a staging array that is
-        // added once both are done: no cross-chain ordering inside the chains, and a fixed summation order.
-        if ((rc = ensure_side_stream(n))) return rc;
-        const int Nc = N / 2;
-        float* G2 = (float*)(n->ws + n->off_grad2);
-        OCL_HIP(hipEventRecord(n->ev_fork, s));
-        OCL_HIP(hipStreamWaitEvent(n->s2, n->ev_fork, 0));
-        for (int ch = 0; ch < 2; ++ch) {
-            ocl_net::GraphKey key{3, Nc, 1, slot, ch | (accumulate ? 2 : 0), 0u, P};
-            auto body = [&](hipStream_t st, bool) -> int {
-                return trunk_backward(n, ps, P, ch ? G2 : Gr, S, ch * Nc, Nc, 1, ch, ch, ch ? 0 : accumulate, dfeat + (int64_t)ch * Nc * FD, st,
-                                      nullptr, true);
-            };
-            if ((rc = run_cached(n, key, ch ? n->s2 : s, dm == 1, body))) return rc;
-        }
-        OCL_HIP(hipEventRecord(n->ev_join, n->s2));
-        OCL_HIP(hipStreamWaitEvent(s, n->ev_join, 0));
-        return launch_add_inplace(Gr, G2, n->trunk_params, s);
-    }
-    return trunk_backward(n, ps, P, Gr, S, 0, N, G, 0, 0, accumulate, dfeat, s, two_streams ? n->s2 : nullptr, false, frozen);
-}
-
-int ocl_net_graph_enable(ocl_net* n, int mode) {
-    OCL_REQUIRE(n && mode >= -1 && mode <= 2, "graph_enable: net / mode %d", mode);
-    n->dual_mode = mode;
-    return OCL_OK;
-}
-
-int ocl_net_graph_stats(const ocl_net* n, int64_t* launches, int64_t* captures) {
-    OCL_REQUIRE(n, "graph_stats: null net");
-    if (launches) *launches = n->graph_launches;
-    if (captures) *captures = n->graph_captures;
-    return OCL_OK;
+    return trunk_backward(n, ps, P, Gr, S, N, G, accumulate, dfeat, s, two_streams ? n->s2 : nullptr, frozen);
 }
 
 int ocl_net_debug_stop(ocl_net* n, int stage) {
