@@ -47,6 +47,10 @@ int ocl_gather_rows(const void* src, const int64_t* idx, int64_t n, int64_t row_
                     void* stream);
 int ocl_scatter_rows(void* dst, const int64_t* idx, int64_t n, int64_t row_bytes, const void* src,
                      void* stream);
+/* Host -> device upload of a small host array (index vectors the reference builds with torch.tensor(...) / torch.from_numpy(...)
+ * and moves with maybe_cuda: utils/buffer/buffer_utils.py:17-21, reservoir_update.py:52-60).  Asynchronous on `stream`; `host`
+ * may be reused as soon as the call returns (payloads <= 64 KB are staged through pinned memory). */
+int ocl_upload(const void* host, int64_t nbytes, void* dev, void* stream);
 /* dataset_transform + ToTensor for a whole minibatch (continuum/data_utils.py:38-54,
  * utils/setup_elements.py:29-43): gathers n HWC uint8 images by index from a device-resident task
  * tensor and writes CHW fp32 / 255. */
@@ -148,6 +152,14 @@ int ocl_cosine_max(const float* mem, int k, int64_t n, const float* g, float eps
 #define OCL_AUG_NPARAM 12
 int ocl_scr_augment(const float* x, float* out, int n, int h, int w, const float* params,
                     void* stream);
+/* Same, with the parameter arithmetic on the device: u holds n rows of OCL_AUG_NUNIFORM raw U[0,1) draws (host generator,
+ * one torch.rand call as before): [0,10) crop areas, [10,20) crop log-ratios of the 10 attempts RandomResizedCrop makes,
+ * [20,30) position y / x, flip, jitter-on, brightness, contrast, saturation, hue, order, gray.  cfg12 (HOST array):
+ * scale_lo, scale_hi, ratio_lo, ratio_hi, brightness, contrast, saturation, hue, p_jitter, p_gray, fallback crop w, h.
+ * params [n, OCL_AUG_NPARAM] (device) receives the derived per-image parameters (the layout ocl_scr_augment takes). */
+#define OCL_AUG_NUNIFORM 30
+int ocl_scr_augment_uniform(const float* x, float* out, int n, int h, int w, const float* u, const double* cfg12,
+                            float* params, void* stream);
 
 /* ---- small dense GEMM (K5 helper; exposed for tests) ----------------------------------------------
  * C[m,n] = A(m,k) * B(k,n) (+ bias[n]) (relu) with arbitrary element strides, exact-fp32 MFMA

@@ -29,14 +29,40 @@ class ScrAugment(object):
         self.scale, self.ratio, self.jitter = scale, ratio, jitter
         self.p_jitter, self.p_gray = p_jitter, p_gray
 
+    TRIES = 10
+
+    def draw(self, n):
+        """All random numbers of one call: ONE torch.rand on the CPU generator, [n, 30]."""
+        return torch.rand(n, 2 * self.TRIES + 10)
+
+    def fallback_crop(self):
+        """Centre crop used when none of the 10 attempts fits: whole image, aspect ratio clamped into `ratio` (torchvision get_params)."""
+        h, w = float(self.h), float(self.w)
+        in_ratio = w / h
+        if in_ratio < self.ratio[0]:
+            return w, round(w / self.ratio[0])
+        if in_ratio > self.ratio[1]:
+            return round(h * self.ratio[1]), h
+        return w, h
+
+    def config(self):
+        """The 12 numbers ocl_scr_augment_uniform takes (include/ocl_hip.h)."""
+        fw, fh = self.fallback_crop()
+        return [self.scale[0], self.scale[1], self.ratio[0], self.ratio[1], self.jitter[0], self.jitter[1], self.jitter[2],
+                self.jitter[3], self.p_jitter, self.p_gray, fw, fh]
+
     def sample_params(self, n):
-        """Crop boxes the way torchvision / kornia draw them (RandomResizedCrop.get_params; kornia 0.4.1 random_crop_size_generator):
+        return self.params_from_uniform(self.draw(n))
+
+    def params_from_uniform(self, u):
+        """Host statement of the parameter arithmetic (the device kernel `aug_params_kernel` is tested against it).
+        Crop boxes the way torchvision / kornia draw them (RandomResizedCrop.get_params; kornia 0.4.1 random_crop_size_generator):
         up to 10 attempts of (area ~ U(scale) * H * W, log-ratio ~ U(log ratio)), integer width / height, the first attempt that
         fits inside the image wins; if none fits, the centre crop with the aspect ratio clamped into `ratio`.  The position is
         uniform over the placements that keep the box inside the image.  All draws come from the torch CPU generator."""
         h, w = float(self.h), float(self.w)
-        tries = 10
-        u = torch.rand(n, 2 * tries + 10)
+        tries = self.TRIES
+        n = u.shape[0]
         area = (self.scale[0] + (self.scale[1] - self.scale[0]) * u[:, :tries]) * h * w
         logr = math.log(self.ratio[0]) + (math.log(self.ratio[1]) - math.log(self.ratio[0])) * u[:, tries:2 * tries]
         r = torch.exp(logr)
@@ -47,14 +73,8 @@ class ScrAugment(object):
         cw = cw_try.gather(1, first[:, None]).squeeze(1)
         ch = ch_try.gather(1, first[:, None]).squeeze(1)
         none = ~fits.any(1)
-        if none.any():   # fallback: centre crop, aspect ratio clamped (torchvision get_params)
-            in_ratio = w / h
-            if in_ratio < self.ratio[0]:
-                fw, fh = w, round(w / self.ratio[0])
-            elif in_ratio > self.ratio[1]:
-                fw, fh = round(h * self.ratio[1]), h
-            else:
-                fw, fh = w, h
+        if none.any():
+            fw, fh = self.fallback_crop()
             cw = torch.where(none, torch.full_like(cw, float(fw)), cw)
             ch = torch.where(none, torch.full_like(ch, float(fh)), ch)
         e = u[:, 2 * tries:]
@@ -76,8 +96,14 @@ class ScrAugment(object):
         return p
 
     def __call__(self, x):
-        params = ops.upload(self.sample_params(x.shape[0]), x.device)
-        return ops.scr_augment(x, params)
+        # the draws on the host generator (one call, as before); everything derived from them on the device: the ~40 small CPU
+        # tensor ops of params_from_uniform cost 0.25 ms of host time per step
+        u = ops.upload(self.draw(x.shape[0]), x.device)
+        if debug.on():
+            out, params = ops.scr_augment_uniform(x, u, self.config(), want_params=True)
+            debug.emit("scr_augment", params=params.cpu().numpy())
+            return out
+        return ops.scr_augment_uniform(x, u, self.config())
 
 
 class SupContrastReplay(ContinualLearner):

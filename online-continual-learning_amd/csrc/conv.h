@@ -56,6 +56,10 @@ struct ConvArgs {
     int Qc, Qpad;               // (tap, channel-quad) groups of one channel chunk; rounded up to whole rounds of 4
     int QS, nstage, wres;       // groups per weight stage, stages per chunk; 1: all weights stay in LDS for the workgroup's lifetime
     int aligned;                // 1: every tile starts at a lattice row and holds whole rows / whole images: a lane's pixel geometry is tile-invariant
+    // output classes sharing one launch (the four parity classes of a stride-2 data gradient: same input window, disjoint taps and
+    // output lattices).  cls_pack = ncls | ntaps(class 0) << 4 | ntaps(class 1) << 8 | ...: the taps are listed class by class;
+    // cls_oyx bit 2c = oy0 of class c, bit 2c+1 = ox0.  One class (ncls = 1): an ordinary convolution.
+    int cls_pack, cls_oyx;
     unsigned m_tpg, m_tpi, m_lw, m_ppi, m_kc4, m_pc, m_pr;   // ceil(2^32 / d) of the plan's divisors (exact quotients by one v_mul_hi)
     unsigned long long* trace;  // measurement only (kbench): per workgroup 64 s_memtime stamps of wave 0 at the phase boundaries
 };
@@ -81,6 +85,8 @@ struct ConvGeomDesc {
     int force_W, force_MT, force_NT, force_bpc;   // 0 = planner's choice (benchmarks / tests)
     int force_kind;             // 0 = planner's choice, 1 = conv_gemm_kernel, 2 = conv_t_kernel
     int WPT;                    // row stride of the K-grouped pack (0: the plan's own CoutP)
+    int ncls;                   // > 1: output classes of one launch (conv_t_kernel only), taps listed class by class
+    int cls_ntaps[4], cls_oy[4], cls_ox[4];
 };
 
 int plan_conv(const ConvGeomDesc& g, ConvPlan* p);
@@ -92,9 +98,10 @@ struct ConvShape {
 };
 int pack_width(int channels);   // row stride of a weight pack with `channels` columns (multiple of 16)
 // forward geometry; data-gradient geometry ("input" = dy, "output" = dx): one launch for stride 1 and for the 1x1
-// stride-2 shortcut, four dense parity classes of the dx lattice for 3x3 stride 2.
+// stride-2 shortcut, four dense parity classes of the dx lattice for 3x3 stride 2 (merge_classes: as ONE description with
+// four output classes when the lattices coincide, i.e. even input height and width).
 void geom_fwd(const ConvShape& c, int N, int groups, ConvGeomDesc* g);
-void geom_dgrad(const ConvShape& c, int N, std::vector<ConvGeomDesc>* out);
+void geom_dgrad(const ConvShape& c, int N, std::vector<ConvGeomDesc>* out, bool merge_classes = false);
 int launch_conv(const ConvPlan& p, hipStream_t s);
 
 // ---- wgrad -------------------------------------------------------------------------------------------
@@ -130,6 +137,21 @@ int launch_wgrad(const WgradPlan& p, hipStream_t s);
 // sums the S partials and writes/accumulates the OIHW gradient
 int launch_wgrad_reduce(const WgradPlan& p, float* grad_oihw, int accumulate, hipStream_t s);
 
+// all layers' reductions in one launch (single-stream backward of replay-sized batches)
+constexpr int kMaxReduceLayers = 24;
+struct WgradReduceLayer {
+    int64_t partial_off, grad_off;   // floats from `partial` / `grads`
+    int S, Mrows_total, CoutP, mrows_chunk, KC, ntaps, CinReal, Cout, block0;
+};
+struct WgradReduceMulti {
+    const float* partial;
+    float* grads;
+    int accumulate, n;
+    WgradReduceLayer L[kMaxReduceLayers];
+};
+void wgrad_reduce_layer(const WgradPlan& p, int64_t partial_off, int64_t grad_off, WgradReduceLayer* d);
+int launch_wgrad_reduce_multi(WgradReduceMulti m, hipStream_t s);
+
 // ---- weight packing -----------------------------------------------------------------------------------
 // fwd pack:   wf[t][ci][coP] = w[co][ci][t]          (ci padded with zero rows up to CinP)
 // dgrad pack: wd[t][co][ciP] = w[co][ci][t]
@@ -143,8 +165,9 @@ struct PackDesc {
     int64_t td_off;     // K-grouped dgrad pack, -1 = none
     int Cout, Cin, ntaps, CinP, CoutP, CiP;
 };
+enum { PACK_F = 1, PACK_D = 2, PACK_TF = 4, PACK_TD = 8, PACK_ALL = 15 };   // which packs a launch writes
 int launch_pack_weights(const float* params, float* arena, const PackDesc* descs_dev, int n_layers, int max_elems,
-                        hipStream_t s);
+                        hipStream_t s, int mask = PACK_ALL);
 
 // ---- layout / elementwise ------------------------------------------------------------------------------
 int launch_nchw3_to_nhwc4(const float* x, float* out, int N, int H, int W, hipStream_t s);

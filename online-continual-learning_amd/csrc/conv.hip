@@ -512,12 +512,13 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 constexpr int kMaxWgTiles = 64;                // tile descriptors a workgroup keeps in LDS
 
-template <int MT, int NT, int PF, bool RES>
+template <int MT, int NT, int PF, bool RES, bool CLS = false>   // CLS: several output classes per tile (merged parity classes of a stride-2 data gradient)
 __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     constexpr int COPW = 16 * MT;              // channels per workgroup (one channel split)
     int* tdesc = (int*)lds_raw;                // [kMaxWgTiles][8] per-tile geometry of this workgroup's tile range
-    int* qoff = tdesc + kMaxWgTiles * 8;       // [Qpad] patch offset (floats) of group q relative to a pixel's origin
+    int* ctab = tdesc + kMaxWgTiles * 8;       // [4][4] per output class: first group, groups (padded to rounds), output offset, weight stages
+    int* qoff = ctab + 16;                     // [Qpad] patch offset (floats) of group q relative to a pixel's origin
     int* qrow = qoff + a.Qpad;                 // [Qpad] row of the K-grouped pack (tap * C4tot + channel quad), -1: padding group
     float* wl = (float*)(qrow + a.Qpad);       // resident: [Qpad][COPW][4]; staged: [2][QS][COPW][4]
     float* patch = wl + (size_t)(RES ? a.Qpad : 2 * a.QS) * COPW * 4;   // [imgs][PR][PC][CP]
@@ -539,12 +540,34 @@ __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
     };
     stamp();   // 0: start
     // ---- tables: K groups, and the geometry of every tile of this workgroup (computed in parallel, read back as plain data) ------
+    const int ncls = CLS ? (a.cls_pack & 15) : 1;
     for (int q = tid; q < a.Qpad; q += 256) {
+        // the class of group q: classes follow each other, each padded to whole rounds of 4 groups
+        int c = 0, q0 = 0, t0 = 0;
+        int ntc = (a.cls_pack >> 4) & 15, nq = (ntc * kc4 + 3) & ~3;
+        while (c + 1 < ncls && q >= q0 + nq) {
+            q0 += nq; t0 += ntc; ++c;
+            ntc = (a.cls_pack >> (4 + 4 * c)) & 15;
+            nq = (ntc * kc4 + 3) & ~3;
+        }
+        const int ql = q - q0;
         int c4;
-        const int t = mdiv(q, a.m_kc4, kc4, c4);
-        const bool ok = q < a.Qc;
+        const int t = t0 + mdiv(ql, a.m_kc4, kc4, c4);
+        const bool ok = ql < ntc * kc4;
         qoff[q] = ok ? tap_sel(a.tpo, t) + 4 * c4 : 0;
         qrow[q] = ok ? tap_sel(a.tw, t) * a.C4tot + c4 : -1;
+    }
+    if (CLS && tid < 4) {
+        int q0 = 0, nq = 0;
+        for (int c = 0; c <= tid && c < ncls; ++c) {
+            q0 += nq;
+            nq = ((((a.cls_pack >> (4 + 4 * c)) & 15) * kc4) + 3) & ~3;
+        }
+        const int oy = (a.cls_oyx >> (2 * tid)) & 1, ox = (a.cls_oyx >> (2 * tid + 1)) & 1;
+        ctab[tid * 4 + 0] = q0;
+        ctab[tid * 4 + 1] = tid < ncls ? nq : 0;
+        ctab[tid * 4 + 2] = (oy * a.Wout + ox) * a.Cout;
+        ctab[tid * 4 + 3] = RES ? 1 : (nq + a.QS - 1) / a.QS;
     }
     if (tid < nwt) {
         const int tile = t_begin + tid;
@@ -594,15 +617,15 @@ __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
     stamp();   // P3: weight DMA issued
     // staged: stage s of chunk c0 covers groups [s*QS, s*QS + QS); unit u = tid + i*256 -> (group in stage, channel)
     float4 wv[RES ? 1 : kWPF];
-    auto w_prefetch = [&](int s_, int c0_) __attribute__((always_inline)) {
-        const int q0 = s_ * a.QS;
+    auto w_prefetch = [&](int s_, int c0_, int cls) __attribute__((always_inline)) {
+        const int q0 = (CLS ? ctab[cls * 4] : 0) + s_ * a.QS, qend = CLS ? ctab[cls * 4] + ctab[cls * 4 + 1] : a.Qpad;
         const int c4base = c0_ >> 2;
 #pragma unroll
         for (int i = 0; i < (RES ? 1 : kWPF); ++i) {
             const int u = tid + i * 256;
             const int qq = u / COPW, c = u - qq * COPW;
             const int q = q0 + qq;
-            const int row = (qq < a.QS && q < a.Qpad) ? qrow[q] : -1;
+            const int row = (qq < a.QS && q < qend) ? qrow[q] : -1;
             wv[i] = buf_load16(rs_w, (row >= 0 && c < wcol_ok) ? (((row + c4base) * a.WPT + n0 + c) * 4) * 4 : kOob);
         }
     };
@@ -707,7 +730,7 @@ __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
     }
 
     int st = 0;
-    if (!RES) w_prefetch(0, 0);
+    if (!RES) w_prefetch(0, 0, 0);
     // the resident weights (LDS-DMA) were in flight during the per-lane set-up above; every wave waits for ITS OWN DMA writes here
     // (a barrier does not wait for vector-memory operations), the barriers of the first tile publish them
     if (RES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -745,10 +768,6 @@ __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
             }
         }
         f32x4 acc[MT][NT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
         // operands of round rho+1 are read from LDS while the MFMAs of round rho issue (two register sets)
         auto rounds = [&](const float* wbase, int q0, int nq) __attribute__((always_inline)) {
@@ -784,32 +803,51 @@ __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
             if (rho < nr) fma4(0);
         };
 
+        // output classes (one for an ordinary convolution): with a single channel chunk they share the tile's patch; with several
+        // chunks every (class, chunk) stages its own
+        for (int cls = 0; cls < ncls; ++cls) {
+        const int4 ct = CLS ? *(const int4*)(ctab + cls * 4) : make_int4(0, a.Qpad, 0, a.nstage);   // first group, groups, output offset, weight stages
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         for (int chunk = 0; chunk < nchunks; ++chunk) {
             const int c0 = chunk * a.KC;
-            stamp();   // tile + 0: tile set-up done
-            __syncthreads();   // consumers of the previous patch are done
-            stamp();   // tile + 1: barrier passed
-            store_patch(d0.z);
-            stamp();   // tile + 2: patch arrived and written to LDS
-            if (chunk + 1 < nchunks) load_patch(k, c0 + a.KC);
-            else if (k + 1 < nwt) load_patch(k + 1, 0);
+            const bool fresh = (nchunks > 1) | (cls == 0);   // block-uniform
+            if (fresh) {
+                stamp();   // tile + 0: tile set-up done
+                __syncthreads();   // consumers of the previous patch are done
+                stamp();   // tile + 1: barrier passed
+                store_patch(d0.z);
+                stamp();   // tile + 2: patch arrived and written to LDS
+                if (chunk + 1 < nchunks) load_patch(k, c0 + a.KC);
+                else if (nchunks > 1 && cls + 1 < ncls) load_patch(k, 0);
+                else if (k + 1 < nwt) load_patch(k + 1, 0);
+            }
             if (RES) {
-                __syncthreads();   // patch (and, the first time, the resident weights) visible
-                stamp();   // tile + 3: second barrier passed
-                rounds(wl, 0, a.Qpad);
-                stamp();   // tile + 4: MFMAs issued
+                if (fresh) {
+                    __syncthreads();   // patch (and, the first time, the resident weights) visible
+                    stamp();   // tile + 3: second barrier passed
+                }
+                rounds(wl + (size_t)ct.x * COPW * 4, ct.x, ct.y);
+                if (fresh) stamp();   // tile + 4: MFMAs issued
             } else {
-                for (int s_ = 0; s_ < a.nstage; ++s_, ++st) {
+                for (int s_ = 0; s_ < ct.w; ++s_, ++st) {
                     w_commit(st & 1);
                     __syncthreads();   // stage st's weights (and the patch) visible; everyone is done with stage st-1
-                    {
-                        int ns = s_ + 1, nc0 = c0;
-                        if (ns >= a.nstage) { ns = 0; nc0 = c0 + a.KC; }
-                        if (nc0 >= a.Cin) nc0 = k + 1 < nwt ? 0 : -1;
-                        if (nc0 >= 0) w_prefetch(ns, nc0);
+                    {   // the stage after this one: next stage of the class, next chunk, next class, next tile
+                        int ns = s_ + 1, nc0 = c0, ncl = cls, nk = k;
+                        if (ns >= ct.w) {
+                            ns = 0; nc0 = c0 + a.KC;
+                            if (nc0 >= a.Cin) {
+                                nc0 = 0; ncl = cls + 1;
+                                if (ncl >= ncls) { ncl = 0; nk = k + 1; }
+                            }
+                        }
+                        if (nk < nwt) w_prefetch(ns, nc0, ncl);
                     }
-                    const int q0 = s_ * a.QS;
-                    rounds(wl + (size_t)(st & 1) * a.QS * COPW * 4, q0, min(a.QS, a.Qpad - q0));
+                    const int q0 = ct.x + s_ * a.QS;
+                    rounds(wl + (size_t)(st & 1) * a.QS * COPW * 4, q0, min(a.QS, ct.x + ct.y - q0));
                 }
             }
         }
@@ -828,7 +866,7 @@ __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
                         s1[mt][0] += v.x; s1[mt][1] += v.y; s1[mt][2] += v.z; s1[mt][3] += v.w;
                         s2[mt][0] = fmaf(v.x, v.x, s2[mt][0]); s2[mt][1] = fmaf(v.y, v.y, s2[mt][1]);
                         s2[mt][2] = fmaf(v.z, v.z, s2[mt][2]); s2[mt][3] = fmaf(v.w, v.w, s2[mt][3]);
-                        *(float4*)(a.out + (int64_t)ooff[nt] + co) = v;
+                        *(float4*)(a.out + (int64_t)ooff[nt] + ct.z + co) = v;
                     }
                 }
             }
@@ -846,18 +884,18 @@ __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
                     s2[mt][0] = fmaf(v.x, v.x, s2[mt][0]); s2[mt][1] = fmaf(v.y, v.y, s2[mt][1]);
                     s2[mt][2] = fmaf(v.z, v.z, s2[mt][2]); s2[mt][3] = fmaf(v.w, v.w, s2[mt][3]);
                 }
-                float* op = a.out + (int64_t)ooff[nt] + co;
+                float* op = a.out + (int64_t)ooff[nt] + ct.z + co;
                 if (flags & EPI_AFFINE) {
                     const float4 sc = *(const float4*)(a.scale + co), sh = *(const float4*)(a.shift + co);
                     v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
                 }
                 if (flags & EPI_RES) {
-                    const float4 r = *(const float4*)(a.res + (int64_t)ooff[nt] + co);
+                    const float4 r = *(const float4*)(a.res + (int64_t)ooff[nt] + ct.z + co);
                     v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
                 }
                 if (flags & EPI_RESMASK) {
-                    const float4 r = *(const float4*)(a.res + (int64_t)ooff[nt] + co);
-                    const float4 m = *(const float4*)(a.resmask + (int64_t)ooff[nt] + co);
+                    const float4 r = *(const float4*)(a.res + (int64_t)ooff[nt] + ct.z + co);
+                    const float4 m = *(const float4*)(a.resmask + (int64_t)ooff[nt] + ct.z + co);
                     v.x += m.x > 0.f ? r.x : 0.f; v.y += m.y > 0.f ? r.y : 0.f; v.z += m.z > 0.f ? r.z : 0.f; v.w += m.w > 0.f ? r.w : 0.f;
                 }
                 if (flags & EPI_ACCUM) {
@@ -870,6 +908,7 @@ __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
                 *(float4*)op = v;
             }
         }
+        }   // classes
         stamp();   // tile + 5: epilogue issued
     }
     if ((flags & EPI_STATS) && run_grp >= 0) flush_stats();
@@ -878,7 +917,17 @@ __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
 
 #define OCL_CONVT_TILINGS(X) X(1, 1) X(2, 1) X(3, 1) X(4, 1) X(5, 1) X(1, 2) X(2, 2) X(3, 2) X(4, 2) X(5, 2)
 typedef void (*conv_fn_t)(const ConvArgs);
-static conv_fn_t convt_fn(int MT, int NT, int PF, int res) {
+static conv_fn_t convt_fn(int MT, int NT, int PF, int res, int cls = 0) {
+    if (cls) {   // output classes: one pixel tile per wave (the class lattices are the small ones)
+#define OCL_CASE(M)                                                                                              \
+    if (MT == M && NT == 1) {                                                                                    \
+        if (PF == 4) return res ? conv_t_kernel<M, 1, 4, true, true> : conv_t_kernel<M, 1, 4, false, true>;      \
+        if (PF == 8) return res ? conv_t_kernel<M, 1, 8, true, true> : conv_t_kernel<M, 1, 8, false, true>;      \
+    }
+        OCL_CASE(1) OCL_CASE(2) OCL_CASE(3) OCL_CASE(4) OCL_CASE(5)
+#undef OCL_CASE
+        return nullptr;
+    }
 #define OCL_CASE(M, N)                                                                              \
     if (MT == M && NT == N) {                                                                       \
         if (PF == 4) return res ? conv_t_kernel<M, N, 4, true> : conv_t_kernel<M, N, 4, false>;     \
@@ -1013,13 +1062,14 @@ static size_t convt_layout(const ConvGeomDesc& g, ConvArgs& a, int MT, int NT) {
             a.KC = KC;
             a.CP = ((KC / 4) & 1) ? KC : KC + 4;     // 16-byte pixel slots, an odd number of them per pixel: b128 reads of 16 pixels spread over all banks
             a.Qc = g.ntaps * (KC / 4);
-            a.Qpad = (int)round_up(a.Qc, 4);
+            a.Qpad = 0;   // every class's groups are padded to whole rounds of 4
+            for (int c = 0; c < std::max(1, g.ncls); ++c) a.Qpad += (int)round_up((g.ncls > 1 ? g.cls_ntaps[c] : g.ntaps) * (KC / 4), 4);
             const size_t w_all = (size_t)a.Qpad * COPW * 16;
             a.wres = (KC == g.Cin && w_all <= kResidentBytes) ? 1 : 0;
             a.QS = a.wres ? a.Qpad : std::min(a.Qpad, ((256 * kWPF) / COPW) & ~3);
             a.nstage = cdiv(a.Qpad, a.QS);
             const size_t patch_b = std::max((size_t)a.imgs * a.PR * a.PC * a.CP * 4, (size_t)8 * COPW * 8);
-            bytes = (size_t)kMaxWgTiles * 32 + (size_t)2 * a.Qpad * 4 + (a.wres ? w_all : (size_t)2 * a.QS * COPW * 16) + patch_b;
+            bytes = (size_t)kMaxWgTiles * 32 + 64 + (size_t)2 * a.Qpad * 4 + (a.wres ? w_all : (size_t)2 * a.QS * COPW * 16) + patch_b;
             const bool units_ok = a.imgs * a.PR * a.PC * (KC / 4) <= 256 * kConvPatchPF;
             if (units_ok && bytes <= kLdsLimit - 2048 && (bytes <= 100 * 1024 || KC <= 20)) goto found;
         }
@@ -1056,12 +1106,19 @@ static int plan_conv_t(const ConvGeomDesc& g, ConvPlan* p) {
     while (MT > 1 && tiles64 * cdiv(nt16, MT) < 200) --MT;   // kbench sweep: 4x55 workgroups of 3 channel tiles beat 5x55 of 2 on layer 4
     if (nt16 > MT) MT = cdiv(nt16, cdiv(nt16, MT));
     int NT = tiles64 * cdiv(nt16, MT) >= 2048 ? 2 : 1;
+    if (g.ncls > 1) NT = 1;
     if (g.force_MT) MT = g.force_MT;
     if (g.force_NT) NT = g.force_NT;
     if (MT < 1 || MT > 5 || NT < 1 || NT > 2 || MT > nt16) return OCL_ERR_ARG;
     size_t lds = convt_layout(g, a, MT, NT);
     if (!lds && NT == 2 && !g.force_NT) { NT = 1; lds = convt_layout(g, a, MT, NT); }
     if (!lds) return OCL_ERR_ARG;
+    a.cls_pack = std::max(1, g.ncls);
+    a.cls_oyx = 0;
+    for (int c = 0; c < std::max(1, g.ncls); ++c) {
+        a.cls_pack |= (g.ncls > 1 ? g.cls_ntaps[c] : g.ntaps) << (4 + 4 * c);
+        if (g.ncls > 1) a.cls_oyx |= (g.cls_oy[c] << (2 * c)) | (g.cls_ox[c] << (2 * c + 1));
+    }
     p->kind = 1;
     p->W = 16; p->MT = MT; p->NT = NT;
     p->lds_bytes = lds;
@@ -1121,12 +1178,14 @@ int plan_conv(const ConvGeomDesc& g, ConvPlan* p) {
     if (want_kind == 1 && !g.force_W) {
         if (plan_conv_t(g, p) == OCL_OK) return OCL_OK;
         if (g.force_kind == 2) { set_error("plan_conv: no conv_t tiling for MT=%d NT=%d", g.force_MT, g.force_NT); return OCL_ERR_ARG; }
+        if (g.ncls > 1) { set_error("plan_conv: no conv_t tiling for a %d-class geometry", g.ncls); return OCL_ERR_ARG; }
         // fall through to conv_gemm_kernel with a clean plan
         ConvArgs keep = a;
         memset(p, 0, sizeof(*p));
         a = keep;
         a.n_splits = a.CoutP = a.group_size = a.imgs = a.ppi = a.tiles_per_img = a.PC = a.PR = a.KC = a.CP = 0;
     }
+    if (g.ncls > 1) { set_error("plan_conv: output classes need conv_t_kernel"); return OCL_ERR_ARG; }
     // ---- tile choice ---------------------------------------------------------------------------------------------
     // Rules distilled from the kbench sweeps on MI355X (profiles/r1_kbench_conv_sweep*.txt):
     //  * enough pixels for 128-row tiles -> 32x32x2 MFMA (W = 32), all output channels of a 32/64/96-wide block per
@@ -1222,7 +1281,7 @@ void geom_fwd(const ConvShape& c, int N, int groups, ConvGeomDesc* g) {
     }
 }
 
-void geom_dgrad(const ConvShape& c, int N, std::vector<ConvGeomDesc>* out) {
+void geom_dgrad(const ConvShape& c, int N, std::vector<ConvGeomDesc>* out, bool merge_classes) {
     out->clear();
     ConvGeomDesc g;
     memset(&g, 0, sizeof(g));
@@ -1247,6 +1306,32 @@ void geom_dgrad(const ConvShape& c, int N, std::vector<ConvGeomDesc>* out) {
         g.LH = (c.Hin + 1) / 2; g.LW = (c.Win + 1) / 2;
         g.ntaps = 1;
         g.tdy[0] = 0; g.tdx[0] = 0; g.tw[0] = 0;
+        out->push_back(g);
+    } else if (merge_classes && c.Hin % 2 == 0 && c.Win % 2 == 0) {
+        // the four parity classes as output classes of one launch: they read the same dy window (rows / columns +0, +1), use
+        // disjoint taps (1, 2, 2 and 4 of the 9) and write the four interleaved lattices of dx
+        g.os = 2; g.oy0 = 0; g.ox0 = 0;
+        g.LH = c.Hin / 2; g.LW = c.Win / 2;
+        g.ncls = 4;
+        int nt = 0;
+        for (int py = 0; py < 2; ++py)
+            for (int px = 0; px < 2; ++px) {
+                const int cls = py * 2 + px;
+                g.cls_oy[cls] = py; g.cls_ox[cls] = px;
+                const int first = nt;
+                for (int ky = 0; ky < 3; ++ky) {
+                    if (((py + 1 - ky) & 1) != 0) continue;
+                    for (int kx = 0; kx < 3; ++kx) {
+                        if (((px + 1 - kx) & 1) != 0) continue;
+                        g.tdy[nt] = (py + 1 - ky) / 2;
+                        g.tdx[nt] = (px + 1 - kx) / 2;
+                        g.tw[nt] = ky * 3 + kx;
+                        ++nt;
+                    }
+                }
+                g.cls_ntaps[cls] = nt - first;
+            }
+        g.ntaps = nt;
         out->push_back(g);
     } else {  // 3x3 stride 2 pad 1: four dense parity classes of the dx lattice
         for (int py = 0; py < 2; ++py)
@@ -1274,7 +1359,7 @@ void geom_dgrad(const ConvShape& c, int N, std::vector<ConvGeomDesc>* out) {
 
 int launch_conv(const ConvPlan& p, hipStream_t s) {
     const int pfu = conv_pf_for(p.a.imgs * p.a.PR * p.a.PC * (p.a.KC / 4));
-    conv_fn_t fn = p.kind == 1 ? convt_fn(p.MT, p.NT, convt_pf_for(p.a.imgs * p.a.PR * p.a.PC * (p.a.KC / 4)), p.a.wres)
+    conv_fn_t fn = p.kind == 1 ? convt_fn(p.MT, p.NT, convt_pf_for(p.a.imgs * p.a.PR * p.a.PC * (p.a.KC / 4)), p.a.wres, (p.a.cls_pack & 15) > 1)
                                : p.a.wreg ? conv_fn_wreg(pfu) : conv_fn(p.W, p.MT, p.NT, pfu);
     if (!fn) {
         set_error("launch_conv: no kernel for W=%d MT=%d NT=%d", p.W, p.MT, p.NT);
@@ -1494,12 +1579,11 @@ static int wgrad_pf_for(int units) { return units <= 1024 ? 4 : 8; }
 // sums the split-K partials into the OIHW gradient: grad[co][ci][t] (+)= sum_s partial[s][(chunk,t,cc)][co].
 // 32 consecutive outputs (co fastest: coalesced partial reads) x 8 split lanes per block; the 8 lane sums are combined
 // through LDS in a fixed order, so the result does not depend on scheduling.
-__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ partial, int S, int Mrows_total, int CoutP,
-                                                           int mrows_chunk, int KC, int ntaps, int CinReal, int Cout,
-                                                           float* __restrict__ grad, int accumulate) {
-    __shared__ float red[8][33];
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ partial, int S, int Mrows_total, int CoutP, int mrows_chunk,
+                                                  int KC, int ntaps, int CinReal, int Cout, float* __restrict__ grad, int accumulate,
+                                                  int block, float (*red)[33]) {
     const int o = threadIdx.x & 31, sl = threadIdx.x >> 5;
-    const int idx = blockIdx.x * 32 + o;  // (t, ci, co) with co fastest
+    const int idx = block * 32 + o;  // (t, ci, co) with co fastest
     const int total = ntaps * CinReal * Cout;
     const bool valid = idx < total;
     const int co = idx % Cout;
@@ -1528,6 +1612,25 @@ __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restri
         if (accumulate) v += *gp;
         *gp = v;
     }
+}
+
+__global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ partial, int S, int Mrows_total, int CoutP,
+                                                           int mrows_chunk, int KC, int ntaps, int CinReal, int Cout,
+                                                           float* __restrict__ grad, int accumulate) {
+    __shared__ float red[8][33];
+    wgrad_reduce_body(partial, S, Mrows_total, CoutP, mrows_chunk, KC, ntaps, CinReal, Cout, grad, accumulate, blockIdx.x, red);
+}
+
+// the reductions of ALL layers of a backward pass in one launch (replay-sized batches run the whole backward on one stream and are
+// bound by the number of dependent launches: 21 reductions -> 1); every layer keeps its own slab region until then
+__global__ void __launch_bounds__(256) wgrad_reduce_multi_kernel(const WgradReduceMulti m) {
+    __shared__ float red[8][33];
+    int l = 0;
+#pragma unroll 1
+    while (l + 1 < m.n && (int)blockIdx.x >= m.L[l + 1].block0) ++l;
+    const WgradReduceLayer& d = m.L[l];
+    wgrad_reduce_body(m.partial + d.partial_off, d.S, d.Mrows_total, d.CoutP, d.mrows_chunk, d.KC, d.ntaps, d.CinReal, d.Cout,
+                      m.grads + d.grad_off, m.accumulate, (int)blockIdx.x - d.block0, red);
 }
 
 // LDS pixel stride of the wgrad input patch.  A reads (ds_read_b32, 32 banks, lanes 0-31 = 2 pixels x 16 channels)
@@ -1655,12 +1758,42 @@ int launch_wgrad_reduce(const WgradPlan& p, float* grad_oihw, int accumulate, hi
     return OCL_OK;
 }
 
+void wgrad_reduce_layer(const WgradPlan& p, int64_t partial_off, int64_t grad_off, WgradReduceLayer* d) {
+    const WgradArgs& a = p.a;
+    d->partial_off = partial_off;
+    d->grad_off = grad_off;
+    d->S = a.S; d->Mrows_total = a.Mrows_total; d->CoutP = a.CoutP;
+    d->mrows_chunk = a.mblocks_per_chunk * 64 * p.MTW;
+    d->KC = a.KC; d->ntaps = a.ntaps;
+    d->CinReal = a.Cin == 4 ? 3 : a.Cin;
+    d->Cout = a.Cout;
+    d->block0 = 0;
+}
+
+int launch_wgrad_reduce_multi(WgradReduceMulti m, hipStream_t s) {
+    OCL_REQUIRE(m.n >= 1 && m.n <= kMaxReduceLayers, "wgrad_reduce_multi: %d layers", m.n);
+    int blocks = 0;
+    for (int i = 0; i < m.n; ++i) {
+        m.L[i].block0 = blocks;
+        blocks += cdiv(m.L[i].ntaps * m.L[i].CinReal * m.L[i].Cout, 32);
+    }
+    ProfScope ps(PROF_WGRAD, s);
+    hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(blocks), dim3(256), 0, s, m);
+    OCL_LAUNCH_CHECK();
+    return OCL_OK;
+}
+
 // =====================================================================================================
 // weight packing (all conv layers in one launch)
 // =====================================================================================================
 __global__ void __launch_bounds__(256) pack_weights_kernel(const float* __restrict__ params, float* __restrict__ arena,
-                                                           const PackDesc* __restrict__ descs) {
-    const PackDesc d = descs[blockIdx.y];
+                                                           const PackDesc* __restrict__ descs, int mask) {
+    PackDesc d = descs[blockIdx.y];
+    // the scattered stores are the cost of this kernel: a pass writes only the packs it reads (PACK_* bits)
+    if (!(mask & PACK_F)) d.f_off = -1;
+    if (!(mask & PACK_D)) d.d_off = -1;
+    if (!(mask & PACK_TF)) d.tf_off = -1;
+    if (!(mask & PACK_TD)) d.td_off = -1;
     const int total = d.Cout * d.Cin * d.ntaps;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
         const int co = e / (d.Cin * d.ntaps);
@@ -1674,10 +1807,11 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const float* __restri
     }
 }
 
-int launch_pack_weights(const float* params, float* arena, const PackDesc* descs_dev, int n_layers, int max_elems, hipStream_t s) {
+int launch_pack_weights(const float* params, float* arena, const PackDesc* descs_dev, int n_layers, int max_elems, hipStream_t s,
+                        int mask) {
     ProfScope ps(PROF_BN, s);
     hipLaunchKernelGGL(pack_weights_kernel, dim3(std::min(64, cdiv(max_elems, 256)), n_layers), dim3(256), 0, s, params, arena,
-                       descs_dev);
+                       descs_dev, mask);
     OCL_LAUNCH_CHECK();
     return OCL_OK;
 }
@@ -2316,6 +2450,10 @@ int conv_kernels_init() {
             for (int pf = 4; pf <= 8; pf += 4)
                 for (int res = 0; res < 2; ++res)
                     OCL_HIP(hipFuncSetAttribute((const void*)convt_fn(m, n, pf, res), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+    for (int m = 1; m <= 5; ++m)
+        for (int pf = 4; pf <= 8; pf += 4)
+            for (int res = 0; res < 2; ++res)
+                OCL_HIP(hipFuncSetAttribute((const void*)convt_fn(m, 1, pf, res, 1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     done = true;
     return OCL_OK;
 }

@@ -1,0 +1,179 @@
+/* Host-side helper of the ASER plugins: the class-balanced draw of ClassBalancedRandomSampling.sample
+ * (reference: utils/buffer/buffer_utils.py:86-118) as one C call.
+ *
+ * What the reference's loop observably depends on, and how it is kept:
+ *   - dict order of class_index_cache            -> PyDict_Next (insertion order)
+ *   - `slots - excluded` building a NEW set whose iteration order decides which slot a permutation index means
+ *                                                -> the same CPython operation (PyNumber_Subtract) and CPython's own set iterator
+ *   - one torch.randperm(len(eligible)) per non-empty class on torch's global CPU generator
+ *                                                -> the generator's algorithm restated here (mt19937 word stream, randperm's swap
+ *                                                   loop) on the state bytes of torch.get_rng_state(); the caller writes the
+ *                                                   advanced state back with torch.set_rng_state().  `randperm_check` lets the
+ *                                                   Python side compare this restatement with the installed torch before it is
+ *                                                   trusted (plugins/buffer_utils.py falls back to the Python loop otherwise).
+ * Only bookkeeping: no image data passes through here. */
+#define PY_SSIZE_T_CLEAN
+#include <Python.h>
+#include <stdint.h>
+#include <string.h>
+
+/* layout of at::CPUGeneratorImpl's serialized state (ATen/CPUGeneratorImpl.cpp, CPUGeneratorImplStateLegacy + 2 trailing fields) */
+#define MT_N 624
+#define MT_M 397
+#define TORCH_STATE_BYTES 5056
+typedef struct {
+    uint64_t seed;
+    int32_t left;
+    int32_t seeded;
+    uint64_t next;
+    uint64_t state[MT_N];
+} MtState;
+
+static void mt_reload(MtState* s) {
+    uint64_t* st = s->state;
+    int k;
+#define TWIST(u, v) (((((uint32_t)(u)) & 0x80000000u) | (((uint32_t)(v)) & 0x7fffffffu)) >> 1 ^ ((((uint32_t)(v)) & 1u) ? 0x9908b0dfu : 0u))
+    for (k = 0; k < MT_N - MT_M; ++k) st[k] = (uint32_t)st[k + MT_M] ^ TWIST(st[k], st[k + 1]);
+    for (; k < MT_N - 1; ++k) st[k] = (uint32_t)st[k + MT_M - MT_N] ^ TWIST(st[k], st[k + 1]);
+    st[MT_N - 1] = (uint32_t)st[MT_M - 1] ^ TWIST(st[MT_N - 1], st[0]);
+#undef TWIST
+    s->left = MT_N;
+    s->next = 0;
+}
+
+static inline uint32_t mt_next(MtState* s) {
+    if (--s->left == 0) mt_reload(s);
+    uint32_t y = (uint32_t)s->state[s->next++];
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+/* torch.randperm(n) on the CPU generator (aten/src/ATen/native/TensorFactories.cpp, randperm_cpu, n < 2^32 / 20) */
+static void randperm(MtState* s, int64_t n, int64_t* r) {
+    for (int64_t i = 0; i < n; ++i) r[i] = i;
+    for (int64_t i = 0; i < n - 1; ++i) {
+        const int64_t z = (int64_t)(mt_next(s) % (uint32_t)(n - i));   /* n < 2^32 / 20: 32-bit arithmetic is exact */
+        const int64_t t = r[i];
+        r[i] = r[z + i];
+        r[z + i] = t;
+    }
+}
+
+static int state_from_buffer(Py_buffer* b, MtState** out) {
+    if (b->len != TORCH_STATE_BYTES || b->readonly) {
+        PyErr_SetString(PyExc_ValueError, "rng state must be a writable buffer of 5056 bytes (torch.get_rng_state())");
+        return -1;
+    }
+    MtState* s = (MtState*)b->buf;
+    if (s->left < 1 || s->left > MT_N || s->next > MT_N) {
+        PyErr_SetString(PyExc_ValueError, "rng state does not look like a CPU mt19937 state");
+        return -1;
+    }
+    *out = s;
+    return 0;
+}
+
+/* randperm_check(state, n) -> list: the permutation this file would draw (advances `state` in place) */
+static PyObject* py_randperm_check(PyObject* self, PyObject* args) {
+    Py_buffer sb;
+    long long n;
+    if (!PyArg_ParseTuple(args, "w*L", &sb, &n)) return NULL;
+    MtState* s;
+    if (state_from_buffer(&sb, &s) < 0 || n < 0 || n > (1 << 24)) {
+        if (!PyErr_Occurred()) PyErr_SetString(PyExc_ValueError, "bad n");
+        PyBuffer_Release(&sb);
+        return NULL;
+    }
+    int64_t* r = (int64_t*)PyMem_Malloc(sizeof(int64_t) * (size_t)(n ? n : 1));
+    if (!r) { PyBuffer_Release(&sb); return PyErr_NoMemory(); }
+    randperm(s, n, r);
+    PyObject* out = PyList_New((Py_ssize_t)n);
+    for (long long i = 0; out && i < n; ++i) PyList_SET_ITEM(out, (Py_ssize_t)i, PyLong_FromLongLong(r[i]));
+    PyMem_Free(r);
+    PyBuffer_Release(&sb);
+    return out;
+}
+
+/* cbrs_sample(class_index_cache: dict[label -> set[int]], excluded: set | None, n_smp_cls: int, state, out) -> number of picks
+ * out: writable buffer of int64; raises if it is too small. */
+static PyObject* py_cbrs_sample(PyObject* self, PyObject* args) {
+    PyObject *cache, *excluded;
+    long long n_smp;
+    Py_buffer sb, ob;
+    if (!PyArg_ParseTuple(args, "O!OLw*w*", &PyDict_Type, &cache, &excluded, &n_smp, &sb, &ob)) return NULL;
+    MtState* s;
+    PyObject* result = NULL;
+    PyObject* empty = NULL;
+    int64_t *members = NULL, *perm = NULL;
+    Py_ssize_t cap = 0;
+    if (state_from_buffer(&sb, &s) < 0) goto done;
+    if (excluded == Py_None) {
+        empty = PySet_New(NULL);
+        if (!empty) goto done;
+        excluded = empty;
+    } else if (!PyAnySet_Check(excluded)) {
+        PyErr_SetString(PyExc_TypeError, "excluded must be a set or None");
+        goto done;
+    }
+    if (n_smp < 0) n_smp = 0;
+    {
+        int64_t* out = (int64_t*)ob.buf;
+        const Py_ssize_t out_cap = ob.len / (Py_ssize_t)sizeof(int64_t);
+        Py_ssize_t n_out = 0, pos = 0;
+        PyObject *key, *slots;
+        while (PyDict_Next(cache, &pos, &key, &slots)) {
+            if (!PyAnySet_Check(slots)) {
+                PyErr_SetString(PyExc_TypeError, "class_index_cache values must be sets");
+                goto done;
+            }
+            if (PySet_GET_SIZE(slots) == 0) continue;
+            PyObject* eligible = PyNumber_Subtract(slots, excluded);   /* a new set, exactly as `slots - excluded` */
+            if (!eligible) goto done;
+            const Py_ssize_t n = PySet_GET_SIZE(eligible);
+            if (n > cap) {
+                cap = n * 2 + 64;
+                int64_t* m2 = (int64_t*)PyMem_Realloc(members, sizeof(int64_t) * (size_t)cap);
+                int64_t* p2 = m2 ? (int64_t*)PyMem_Realloc(perm, sizeof(int64_t) * (size_t)cap) : NULL;
+                if (m2) members = m2;
+                if (p2) perm = p2;
+                if (!m2 || !p2) { Py_DECREF(eligible); PyErr_NoMemory(); goto done; }
+            }
+            randperm(s, (int64_t)n, perm);                              /* drawn even when nothing is eligible (n == 0) */
+            Py_ssize_t spos = 0, k = 0;
+            PyObject* item;
+            Py_hash_t h;
+            while (_PySet_NextEntry(eligible, &spos, &item, &h)) {      /* CPython's own iteration order */
+                const long long v = PyLong_AsLongLong(item);
+                if (v == -1 && PyErr_Occurred()) { Py_DECREF(eligible); goto done; }
+                members[k++] = (int64_t)v;
+            }
+            Py_DECREF(eligible);
+            const Py_ssize_t take = n < (Py_ssize_t)n_smp ? n : (Py_ssize_t)n_smp;
+            if (n_out + take > out_cap) {
+                PyErr_SetString(PyExc_ValueError, "output buffer too small");
+                goto done;
+            }
+            for (Py_ssize_t j = 0; j < take; ++j) out[n_out++] = members[perm[j]];
+        }
+        result = PyLong_FromSsize_t(n_out);
+    }
+done:
+    PyMem_Free(members);
+    PyMem_Free(perm);
+    Py_XDECREF(empty);
+    PyBuffer_Release(&sb);
+    PyBuffer_Release(&ob);
+    return result;
+}
+
+static PyMethodDef methods[] = {
+    {"cbrs_sample", py_cbrs_sample, METH_VARARGS, "class-balanced draw (see file header)"},
+    {"randperm_check", py_randperm_check, METH_VARARGS, "the permutation the restated generator draws"},
+    {NULL, NULL, 0, NULL}};
+
+static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_hostc", "host-side helpers (ASER class-balanced sampling)", -1, methods};
+
+PyMODINIT_FUNC PyInit__hostc(void) { return PyModule_Create(&moddef); }

@@ -518,6 +518,40 @@ int main(int argc, char** argv) {
                     const double f = 2.0 * (double)N * q.LH * q.LW * q.Cout * q.Cin * q.ntaps;
                     bench_geom(l.name.c_str(), kind, q, bufA, w, bufB, bufC, stats, 0, f, (size_t)N * c.Hin * c.Win * c.Cin, sweep);
                 }
+                std::vector<ConvGeomDesc> dm;
+                geom_dgrad(c, N, &dm, true);
+                if (dg.size() == 4 && dm.size() == 1 && dm[0].ncls > 1) {   // the four parity classes as ONE launch vs four
+                    const size_t out_elems = (size_t)N * c.Hin * c.Win * c.Cin;
+                    float* wT = make_packT(w, dm[0].Cin, dm[0].WP);
+                    std::vector<ConvPlan> p4(4);
+                    for (int i = 0; i < 4; ++i) { dg[i].WPT = dg[i].WP; OK(plan_conv(dg[i], &p4[i])); }
+                    for (int fmt = 0; fmt <= (sweep ? 5 : 0); ++fmt) {
+                    ConvGeomDesc gm = dm[0];
+                    gm.WPT = gm.WP;
+                    gm.force_MT = fmt;
+                    ConvPlan pm;
+                    if (plan_conv(gm, &pm) == OCL_OK) {
+                        auto run = [&](ConvPlan p, float* o) {
+                            p.a.in = bufA; p.a.w = w; p.a.wT = wT; p.a.out = o; p.a.flags = 0; p.a.stats = stats; p.a.stat_rep_stride = 8 * 2 * 1024;
+                            OK(launch_conv(p, 0));
+                        };
+                        CK(hipMemset(bufC, 0, out_elems * 4));
+                        CK(hipMemset(bufB, 0, out_elems * 4));
+                        for (auto& p : p4) run(p, bufC);
+                        run(pm, bufB);
+                        const double d = max_diff(bufB, bufC, out_elems);
+                        const double t4 = time_us([&] { for (auto& p : p4) run(p, bufC); });
+                        const double tm = time_us([&] { run(pm, bufB); });
+                        const double f = 2.0 * (double)N * c.Ho * c.Wo * c.Cout * c.Cin * 9;
+                        printf("%-20s dgradM%s 4 launches %7.1f us; merged MT=%d NT=%d grid=%5dx%d lds=%6zu KC=%3d Qpad=%3d QS=%3d res=%d  %7.1f us %6.1f TF/s  maxdiff=%.2e%s\n",
+                               l.name.c_str(), fmt ? " " : "*", t4, pm.MT, pm.NT, pm.grid_x, pm.grid_y, pm.lds_bytes, pm.a.KC, pm.a.Qpad, pm.a.QS, pm.a.wres, tm,
+                               f / tm * 1e-6, d, d > 1e-3 ? "  <-- MISMATCH" : "");
+                    } else if (!fmt) {
+                        printf("%-20s dgradM  no merged plan: %s\n", l.name.c_str(), ocl_last_error());
+                    }
+                    }
+                    CK(hipFree(wT));
+                }
             }
             (void)tot_auto;
         }

@@ -48,6 +48,8 @@ struct PlanSet {
     std::vector<ConvPlan> fwd;                  // per conv
     std::vector<std::vector<ConvPlan>> dgrad;   // per conv: 0 (stem), 1 or 4 launches
     std::vector<WgradPlan> wgrad;
+    std::vector<int64_t> partial_off;           // per conv: its own slab region (batched reduction), floats
+    bool batched_reduce = false;                // every layer's slabs fit the workspace side by side
 };
 
 }  // namespace
@@ -89,6 +91,8 @@ struct ocl_net {
     bool bound = false;
     bool descs_uploaded = false;
     const float* pack_src = nullptr;   // parameter array the weight-pack arena was last written from (by a forward)
+    int pack_have = 0;                 // PACK_* bits of the packs that hold `pack_src`'s weights
+    int pack_need_fwd = 0, pack_need_bwd = 0;   // packs the plans made so far read (the round-1 kernel's layouts only where it is planned)
 
     int dbg_stop = -1;            // debug: return from backward right after stage (block*10 + step)
     float* dbg_role[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -300,7 +304,8 @@ static int build_layout(ocl_net* n) {
         pmax = std::max<int64_t>(pmax, (int64_t)wp.partial_floats);
     }
     // plan_wgrad caps the split-K slabs at 12 MB for every batch size (the split differs per batch): size for the cap
-    n->partial_floats = std::max<int64_t>(pmax, (int64_t)(12ll << 20) / 4 + (1ll << 20)) + 1024;
+    // (and for the side-by-side slab regions of the batched reduction of replay-sized batches: 64 MB)
+    n->partial_floats = std::max<int64_t>(pmax, (int64_t)(64ll << 20) / 4) + 1024;
     n->off_partial = takeb(n->partial_floats * 4);
     int64_t so = 0;
     for (auto& b : n->bns) {
@@ -352,14 +357,22 @@ static int get_plans(ocl_net* n, int N, int groups, PlanSet** out) {
         geom_fwd(c, N, groups, &g);
         int rc = plan_conv(g, &ps.fwd[i]);
         if (rc != OCL_OK) return rc;
+        n->pack_need_fwd |= ps.fwd[i].kind == 1 ? PACK_TF : PACK_F;
         if (c.Cin != 3) {
+            // stride-2 3x3: the four parity classes as one launch where conv_t_kernel can take them (OCL_DGRAD_MERGE=0: four launches)
+            static const bool merge = [] { const char* e = getenv("OCL_DGRAD_MERGE"); return !(e && e[0] == '0'); }();
             std::vector<ConvGeomDesc> dg;
-            geom_dgrad(c, N, &dg);
+            geom_dgrad(c, N, &dg, merge);
+            if (dg.size() == 1 && dg[0].ncls > 1) {
+                ConvPlan p;
+                if (plan_conv(dg[0], &p) != OCL_OK) geom_dgrad(c, N, &dg, false);
+            }
             for (auto& q : dg) {
                 ConvPlan p;
                 rc = plan_conv(q, &p);
                 if (rc != OCL_OK) return rc;
                 ps.dgrad[i].push_back(p);
+                n->pack_need_bwd |= p.kind == 1 ? PACK_TD : PACK_D;
             }
         }
         rc = plan_wgrad(N, c.Hin, c.Win, c.CinT, c.Ho, c.Wo, c.Cout, c.k, c.stride, &ps.wgrad[i]);
@@ -369,6 +382,15 @@ static int get_plans(ocl_net* n, int N, int groups, PlanSet** out) {
                       (long long)n->partial_floats);
             return OCL_ERR_STATE;
         }
+    }
+    {
+        int64_t off = 0;
+        ps.partial_off.resize(n->convs.size());
+        for (size_t i = 0; i < n->convs.size(); ++i) {
+            ps.partial_off[i] = off;
+            off += (int64_t)((ps.wgrad[i].partial_floats + 63) / 64) * 64;
+        }
+        ps.batched_reduce = off <= n->partial_floats && (int)n->convs.size() <= kMaxReduceLayers;
     }
     auto res = n->plans.emplace(key, std::move(ps));
     *out = &res.first->second;
@@ -679,8 +701,12 @@ int ocl_net_forward(ocl_net* n, const float* x, int N, int groups, uint32_t flag
     float* pack = (float*)(n->ws + n->off_pack);
     int max_elems = 0;
     for (auto& c : n->convs) max_elems = std::max(max_elems, c.Cout * c.Cin * c.k * c.k);
-    rc = launch_pack_weights(P, pack, pack_descs(n), (int)n->convs.size(), max_elems, s);   // every forward: the caller
-    if (rc != OCL_OK) return rc;                                                               // may have stepped the weights
+    // every forward packs (the caller may have stepped the weights), but only the layouts the pass reads: the forward packs, and the
+    // data-gradient packs when a backward will follow this tape
+    const int pack_mask = n->pack_need_fwd | ((flags & OCL_FWD_SAVE_TAPE) ? n->pack_need_bwd : 0);
+    rc = launch_pack_weights(P, pack, pack_descs(n), (int)n->convs.size(), max_elems, s, pack_mask);
+    if (rc != OCL_OK) return rc;
+    n->pack_have = n->pack_src == P ? (n->pack_have | pack_mask) : pack_mask;   // (older packs of the same array stay as they were)
     n->pack_src = P;
 
     float* S = n->slotf(slot);
@@ -757,6 +783,7 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
     float* partial = n->partialbuf();
     double* bsums = n->bsumsbuf();
     int rc = OCL_OK;
+    const bool two_streams_arg = side != nullptr;
     OCL_HIP(hipMemsetAsync(bsums, 0, n->bsums_doubles * 8, s));
     auto T = [&](int t) { return P + n->tensors[t].off; };
     auto GT = [&](int t) { return Gr + n->tensors[t].off; };
@@ -829,13 +856,23 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
         a.frozen = frozen ? 1 : 0;
         return launch_bn_bwd(a, s);
     };
+    // one stream (replay-sized batches: bound by the number of dependent launches): every layer writes its slabs into its own region
+    // and ONE launch at the end of the backward reduces them all
+    static const bool env_noreduce = [] { const char* e = getenv("OCL_BATCHED_REDUCE"); return e && e[0] == '0'; }();
+    const bool batched = !two_streams_arg && Nc < kTwoStreamMinBatch && ps->batched_reduce && !env_noreduce && n->dbg_stop < 0;
+    WgradReduceMulti rm;
+    rm.partial = partial; rm.grads = Gr; rm.accumulate = accumulate; rm.n = 0;
     auto wgrad = [&](int conv_i, const float* xin, const float* dy) -> int {   // on the weight-gradient stream
         WgradPlan wp = ps->wgrad[conv_i];
         wp.a.x = xin;
         wp.a.dy = dy;
-        wp.a.partial = partial;
+        wp.a.partial = batched ? partial + ps->partial_off[conv_i] : partial;
         int r = launch_wgrad(wp, sw);
         if (r) return r;
+        if (batched) {
+            wgrad_reduce_layer(wp, ps->partial_off[conv_i], n->tensors[n->convs[conv_i].w_t].off, &rm.L[rm.n++]);
+            return OCL_OK;
+        }
         return launch_wgrad_reduce(wp, GT(n->convs[conv_i].w_t), accumulate, sw);
     };
     auto dgrad = [&](int conv_i, const float* dy, float* dx, const float* res, const float* resmask, int extra_flags) -> int {
@@ -910,6 +947,7 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
         sw = s;
     }
     if ((rc = wgrad(0, S + n->x4_off + (int64_t)img0 * n->d.in_h * n->d.in_w * 4, gS))) return rc;
+    if (batched && rm.n > 0 && (rc = launch_wgrad_reduce_multi(rm, s))) return rc;
     return OCL_OK;
 }
 
@@ -932,11 +970,14 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
     const float* P = n->params;
     float* Gr = n->grads;
     float* pack = (float*)(n->ws + n->off_pack);
-    if (n->pack_src != P) {   // the arena was rewritten by a forward of MIR's virtual model since the taped forward
+    if (n->pack_src != P || (n->pack_have & n->pack_need_bwd) != n->pack_need_bwd) {
+        // the arena was rewritten by a forward of MIR's virtual model since the taped forward (or plans made since need another layout)
         int max_elems = 0;
         for (auto& c : n->convs) max_elems = std::max(max_elems, c.Cout * c.Cin * c.k * c.k);
-        if ((rc = launch_pack_weights(P, pack, pack_descs(n), (int)n->convs.size(), max_elems, s))) return rc;
+        const int m = n->pack_need_fwd | n->pack_need_bwd;
+        if ((rc = launch_pack_weights(P, pack, pack_descs(n), (int)n->convs.size(), max_elems, s, m))) return rc;
         n->pack_src = P;
+        n->pack_have = m;
     }
     auto T = [&](int t) { return P + n->tensors[t].off; };
     auto GT = [&](int t) { return Gr + n->tensors[t].off; };

@@ -84,6 +84,51 @@ void prof_end(int cls, hipStream_t s) {
     g_pairs[cls].push_back(p);
 }
 
+// ---- small host -> device uploads ---------------------------------------------------------------------
+// Index vectors and parameter rows (<= 64 KB) go through a ring of pinned staging slots: memcpy into the slot, asynchronous copy
+// on the caller's stream, an event behind it; a slot is reused only after its event has completed.  One ring per device.
+static constexpr int kStageSlots = 128;
+static constexpr size_t kStageBytes = 64 * 1024;
+struct StageRing {
+    char* base = nullptr;
+    hipEvent_t ev[kStageSlots];
+    bool used[kStageSlots];
+    int next = 0;
+};
+static StageRing g_rings[16];
+static std::mutex g_stage_mu;
+
+int upload_small(const void* host, size_t nbytes, void* dev, hipStream_t s) {
+    if (nbytes == 0) return OCL_OK;
+    if (nbytes > kStageBytes) {   // large payloads: plain copy (blocks the host until staged)
+        OCL_HIP(hipMemcpyAsync(dev, host, nbytes, hipMemcpyHostToDevice, s));
+        return OCL_OK;
+    }
+    int d = 0;
+    OCL_HIP(hipGetDevice(&d));
+    OCL_REQUIRE(d >= 0 && d < 16, "ocl_upload: device index %d not supported", d);
+    std::lock_guard<std::mutex> lk(g_stage_mu);
+    StageRing& r = g_rings[d];
+    if (!r.base) {
+        void* h = nullptr;
+        OCL_HIP(hipHostMalloc(&h, kStageSlots * kStageBytes, hipHostMallocDefault));
+        r.base = (char*)h;
+        for (int i = 0; i < kStageSlots; ++i) {
+            OCL_HIP(hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming));
+            r.used[i] = false;
+        }
+    }
+    const int k = r.next;
+    r.next = (k + 1) % kStageSlots;
+    if (r.used[k]) OCL_HIP(hipEventSynchronize(r.ev[k]));
+    char* slot = r.base + (size_t)k * kStageBytes;
+    memcpy(slot, host, nbytes);
+    OCL_HIP(hipMemcpyAsync(dev, slot, nbytes, hipMemcpyHostToDevice, s));
+    OCL_HIP(hipEventRecord(r.ev[k], s));
+    r.used[k] = true;
+    return OCL_OK;
+}
+
 }  // namespace ocl
 
 using namespace ocl;
@@ -107,6 +152,11 @@ int ocl_init(int device) {
         return OCL_ERR_UNSUPPORTED;
     }
     return OCL_OK;
+}
+
+int ocl_upload(const void* host, int64_t nbytes, void* dev, void* stream) {
+    OCL_REQUIRE(nbytes >= 0 && (nbytes == 0 || (host && dev)), "ocl_upload: null pointer");
+    return upload_small(host, (size_t)nbytes, dev, (hipStream_t)stream);
 }
 
 int ocl_prof_enable(int on) {

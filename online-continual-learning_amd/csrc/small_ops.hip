@@ -684,6 +684,55 @@ __device__ __forceinline__ void hsv2rgb(float h, float s, float v, float& r, flo
     }
 }
 
+// Per-image augmentation parameters from raw uniform draws (the arithmetic of ScrAugment.sample_params, agents/scr.py, one thread
+// per image): 10 crop attempts of (area, log-ratio), first fit wins, centre-crop fallback; position, flip, jitter factors, order, gray.
+struct AugCfg {
+    float s0, ds, lr0, dlr;            // scale lower bound / width, log-ratio lower bound / width
+    float b, c, s, hue, p_jit, p_gray;
+    float fb_w, fb_h;                  // fallback crop (whole image with the aspect ratio clamped)
+    float j0[4], j1[4];                // jitter factor = j0 + j1 * u  (1-b, 2b; 1-c, 2c; 1-s, 2s; -hue, 2 hue)
+};
+__global__ void __launch_bounds__(64) aug_params_kernel(const float* __restrict__ u, int n, int h, int w, AugCfg cfg,
+                                                        float* __restrict__ params) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* ui = u + (int64_t)i * OCL_AUG_NUNIFORM;
+    const float H = (float)h, W = (float)w;
+    float cw = 0.f, ch = 0.f;
+    bool found = false;
+    for (int t = 0; t < 10; ++t) {
+        const float area = __fmul_rn(__fmul_rn(__fadd_rn(cfg.s0, __fmul_rn(cfg.ds, ui[t])), H), W);
+        const float r = expf(__fadd_rn(cfg.lr0, __fmul_rn(cfg.dlr, ui[10 + t])));
+        const float cwt = rintf(sqrtf(__fmul_rn(area, r)));
+        const float cht = rintf(sqrtf(area / r));
+        const bool fit = cwt > 0.f && cwt <= W && cht > 0.f && cht <= H;
+        if (fit && !found) {
+            found = true;
+            cw = cwt;
+            ch = cht;
+        }
+    }
+    const float* e = ui + 20;
+    float y0, x0;
+    if (found) {
+        y0 = fminf(floorf(__fmul_rn(e[0], H - ch + 1.f)), H - 1.f);
+        x0 = fminf(floorf(__fmul_rn(e[1], W - cw + 1.f)), W - 1.f);
+    } else {
+        cw = cfg.fb_w;
+        ch = cfg.fb_h;
+        y0 = floorf((H - ch) / 2.f);
+        x0 = floorf((W - cw) / 2.f);
+    }
+    float* p = params + (int64_t)i * OCL_AUG_NPARAM;
+    p[0] = y0; p[1] = x0; p[2] = ch; p[3] = cw;
+    p[4] = e[2] < 0.5f ? 1.f : 0.f;
+    p[5] = e[3] < cfg.p_jit ? 1.f : 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) p[6 + k] = __fadd_rn(cfg.j0[k], __fmul_rn(cfg.j1[k], e[4 + k]));
+    p[10] = fminf(fmaxf(floorf(__fmul_rn(e[8], 24.f)), 0.f), 23.f);
+    p[11] = e[9] < cfg.p_gray ? 1.f : 0.f;
+}
+
 __global__ void __launch_bounds__(256) augment_kernel(const float* __restrict__ x, float* __restrict__ out, int h, int w,
                                                       const float* __restrict__ params) {
     const int n = blockIdx.y;
@@ -1007,6 +1056,33 @@ int ocl_scr_augment(const float* x, float* out, int n, int h, int w, const float
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(PROF_BN, s);
     hipLaunchKernelGGL(augment_kernel, dim3(cdiv(h * w, 256), n), dim3(256), 0, s, x, out, h, w, params);
+    OCL_LAUNCH_CHECK();
+    return OCL_OK;
+}
+
+int ocl_scr_augment_uniform(const float* x, float* out, int n, int h, int w, const float* u, const double* cfg12, float* params,
+                            void* stream) {
+    OCL_REQUIRE(n >= 0 && h > 0 && w > 0, "augment: bad shape");
+    if (n == 0) return OCL_OK;
+    OCL_REQUIRE(x && out && u && cfg12 && params && x != out, "augment: null pointer or in-place");
+    AugCfg cfg;
+    // derived constants in double, rounded once (what the host arithmetic does with Python floats applied to fp32 tensors)
+    cfg.s0 = (float)cfg12[0]; cfg.ds = (float)(cfg12[1] - cfg12[0]);
+    cfg.lr0 = (float)log(cfg12[2]); cfg.dlr = (float)(log(cfg12[3]) - log(cfg12[2]));
+    cfg.b = (float)cfg12[4]; cfg.c = (float)cfg12[5]; cfg.s = (float)cfg12[6]; cfg.hue = (float)cfg12[7];
+    cfg.p_jit = (float)cfg12[8]; cfg.p_gray = (float)cfg12[9];
+    cfg.fb_w = (float)cfg12[10]; cfg.fb_h = (float)cfg12[11];
+    for (int k = 0; k < 3; ++k) {
+        cfg.j0[k] = (float)(1.0 - cfg12[4 + k]);
+        cfg.j1[k] = (float)(2.0 * cfg12[4 + k]);
+    }
+    cfg.j0[3] = (float)(-cfg12[7]);
+    cfg.j1[3] = (float)(2.0 * cfg12[7]);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope ps(PROF_BN, s);
+    hipLaunchKernelGGL(aug_params_kernel, dim3(cdiv(n, 64)), dim3(64), 0, s, u, n, h, w, cfg, params);
+    OCL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(augment_kernel, dim3(cdiv(h * w, 256), n), dim3(256), 0, s, x, out, h, w, (const float*)params);
     OCL_LAUNCH_CHECK();
     return OCL_OK;
 }

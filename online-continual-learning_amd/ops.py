@@ -8,37 +8,6 @@ import torch
 from . import ffi
 
 
-class _PinnedRing(object):
-    """Small host->device uploads (index vectors, augmentation parameters) without stalling the host: a pageable-memory
-    `.to(device)` blocks until the stream has drained, which serialises the host bookkeeping of step i+1 behind the GPU
-    work of step i.  Each upload goes through one slot of a ring of pinned buffers and an asynchronous copy; a slot is
-    reused only after the event recorded behind its copy has completed."""
-
-    def __init__(self, slots=64, slot_bytes=1 << 16):
-        self.slots, self.slot_bytes = slots, slot_bytes
-        self.bufs, self.events, self.i = None, [None] * slots, 0
-
-    def upload(self, t, device):
-        nbytes = t.numel() * t.element_size()
-        if nbytes == 0 or nbytes > self.slot_bytes:
-            return t.to(device)
-        if self.bufs is None:
-            self.bufs = [torch.empty(self.slot_bytes, dtype=torch.uint8).pin_memory() for _ in range(self.slots)]
-        k = self.i
-        self.i = (k + 1) % self.slots
-        if self.events[k] is not None:
-            self.events[k].synchronize()
-        stage = self.bufs[k][:nbytes].view(t.dtype).view(t.shape)
-        stage.copy_(t)
-        d = stage.to(device, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        self.events[k] = ev
-        return d
-
-
-_ring = _PinnedRing()
-
 _data_streams = {}
 
 
@@ -52,12 +21,24 @@ def data_stream(device):
 
 
 def upload(t, device):
-    """Asynchronous upload of a small CPU tensor (or numpy array) to `device`."""
+    """Asynchronous upload of a small CPU tensor (or numpy array) to `device` on the current stream.  A pageable-memory
+    `.to(device)` blocks the host until the stream has drained, which serialises the host bookkeeping of step i+1 behind the GPU
+    work of step i; `ocl_upload` stages the payload through the library's ring of pinned slots instead (one C call, no torch
+    event / pinned-tensor objects: the index vectors of a replay step are 4 such uploads)."""
     if not torch.is_tensor(t):
         t = torch.from_numpy(t)
     if t.is_cuda:
         return t
-    return _ring.upload(t.contiguous(), device)
+    t = t.contiguous()
+    d = torch.empty(t.shape, dtype=t.dtype, device=device)
+    n = t.numel() * t.element_size()
+    if n:
+        if d.device.index != torch._C._cuda_getDevice():     # the staging ring and the stream belong to the current device
+            with torch.cuda.device(d.device):
+                return upload(t, device)
+        ffi.init()
+        ffi.check(ffi.lib().ocl_upload(ffi.vp(t.data_ptr()), n, ffi.vp(d.data_ptr()), ffi.stream()), "upload")
+    return d
 
 
 def _f32(t):
@@ -288,6 +269,7 @@ def mir_scores(logits_pre, logits_post, y):
 
 # ---- K13 ---------------------------------------------------------------------------------------------
 AUG_NPARAM = 12
+AUG_NUNIFORM = 30
 
 
 def scr_augment(x, params):
@@ -299,6 +281,21 @@ def scr_augment(x, params):
     out = torch.empty_like(x)
     ffi.check(ffi.lib().ocl_scr_augment(ffi.ptr(x), ffi.ptr(out), n, h, w, ffi.ptr(params), ffi.stream()), "scr_augment")
     return out
+
+
+def scr_augment_uniform(x, u, cfg12, want_params=False):
+    """Augmented view from raw uniform draws u [n, AUG_NUNIFORM] (device): parameter arithmetic and the image kernel in one call."""
+    ffi.init()
+    x, u = _f32(x), _f32(u)
+    n, c, h, w = x.shape
+    if c != 3 or u.shape != (n, AUG_NUNIFORM) or len(cfg12) != 12:
+        raise RuntimeError("scr_augment_uniform: x must be [n,3,h,w], u [n,%d], cfg 12 floats" % AUG_NUNIFORM)
+    out = torch.empty_like(x)
+    params = torch.empty((n, AUG_NPARAM), dtype=torch.float32, device=x.device)
+    cfg = (ffi.C.c_double * 12)(*[float(v) for v in cfg12])
+    ffi.check(ffi.lib().ocl_scr_augment_uniform(ffi.ptr(x), ffi.ptr(out), n, h, w, ffi.ptr(u), cfg, ffi.ptr(params), ffi.stream()),
+              "scr_augment_uniform")
+    return (out, params) if want_params else out
 
 
 def gemm_small(a, b, bias=None, relu=False, trans_b=False):

@@ -4,6 +4,8 @@ import torch
 
 def maybe_cuda(what, use_cuda=True, **kw):
     """utils/utils.py:4-16. Moves `what` to the GPU when one is visible (and use_cuda is not False)."""
+    if getattr(what, "is_cuda", False):      # already resident (the common case inside the replay loop)
+        return what
     if use_cuda is not False and torch.cuda.is_available():
         what = what.cuda()
     return what

@@ -229,3 +229,42 @@ def test_reference_driver_with_the_integration_patch_reaches_the_hip_boundary():
         for k in [k for k in sys.modules if k.split(".")[0] in ("utils", "experiment", "continuum", "agents", "models")]:
             del sys.modules[k]
         sys.modules.update({k: v for k, v in saved.items() if v is not None})
+
+
+def test_class_balanced_draw_in_c_equals_the_python_loop():
+    """csrc/hostc.c (CPython set operations + torch's CPU generator restated on the bytes of get_rng_state) against the Python
+    statement of ClassBalancedRandomSampling's loop: same picks, same generator state afterwards, for churned class tables, empty
+    classes, exclusion sets and arbitrary generator positions (also across the generator's 624-word reload)."""
+    from collections import defaultdict
+    from ocl_amd.plugins import buffer_utils as B
+    assert B._hostc is not None, "online-continual-learning_amd/_hostc*.so is not built (make -C online-continual-learning_amd/csrc)"
+    assert B._hostc_usable()
+    C = B.ClassBalancedRandomSampling
+    saved = C.class_index_cache
+    rng = np.random.default_rng(0)
+    try:
+        for trial in range(12):
+            cache = defaultdict(set)
+            labels = rng.integers(0, 100, 3000)
+            for slot in rng.permutation(3000):
+                cache[int(labels[slot])].add(int(slot))
+            for _ in range(1500):                      # slots change class the way updates move them
+                slot, new = int(rng.integers(0, 3000)), int(rng.integers(0, 100))
+                for members in cache.values():
+                    if slot in members:
+                        members.remove(slot)
+                        break
+                cache[new].add(slot)
+            cache[777] = set()
+            C.class_index_cache = cache
+            excl = set(int(v) for v in rng.choice(3000, int(rng.integers(0, 400)), replace=False)) if trial % 3 else None
+            n_smp = [1, 2, 3, 5, 80][trial % 5]
+            torch.manual_seed(trial)
+            torch.rand(trial * 37)
+            a, sa = C.draw(n_smp, excl), torch.get_rng_state()
+            torch.manual_seed(trial)
+            torch.rand(trial * 37)
+            b, sb = C.draw_fast(n_smp, excl), torch.get_rng_state()
+            assert torch.equal(a, b) and torch.equal(sa, sb), trial
+    finally:
+        C.class_index_cache = saved

@@ -221,6 +221,32 @@ def test_scr_augment_kernel_properties(cuda):
     assert oc.min() >= 0 and oc.max() <= 1
 
 
+def test_scr_augment_parameters_on_the_device_match_the_host_statement(cuda):
+    """aug_params_kernel (crop attempts, fallback, position, jitter factors from raw uniform draws) against
+    ScrAugment.params_from_uniform on the same draws; the fused call equals the two-step call on its own parameters."""
+    from ocl_amd import ops
+    from ocl_amd.agents.scr import ScrAugment
+    torch.manual_seed(5)
+    for size, scale, n in (((32, 32), (0.2, 1.0), 4096), ((84, 84), (0.2, 1.0), 2048), ((16, 64), (0.99, 1.0), 512)):
+        aug = ScrAugment(size, scale=scale)
+        u = aug.draw(n)
+        want = aug.params_from_uniform(u).numpy()
+        x = torch.rand(n, 3, size[0], size[1])
+        out, params = ops.scr_augment_uniform(dev(x, cuda), dev(u, cuda), aug.config(), want_params=True)
+        got = params.cpu().numpy()
+        # exp / sqrt differ by an ulp between the two maths libraries: a crop edge may round the other way for a draw that lands on
+        # a rounding boundary (and then the position, drawn inside the crop's slack, moves with it): rare, and never by more than 1
+        differs = np.abs(got - want).max(1) > 1e-5
+        assert differs.mean() < 2e-3, differs.mean()
+        assert np.abs(got[:, 2:4] - want[:, 2:4]).max() <= 1.0
+        assert np.array_equal(got[:, [4, 5, 10, 11]], want[:, [4, 5, 10, 11]])
+        assert np.abs(got[:, 6:10] - want[:, 6:10]).max() < 1e-6
+        if size == (16, 64):
+            assert (got[:, 2] == 16).all() and (got[:, 3] == 21).all()          # fallback crop: ratio clamped to 4/3
+        two_step = ops.scr_augment(dev(x, cuda), params)
+        assert torch.equal(out, two_step)
+
+
 def test_ce_tricks_match_reference_golden(cuda):
     """ocl_ce_segmented_fwd_bwd through the agent's criterion (host-built segment table) vs the reference's labels trick /
     separated softmax + autograd: loss and d(loss)/d(logits) within 1e-5 abs (fp32 exp/log round-off); a label outside
