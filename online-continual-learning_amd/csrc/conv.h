@@ -166,8 +166,10 @@ struct PackDesc {
     int Cout, Cin, ntaps, CinP, CoutP, CiP;
 };
 enum { PACK_F = 1, PACK_D = 2, PACK_TF = 4, PACK_TD = 8, PACK_ALL = 15 };   // which packs a launch writes
+// zero_a / zero_b: two arrays of doubles cleared by the same launch (the BatchNorm statistics arenas of the pass), may be null / 0
 int launch_pack_weights(const float* params, float* arena, const PackDesc* descs_dev, int n_layers, int max_elems,
-                        hipStream_t s, int mask = PACK_ALL);
+                        hipStream_t s, int mask = PACK_ALL, double* zero_a = nullptr, int64_t zero_a_n = 0, double* zero_b = nullptr,
+                        int64_t zero_b_n = 0);
 
 // ---- layout / elementwise ------------------------------------------------------------------------------
 int launch_nchw3_to_nhwc4(const float* x, float* out, int N, int H, int W, hipStream_t s);

@@ -1787,7 +1787,15 @@ int launch_wgrad_reduce_multi(WgradReduceMulti m, hipStream_t s) {
 // weight packing (all conv layers in one launch)
 // =====================================================================================================
 __global__ void __launch_bounds__(256) pack_weights_kernel(const float* __restrict__ params, float* __restrict__ arena,
-                                                           const PackDesc* __restrict__ descs, int mask) {
+                                                           const PackDesc* __restrict__ descs, int mask, int n_layers, double* __restrict__ zero_a,
+                                                           int64_t zero_a_n, double* __restrict__ zero_b, int64_t zero_b_n) {
+    if ((int)blockIdx.y >= n_layers) {   // the last grid row clears the statistics arenas of the pass (saves two memset launches)
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < zero_a_n + zero_b_n; i += (int64_t)gridDim.x * blockDim.x) {
+            if (i < zero_a_n) zero_a[i] = 0.0;
+            else zero_b[i - zero_a_n] = 0.0;
+        }
+        return;
+    }
     PackDesc d = descs[blockIdx.y];
     // the scattered stores are the cost of this kernel: a pass writes only the packs it reads (PACK_* bits)
     if (!(mask & PACK_F)) d.f_off = -1;
@@ -1808,10 +1816,11 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const float* __restri
 }
 
 int launch_pack_weights(const float* params, float* arena, const PackDesc* descs_dev, int n_layers, int max_elems, hipStream_t s,
-                        int mask) {
+                        int mask, double* zero_a, int64_t zero_a_n, double* zero_b, int64_t zero_b_n) {
     ProfScope ps(PROF_BN, s);
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(std::min(64, cdiv(max_elems, 256)), n_layers), dim3(256), 0, s, params, arena,
-                       descs_dev, mask);
+    const int extra = (zero_a_n + zero_b_n) > 0 ? 1 : 0;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(std::min(64, cdiv(max_elems, 256)), n_layers + extra), dim3(256), 0, s, params, arena,
+                       descs_dev, mask, n_layers, zero_a, zero_a_n, zero_b, zero_b_n);
     OCL_LAUNCH_CHECK();
     return OCL_OK;
 }

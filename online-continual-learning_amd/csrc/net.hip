@@ -92,6 +92,7 @@ struct ocl_net {
     bool descs_uploaded = false;
     const float* pack_src = nullptr;   // parameter array the weight-pack arena was last written from (by a forward)
     int pack_have = 0;                 // PACK_* bits of the packs that hold `pack_src`'s weights
+    bool bsums_clean = false;          // the backward's statistics arena was cleared by the last forward's pack launch and not used since
     int pack_need_fwd = 0, pack_need_bwd = 0;   // packs the plans made so far read (the round-1 kernel's layouts only where it is planned)
 
     int dbg_stop = -1;            // debug: return from backward right after stage (block*10 + step)
@@ -612,7 +613,7 @@ static int trunk_forward_train(ocl_net* n, PlanSet* ps, const float* P, float* S
     float* pack = (float*)(n->ws + n->off_pack);
     double* stats = n->statsbuf();
     int rc = OCL_OK;
-    OCL_HIP(hipMemsetAsync(stats, 0, n->stats_doubles * 8, st));
+    // (cleared by the forward's weight-pack launch)
     auto at = [&](int64_t off, const ConvInfo& c) { return S + off + (int64_t)img0 * c.Ho * c.Wo * c.Cout; };
     // side: the projection shortcut (1x1 conv + BatchNorm, 3 blocks) runs on the engine's second stream next to conv1 / bn1 /
     // conv2 of its block, which do not depend on it
@@ -704,7 +705,10 @@ int ocl_net_forward(ocl_net* n, const float* x, int N, int groups, uint32_t flag
     // every forward packs (the caller may have stepped the weights), but only the layouts the pass reads: the forward packs, and the
     // data-gradient packs when a backward will follow this tape
     const int pack_mask = n->pack_need_fwd | ((flags & OCL_FWD_SAVE_TAPE) ? n->pack_need_bwd : 0);
-    rc = launch_pack_weights(P, pack, pack_descs(n), (int)n->convs.size(), max_elems, s, pack_mask);
+    // (the same launch clears the statistics arenas: the forward's, and the backward's for the backward that follows a taped pass)
+    rc = launch_pack_weights(P, pack, pack_descs(n), (int)n->convs.size(), max_elems, s, pack_mask, n->statsbuf(), n->stats_doubles,
+                             n->bsumsbuf(), n->bsums_doubles);
+    n->bsums_clean = true;
     if (rc != OCL_OK) return rc;
     n->pack_have = n->pack_src == P ? (n->pack_have | pack_mask) : pack_mask;   // (older packs of the same array stay as they were)
     n->pack_src = P;
@@ -784,7 +788,8 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
     double* bsums = n->bsumsbuf();
     int rc = OCL_OK;
     const bool two_streams_arg = side != nullptr;
-    OCL_HIP(hipMemsetAsync(bsums, 0, n->bsums_doubles * 8, s));
+    if (!n->bsums_clean) OCL_HIP(hipMemsetAsync(bsums, 0, n->bsums_doubles * 8, s));   // a second backward since the last forward
+    n->bsums_clean = false;
     auto T = [&](int t) { return P + n->tensors[t].off; };
     auto GT = [&](int t) { return Gr + n->tensors[t].off; };
     auto at = [&](int64_t off, const ConvInfo& c) { return S + off + (int64_t)img0 * c.Ho * c.Wo * c.Cout; };
