@@ -834,7 +834,9 @@ __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
             } else {
                 for (int s_ = 0; s_ < ct.w; ++s_, ++st) {
                     w_commit(st & 1);
+                    stamp();   // (staged) weights of the stage arrived and written
                     __syncthreads();   // stage st's weights (and the patch) visible; everyone is done with stage st-1
+                    stamp();   // (staged) barrier passed
                     {   // the stage after this one: next stage of the class, next chunk, next class, next tile
                         int ns = s_ + 1, nc0 = c0, ncl = cls, nk = k;
                         if (ns >= ct.w) {
@@ -848,6 +850,7 @@ __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
                     }
                     const int q0 = ct.x + s_ * a.QS;
                     rounds(wl + (size_t)(st & 1) * a.QS * COPW * 4, q0, min(a.QS, ct.x + ct.y - q0));
+                    stamp();   // (staged) MFMAs of the stage issued
                 }
             }
         }

@@ -186,6 +186,31 @@ static void bench_geom(const char* lname, const char* kind, ConvGeomDesc g, cons
                 stats = stats2;
                 const double t = time_us([&] { run(pt, out); });
                 stats = keep2;
+                if (mt == 0 && !pt.a.wres && getenv("KBENCH_TRACE")) {   // staged weights: raw phase deltas of wave 0 of two workgroups
+                    const int nwg = pt.grid_x * pt.grid_y;
+                    unsigned long long* tr;
+                    CK(hipMalloc(&tr, (size_t)nwg * 64 * 8));
+                    CK(hipMemset(tr, 0, (size_t)nwg * 64 * 8));
+                    ConvPlan ptt = pt;
+                    ptt.a.trace = tr;
+                    stats = stats2;
+                    run(ptt, out);
+                    stats = keep2;
+                    CK(hipDeviceSynchronize());
+                    std::vector<unsigned long long> h((size_t)nwg * 64);
+                    CK(hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost));
+                    unsigned long long t0 = ~0ull, t1 = 0;
+                    for (int w = 0; w < nwg; ++w) { t0 = std::min(t0, h[(size_t)w * 64]); for (int e = 0; e < 64; ++e) t1 = std::max(t1, h[(size_t)w * 64 + e]); }
+                    printf("      trace (staged): kernel span %llu cycles; nstage=%d chunks=%d; per workgroup: start | prologue x5 | per chunk: setup barrier patch-store, then per stage [commit-wait barrier mfma] ... | epilogue\n",
+                           t1 - t0, pt.a.nstage, pt.a.Cin / pt.a.KC);
+                    for (int w : {0, nwg / 2}) {
+                        const unsigned long long* r = &h[(size_t)w * 64];
+                        printf("      wg %4d: +%6llu |", w, r[0] - t0);
+                        for (int e = 1; e < 64 && r[e]; ++e) printf(" %llu", r[e] - r[e - 1]);
+                        printf("\n");
+                    }
+                    CK(hipFree(tr));
+                }
                 if (mt == 0 && pt.a.wres && getenv("KBENCH_TRACE")) {   // phase timeline of wave 0 of a few workgroups (s_memtime cycles)
                     const int nwg = pt.grid_x * pt.grid_y;
                     unsigned long long* tr;
