@@ -97,13 +97,26 @@ static PyObject* py_randperm_check(PyObject* self, PyObject* args) {
     return out;
 }
 
-/* cbrs_sample(class_index_cache: dict[label -> set[int]], excluded: set | None, n_smp_cls: int, state, out) -> number of picks
- * out: writable buffer of int64; raises if it is too small. */
+/* Iteration order of `slots - set()` per class, kept between calls (draws without exclusions: two of the three draws of an ASER
+ * step).  The order of the NEW set only depends on the contents and history of `slots`; the Python side keeps a version counter per
+ * label (bumped whenever update_cache moves a slot in or out of the class) and a token that changes whenever the dict itself is
+ * replaced, so an entry is reused only for an unchanged class of the same dict.  The set's size is compared as well. */
+#define MEMO_LABELS 4096
+typedef struct {
+    long long token, version;
+    Py_ssize_t n;
+    int64_t* members;
+} ClassMemo;
+static ClassMemo g_memo[MEMO_LABELS];
+
+/* cbrs_sample(class_index_cache: dict[label -> set[int]], excluded: set | None, n_smp_cls: int, state, out[, versions, token])
+ * -> number of picks.  out: writable buffer of int64; raises if it is too small.  versions: int64 buffer indexed by label. */
 static PyObject* py_cbrs_sample(PyObject* self, PyObject* args) {
     PyObject *cache, *excluded;
-    long long n_smp;
-    Py_buffer sb, ob;
-    if (!PyArg_ParseTuple(args, "O!OLw*w*", &PyDict_Type, &cache, &excluded, &n_smp, &sb, &ob)) return NULL;
+    long long n_smp, token = 0;
+    Py_buffer sb, ob, vb;
+    vb.buf = NULL; vb.obj = NULL; vb.len = 0;
+    if (!PyArg_ParseTuple(args, "O!OLw*w*|y*L", &PyDict_Type, &cache, &excluded, &n_smp, &sb, &ob, &vb, &token)) return NULL;
     MtState* s;
     PyObject* result = NULL;
     PyObject* empty = NULL;
@@ -120,6 +133,9 @@ static PyObject* py_cbrs_sample(PyObject* self, PyObject* args) {
     }
     if (n_smp < 0) n_smp = 0;
     {
+        const int64_t* versions = (const int64_t*)vb.buf;
+        const Py_ssize_t n_versions = vb.buf ? vb.len / (Py_ssize_t)sizeof(int64_t) : 0;
+        const int memo_ok = versions != NULL && PySet_GET_SIZE(excluded) == 0;
         int64_t* out = (int64_t*)ob.buf;
         const Py_ssize_t out_cap = ob.len / (Py_ssize_t)sizeof(int64_t);
         Py_ssize_t n_out = 0, pos = 0;
@@ -130,6 +146,34 @@ static PyObject* py_cbrs_sample(PyObject* self, PyObject* args) {
                 goto done;
             }
             if (PySet_GET_SIZE(slots) == 0) continue;
+            ClassMemo* memo = NULL;
+            if (memo_ok && PyLong_Check(key)) {
+                const long long label = PyLong_AsLongLong(key);
+                if (label >= 0 && label < MEMO_LABELS && label < n_versions) {
+                    memo = &g_memo[label];
+                    if (memo->members && memo->token == token && memo->version == versions[label] && memo->n == PySet_GET_SIZE(slots)) {
+                        const Py_ssize_t n = memo->n;
+                        if (n > cap) {
+                            cap = n * 2 + 64;
+                            int64_t* m2 = (int64_t*)PyMem_Realloc(members, sizeof(int64_t) * (size_t)cap);
+                            int64_t* p2 = m2 ? (int64_t*)PyMem_Realloc(perm, sizeof(int64_t) * (size_t)cap) : NULL;
+                            if (m2) members = m2;
+                            if (p2) perm = p2;
+                            if (!m2 || !p2) { PyErr_NoMemory(); goto done; }
+                        }
+                        randperm(s, (int64_t)n, perm);
+                        const Py_ssize_t take = n < (Py_ssize_t)n_smp ? n : (Py_ssize_t)n_smp;
+                        if (n_out + take > out_cap) {
+                            PyErr_SetString(PyExc_ValueError, "output buffer too small");
+                            goto done;
+                        }
+                        for (Py_ssize_t j = 0; j < take; ++j) out[n_out++] = memo->members[perm[j]];
+                        continue;
+                    }
+                    memo->version = versions[label];
+                    memo->token = token;
+                }
+            }
             PyObject* eligible = PyNumber_Subtract(slots, excluded);   /* a new set, exactly as `slots - excluded` */
             if (!eligible) goto done;
             const Py_ssize_t n = PySet_GET_SIZE(eligible);
@@ -151,6 +195,17 @@ static PyObject* py_cbrs_sample(PyObject* self, PyObject* args) {
                 members[k++] = (int64_t)v;
             }
             Py_DECREF(eligible);
+            if (memo) {   /* keep the order for the next draw of this (unchanged) class */
+                int64_t* mm = (int64_t*)PyMem_RawRealloc(memo->members, sizeof(int64_t) * (size_t)(n ? n : 1));
+                if (mm) {
+                    memcpy(mm, members, sizeof(int64_t) * (size_t)n);
+                    memo->members = mm;
+                    memo->n = n;
+                } else {
+                    PyMem_RawFree(memo->members);
+                    memo->members = NULL;
+                }
+            }
             const Py_ssize_t take = n < (Py_ssize_t)n_smp ? n : (Py_ssize_t)n_smp;
             if (n_out + take > out_cap) {
                 PyErr_SetString(PyExc_ValueError, "output buffer too small");
@@ -166,6 +221,7 @@ done:
     Py_XDECREF(empty);
     PyBuffer_Release(&sb);
     PyBuffer_Release(&ob);
+    if (vb.obj) PyBuffer_Release(&vb);
     return result;
 }
 

@@ -121,6 +121,11 @@ class ClassBalancedRandomSampling:
     class_index_cache = None
     class_num_cache = None
     _scratch = None
+    # bookkeeping for the C helper's per-class memo of `slots - set()` iteration orders (csrc/hostc.c): a version per label, bumped by
+    # update_cache whenever a slot enters or leaves the class; a token that changes whenever the dict itself is another object
+    _versions = None
+    _tracked = None
+    _token = 0
 
     @classmethod
     def draw(cls, n_smp_cls, excl_indices=None):
@@ -147,11 +152,15 @@ class ClassBalancedRandomSampling:
         if not _hostc_usable():
             return cls.draw(n_smp_cls, excl_indices)
         cache = cls.class_index_cache
+        if cache is not cls._tracked:     # another dict (plugin re-initialised, rebuilt from the labels, set by a test): forget the memo
+            cls._tracked = cache          # (the reference keeps the tracked dict alive, so its identity cannot be reused)
+            ClassBalancedRandomSampling._token += 1
+            cls._versions = np.zeros(4096, dtype=np.int64)
         state = torch.get_rng_state()
         room = max(1, len(cache) * max(0, int(n_smp_cls)))
         if cls._scratch is None or cls._scratch.shape[0] < room:
             cls._scratch = np.empty(room, dtype=np.int64)
-        n = _hostc.cbrs_sample(cache, excl_indices, int(n_smp_cls), state.numpy(), cls._scratch)
+        n = _hostc.cbrs_sample(cache, excl_indices, int(n_smp_cls), state.numpy(), cls._scratch, cls._versions, cls._token)
         torch.set_rng_state(state)
         return torch.from_numpy(cls._scratch[:n].copy())
 
@@ -181,14 +190,19 @@ class ClassBalancedRandomSampling:
                 rebuilt[int(label)].add(slot)
             cls.class_index_cache = rebuilt
             return
+        versions = cls._versions if cls._tracked is cls.class_index_cache else None
         for slot, label in zip(ind, new_y):
             slot, label = int(slot), int(label)
             previous = int(buffer_y_host[slot])
             if previous in cls.class_index_cache and slot in cls.class_index_cache[previous]:
                 cls.class_index_cache[previous].remove(slot)
                 cls.class_num_cache[previous] -= 1
+                if versions is not None and 0 <= previous < 4096:
+                    versions[previous] += 1
             cls.class_index_cache[label].add(slot)
             cls.class_num_cache[label] += 1
+            if versions is not None and 0 <= label < 4096:
+                versions[label] += 1
 
 class BufferClassTracker(object):
     """buffer_utils.py:163-203: per-buffer class -> set-of-slots index and per-class counts, maintained by the reservoir update

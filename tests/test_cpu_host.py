@@ -268,3 +268,37 @@ def test_class_balanced_draw_in_c_equals_the_python_loop():
             assert torch.equal(a, b) and torch.equal(sa, sb), trial
     finally:
         C.class_index_cache = saved
+
+
+def test_class_balanced_draw_memo_follows_the_class_table():
+    """The C helper keeps the iteration order of `slots - set()` per class between exclusion-free draws (versions bumped by
+    update_cache, token per dict object): a long sequence of draws interleaved with slot moves, dict rebuilds and draws with
+    exclusions stays equal to the Python loop, picks and generator state."""
+    from ocl_amd.plugins import buffer_utils as B
+    assert B._hostc_usable()
+    C = B.ClassBalancedRandomSampling
+    saved = (C.class_index_cache, C.class_num_cache)
+    rng = np.random.default_rng(3)
+    try:
+        n_slots, n_cls = 1200, 40
+        labels = rng.integers(0, n_cls, n_slots).astype(np.int64)
+        C.class_index_cache = None
+        C.update_cache(labels, n_cls)                                    # rebuild path: a new dict
+        C.class_num_cache = torch.from_numpy(np.bincount(labels, minlength=n_cls)).long()
+        torch.manual_seed(11)
+        for step in range(60):
+            if step % 17 == 16:                                          # the dict replaced by a rebuild from the labels
+                C.update_cache(labels, n_cls)
+            if step % 2:                                                 # slots change class as an ASER update moves them
+                ind = rng.choice(n_slots, 6, replace=False)
+                new = rng.integers(0, n_cls, 6).astype(np.int64)
+                C.update_cache(labels, n_cls, new_y=new, ind=ind.tolist())
+                labels[ind] = new
+            excl = None if step % 3 else set(int(v) for v in rng.choice(n_slots, 90, replace=False))
+            state = torch.get_rng_state()
+            a, sa = C.draw(3, excl), torch.get_rng_state()
+            torch.set_rng_state(state)
+            b, sb = C.draw_fast(3, excl), torch.get_rng_state()
+            assert torch.equal(a, b) and torch.equal(sa, sb), step
+    finally:
+        C.class_index_cache, C.class_num_cache = saved
