@@ -69,8 +69,9 @@ class ExperienceReplay(ContinualLearner):
         (loss + loss_mem).backward()
         self.opt.step()
 
-    def _two_pass_step(self, batch_x, batch_y, batch_y_host, meters, aser, retrieved=None):
-        logits = self.model.forward(batch_x)
+    def _two_pass_step(self, batch_x, batch_y, batch_y_host, meters, aser, retrieved=None, logits=None):
+        if logits is None:      # (the pipelined ASER loop has issued this forward already)
+            logits = self.model.forward(batch_x)
         loss = self._kd_mix(self.criterion(logits, batch_y), logits, batch_x)
         self._track(meters[0], logits, batch_y, loss)
         self._emit("er_loss", loss)
@@ -116,9 +117,24 @@ class ExperienceReplay(ContinualLearner):
         merge = (self.params.retrieve == 'random' and not aser and not trick['kd_trick'] and not trick['kd_trick_star']
                  and os.environ.get("OCL_ER_MERGE", "1") != "0")
 
+        # ASER update: its host half (wait for the ranking, class-table bookkeeping, row moves) leaves the GPU idle, and the first
+        # forward of the NEXT iteration (batch pass: reads the weights, which are final after opt.step, and updates the running
+        # statistics, which the update's scoring kernels - already issued - read before it) does not depend on it.  That forward is
+        # issued first, the update is finished behind it: same kernels, same data, same RNG draws, the host half hidden.
+        upd = self.buffer.update_method
+        pipeline = (aser and self.params.update == 'ASER' and self.params.retrieve != 'MIR' and self.cuda and not debug.on()
+                    and not trick['kd_trick'] and not trick['kd_trick_star'] and hasattr(upd, "update_begin")
+                    and os.environ.get("OCL_ASER_PIPELINE", "1") != "0")
+
         for ep in range(self.epoch):
+            pending = None
             for i, (batch_x, batch_y) in enumerate(train_loader):
                 batch_y_host = train_loader.last_y_host
+                pre = None
+                if pipeline:
+                    pre = self.model.forward(batch_x)
+                    upd.update_finish(self.buffer, pending)
+                    pending = None
                 for j in range(self.mem_iters):
                     retrieved = None
                     if merge:
@@ -127,12 +143,17 @@ class ExperienceReplay(ContinualLearner):
                             self._merged_step(batch_x, batch_y, maybe_cuda(retrieved[0], self.cuda), maybe_cuda(retrieved[1], self.cuda),
                                               meters)
                             continue
-                    self._two_pass_step(batch_x, batch_y, batch_y_host, meters, aser, retrieved)
+                    self._two_pass_step(batch_x, batch_y, batch_y_host, meters, aser, retrieved, logits=pre if j == 0 else None)
 
-                self.buffer.update(batch_x, batch_y, y_host=batch_y_host)
+                if pipeline:
+                    pending = upd.update_begin(self.buffer, batch_x, batch_y, y_host=batch_y_host)
+                else:
+                    self.buffer.update(batch_x, batch_y, y_host=batch_y_host)
 
                 if i % 100 == 1 and self.verbose:
                     for tag, (loss_meter, acc_meter) in zip(("", "mem "), meters):
                         print('==>>> it: {}, {}avg. loss: {:.6f}, running {}acc: {:.3f}'.format(i, tag, loss_meter.avg(), "mem " if tag else "train ",
                                                                                              acc_meter.avg()))
+            if pipeline:
+                upd.update_finish(self.buffer, pending)
         self.after_train()

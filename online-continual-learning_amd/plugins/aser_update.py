@@ -27,16 +27,28 @@ class ASER_update(object):
         self.n_smp_cls = int(params.n_smp_cls)
         self.n_total_smp = int(params.n_smp_cls * self.out_dim)
         self.reservoir_update = Reservoir_update(params)
+        self._pinned = None
         ClassBalancedRandomSampling.class_index_cache = None     # class-level state, reset per plugin instance (:20)
 
     # ---- entry point ---------------------------------------------------------------------------------------------------------
     def update(self, buffer, x, y, **kwargs):
+        self.update_finish(buffer, self.update_begin(buffer, x, y, **kwargs))
+
+    # Two halves of update(), for a caller that has other GPU work to issue in between (agents/exp_replay.py: the first forward of the
+    # next iteration): `update_begin` does everything up to and including the scoring kernels (all RNG draws, in order), `update_finish`
+    # waits for the ranking, updates the class table and moves the rows.
+    def update_begin(self, buffer, x, y, **kwargs):
         labels = _host_labels(y, kwargs.get("y_host"))
         free = self.mem_size - buffer.current_index
         if free:
             self._append(buffer, x[:free], y[:free], labels[:free])
         if buffer.current_index == self.mem_size:
-            self._compete(buffer, x[free:], y[free:], labels[free:])
+            return self._score(buffer, x[free:], y[free:], labels[free:])
+        return None
+
+    def update_finish(self, buffer, pending):
+        if pending is not None:
+            self._replace(buffer, *pending)
 
     def _append(self, buffer, x, y, labels):
         """Fill phase (:27-36): the class cache first (it reads the labels being overwritten), then the reservoir append."""
@@ -46,7 +58,7 @@ class ASER_update(object):
         self.reservoir_update.update(buffer, x, y, y_host=labels)
 
     # ---- full memory: Shapley-ranked replacement (:43-112) ------------------------------------------------------------------------
-    def _compete(self, buffer, cur_x, cur_y, cur_labels):
+    def _score(self, buffer, cur_x, cur_y, cur_labels):
         cur_x, cur_y = maybe_cuda(cur_x).contiguous(), maybe_cuda(cur_y).contiguous()
         # RNG draws in the reference's order: minority threshold (torch CPU), evaluation set (one randperm per class), candidates (numpy)
         minor_x, minor_y = add_minority_class_input(cur_x, cur_y, self.mem_size, self.out_dim, cur_y_host=cur_labels)
@@ -61,13 +73,31 @@ class ASER_update(object):
         if trace:
             values, knn_order = values
         total = ops.col_reduce(values, "sum")
-        ranking = ops.argsort_desc(total).cpu()          # the update's one device->host copy
+        ranking_dev = ops.argsort_desc(total)
+        # the ranking travels to the host asynchronously, behind the scoring kernels and in front of whatever the caller issues next
+        if ranking_dev.is_cuda:
+            if self._pinned is None or self._pinned.numel() < ranking_dev.numel():
+                self._pinned = torch.empty(max(1024, ranking_dev.numel()), dtype=ranking_dev.dtype).pin_memory()
+            ranking_host = self._pinned[:ranking_dev.numel()]
+            ranking_host.copy_(ranking_dev, non_blocking=True)
+            arrived = torch.cuda.Event()
+            arrived.record()
+        else:
+            ranking_host, arrived = ranking_dev, None
+        buffer.n_seen_so_far += n_cur
+        return (cur_x, cur_y, cur_labels, mem_slots, eval_slots, minor_x, total, (ranking_host, arrived, ranking_dev), knn_order, n_mem, n_cur)
+
+    def _replace(self, buffer, cur_x, cur_y, cur_labels, mem_slots, eval_slots, minor_x, total, ranking_dev, knn_order, n_mem, n_cur):
+        trace = debug.on()
+        ranking_host, arrived, _keep = ranking_dev
+        if arrived is not None:
+            arrived.synchronize()                        # the update's one synchronisation: the ranking has reached the host
+        ranking = ranking_host.clone()
 
         # the n_mem best-valued candidates hold a slot afterwards: batch items among them move in, memory items outside move out
         keep, drop = ranking[:n_mem], ranking[n_mem:]
         entering = keep[keep >= n_mem] - n_mem            # positions in the batch
         leaving = mem_slots[drop[drop < n_mem]]           # memory slots, paired with `entering` in ranking order
-        buffer.n_seen_so_far += n_cur
         if trace:
             debug.emit("aser_update", eval_indices=eval_slots.numpy().copy(), cand_ind=mem_slots.numpy().copy(), sv=total.cpu().numpy(),
                        order=ranking.numpy().copy(), ind_buffer=leaving.numpy().copy(), ind_cur=entering.numpy().copy(),
