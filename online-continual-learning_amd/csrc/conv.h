@@ -219,6 +219,7 @@ struct BnBwdArgs {
     double* sums;         // scratch [nsets][G][2][C], zeroed by the caller
     unsigned* barrier;    // zeroed by the caller, or null: arrival counter of the one-pass kernel (nsets == 1, G <= 2, see launch_bn_bwd)
     double* fsums;        // one-pass kernel: zeroed accumulators [8 replicas][G][2][C]
+    double* fsums_b;      // the same for the second BatchNorm (nsets == 2), null: two-kernel path for two sets
     int accumulate;       // dgamma/dbeta += (1) or = (0)
     unsigned* err;        // host-mapped asynchronous error word (one-pass kernel: arrival time-out), may be null
     int frozen;           // 1: the forward normalised with constant (running) statistics: dy = gamma*invstd*dpre, no mean terms

@@ -2109,10 +2109,14 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const BnBwdArgs a) {
 constexpr int kBnFusedThreads = 512;
 // accumulator replicas (same-address returning atomics serialise at the coherence point: 256 workgroups on one address cost ~20 us)
 constexpr int kBnFusedReps = 8;
-template <int E>
+// NS = 2: the two BatchNorms of a projection block (main path + shortcut) share the masked gradient dz; their outputs differ only
+// in xhat.  One launch reads dz, z, y_a, y_b and writes dy_a, dy_b (6 tensor passes, one grid arrival) instead of reduce + apply
+// (10 passes, 2 launches).  The sum of the masked gradient is the same for both; each BatchNorm's arena receives it with its own
+// sum of d * xhat.
+template <int E, int NS = 1>
 __global__ void __launch_bounds__(kBnFusedThreads) bn_bwd_fused_kernel(const BnBwdArgs a) {
-    __shared__ float4 red[2][kBnFusedThreads];
-    __shared__ float kk[2][4 * 40];
+    __shared__ float4 red[1 + NS][kBnFusedThreads];
+    __shared__ float kk[1 + NS][4 * 40];
     __shared__ bool timed_out;   // some workgroup never arrived (not all resident at once): the results are poisoned with NaN
     const int C4 = a.C >> 2;
     const int tid = threadIdx.x;
@@ -2126,14 +2130,12 @@ __global__ void __launch_bounds__(kBnFusedThreads) bn_bwd_fused_kernel(const BnB
     const int64_t units = M * C4;
     const float4* dz4 = (const float4*)a.dz + (int64_t)g * units;
     const float4* z4 = a.z ? (const float4*)a.z + (int64_t)g * units : nullptr;
-    const float4* y4 = (const float4*)a.y[0] + (int64_t)g * units;
-    float4* o4 = (float4*)a.dy[0] + (int64_t)g * units;
     const bool live = g < a.G && gt < S;
-    float4 d[E], xh[E];
-    float4 sd = make_float4(0.f, 0.f, 0.f, 0.f), sx = sd;
+    float4 d[E], xh[NS][E];
+    float4 sd = make_float4(0.f, 0.f, 0.f, 0.f), sx[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) sx[k] = sd;
     if (live) {
-        const float4 mean = *(const float4*)(a.mean[0] + (int64_t)g * a.C + c4 * 4);
-        const float4 istd = *(const float4*)(a.invstd[0] + (int64_t)g * a.C + c4 * 4);
         float4 zz[E];
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -2141,7 +2143,8 @@ __global__ void __launch_bounds__(kBnFusedThreads) bn_bwd_fused_kernel(const BnB
             const bool in = u < units;
             const int64_t uu = in ? u : 0;
             d[e] = dz4[uu];
-            xh[e] = y4[uu];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) xh[k][e] = ((const float4*)a.y[k] + (int64_t)g * units)[uu];
             zz[e] = z4 ? z4[uu] : make_float4(1.f, 1.f, 1.f, 1.f);
             if (!in) d[e] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
@@ -2149,19 +2152,28 @@ __global__ void __launch_bounds__(kBnFusedThreads) bn_bwd_fused_kernel(const BnB
         for (int e = 0; e < E; ++e) {
             d[e].x = zz[e].x > 0.f ? d[e].x : 0.f; d[e].y = zz[e].y > 0.f ? d[e].y : 0.f;
             d[e].z = zz[e].z > 0.f ? d[e].z : 0.f; d[e].w = zz[e].w > 0.f ? d[e].w : 0.f;
-            xh[e].x = (xh[e].x - mean.x) * istd.x; xh[e].y = (xh[e].y - mean.y) * istd.y;
-            xh[e].z = (xh[e].z - mean.z) * istd.z; xh[e].w = (xh[e].w - mean.w) * istd.w;
             sd.x += d[e].x; sd.y += d[e].y; sd.z += d[e].z; sd.w += d[e].w;
-            sx.x = fmaf(d[e].x, xh[e].x, sx.x); sx.y = fmaf(d[e].y, xh[e].y, sx.y);
-            sx.z = fmaf(d[e].z, xh[e].z, sx.z); sx.w = fmaf(d[e].w, xh[e].w, sx.w);
+        }
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            const float4 mean = *(const float4*)(a.mean[k] + (int64_t)g * a.C + c4 * 4);
+            const float4 istd = *(const float4*)(a.invstd[k] + (int64_t)g * a.C + c4 * 4);
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                xh[k][e].x = (xh[k][e].x - mean.x) * istd.x; xh[k][e].y = (xh[k][e].y - mean.y) * istd.y;
+                xh[k][e].z = (xh[k][e].z - mean.z) * istd.z; xh[k][e].w = (xh[k][e].w - mean.w) * istd.w;
+                sx[k].x = fmaf(d[e].x, xh[k][e].x, sx[k].x); sx[k].y = fmaf(d[e].y, xh[k][e].y, sx[k].y);
+                sx[k].z = fmaf(d[e].z, xh[k][e].z, sx[k].z); sx[k].w = fmaf(d[e].w, xh[k][e].w, sx[k].w);
+            }
         }
     }
     red[0][tid] = sd;
-    red[1][tid] = sx;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) red[1 + k][tid] = sx[k];
     __syncthreads();
     // threads of this workgroup with channel quad q: tid = first(q) + k*C4
-    if (g < a.G && tid < 2 * C4) {
-        const int which = tid / C4, q = tid - which * C4;
+    if (g < a.G && tid < (1 + NS) * C4) {
+        const int which = tid / C4, q = tid - which * C4;   // 0: sum d; 1 + k: sum d * xhat of BatchNorm k
         const int base = (blockIdx.x - g * wpg) * kBnFusedThreads;
         int first = (q - base % C4 + C4) % C4;
         double t0 = 0.0, t1 = 0.0, t2 = 0.0, t3 = 0.0;
@@ -2169,12 +2181,18 @@ __global__ void __launch_bounds__(kBnFusedThreads) bn_bwd_fused_kernel(const BnB
             const float4 v = red[which][t];
             t0 += (double)v.x; t1 += (double)v.y; t2 += (double)v.z; t3 += (double)v.w;
         }
-        double* dst = a.fsums + ((int64_t)(blockIdx.x % kBnFusedReps) * a.G * 2 + (int64_t)g * 2 + which) * a.C + q * 4;
+        double r = 0.0;
         // returning atomics: the wave waits for them to have executed (at the device-wide coherence point) before the barrier below
-        double r = __hip_atomic_fetch_add(dst + 0, t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        r += __hip_atomic_fetch_add(dst + 1, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        r += __hip_atomic_fetch_add(dst + 2, t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        r += __hip_atomic_fetch_add(dst + 3, t3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+            if (which != 0 && which != 1 + k) continue;   // the sum of d goes to both arenas, the sum of d * xhat_k to its own
+            double* arena = k == 0 ? a.fsums : a.fsums_b;
+            double* dst = arena + ((int64_t)(blockIdx.x % kBnFusedReps) * a.G * 2 + (int64_t)g * 2 + (which ? 1 : 0)) * a.C + q * 4;
+            r += __hip_atomic_fetch_add(dst + 0, t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            r += __hip_atomic_fetch_add(dst + 1, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            r += __hip_atomic_fetch_add(dst + 2, t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            r += __hip_atomic_fetch_add(dst + 3, t3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (r == 1.2345e300) red[0][0].x = 0.f;   // keeps the returns (never true)
     }
     // ---- grid-wide arrival ---------------------------------------------------------------------------
@@ -2197,45 +2215,52 @@ __global__ void __launch_bounds__(kBnFusedThreads) bn_bwd_fused_kernel(const BnB
     }
     __syncthreads();
     const double Md = (double)M;
-    if (g < a.G && tid < 2 * a.C) {
+    if (g < a.G && tid < (1 + NS) * a.C) {
         const int which = tid / a.C, c = tid - which * a.C;
+        const double* arena = which <= 1 ? a.fsums : a.fsums_b;
         double v = 0.0;
         for (int r = 0; r < kBnFusedReps; ++r)
-            v += __hip_atomic_load(a.fsums + ((int64_t)r * a.G * 2 + (int64_t)g * 2 + which) * a.C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v += __hip_atomic_load(arena + ((int64_t)r * a.G * 2 + (int64_t)g * 2 + (which ? 1 : 0)) * a.C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         kk[which][c] = timed_out ? __builtin_nanf("") : (float)(v / Md);
     }
-    if (blockIdx.x == 0 && tid < a.C) {   // dgamma / dbeta over all groups
+    if (blockIdx.x == 0 && tid < NS * a.C) {   // dgamma / dbeta over all groups
+        const int k = tid / a.C, c = tid - k * a.C;
+        const double* arena = k == 0 ? a.fsums : a.fsums_b;
         double db = 0.0, dg = 0.0;
         for (int gg = 0; gg < a.G; ++gg)
             for (int r = 0; r < kBnFusedReps; ++r) {
-                db += __hip_atomic_load(a.fsums + ((int64_t)r * a.G * 2 + (int64_t)gg * 2 + 0) * a.C + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                dg += __hip_atomic_load(a.fsums + ((int64_t)r * a.G * 2 + (int64_t)gg * 2 + 1) * a.C + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                db += __hip_atomic_load(arena + ((int64_t)r * a.G * 2 + (int64_t)gg * 2 + 0) * a.C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                dg += __hip_atomic_load(arena + ((int64_t)r * a.G * 2 + (int64_t)gg * 2 + 1) * a.C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         if (a.accumulate) {
-            a.dgamma[0][tid] += (float)dg;
-            a.dbeta[0][tid] += (float)db;
+            a.dgamma[k][c] += (float)dg;
+            a.dbeta[k][c] += (float)db;
         } else {
-            a.dgamma[0][tid] = (float)dg;
-            a.dbeta[0][tid] = (float)db;
+            a.dgamma[k][c] = (float)dg;
+            a.dbeta[k][c] = (float)db;
         }
     }
     __syncthreads();
     if (live) {
         const float4 k1 = *(const float4*)&kk[0][c4 * 4];
-        const float4 k2 = *(const float4*)&kk[1][c4 * 4];
-        const float4 gm = *(const float4*)(a.gamma[0] + c4 * 4);
-        const float4 istd = *(const float4*)(a.invstd[0] + (int64_t)g * a.C + c4 * 4);
-        const float4 sc = make_float4(gm.x * istd.x, gm.y * istd.y, gm.z * istd.z, gm.w * istd.w);
 #pragma unroll
-        for (int e = 0; e < E; ++e) {
-            const int64_t u = (int64_t)gt + (int64_t)e * S;
-            if (u < units) {
-                float4 o;
-                o.x = sc.x * (d[e].x - k1.x - xh[e].x * k2.x);
-                o.y = sc.y * (d[e].y - k1.y - xh[e].y * k2.y);
-                o.z = sc.z * (d[e].z - k1.z - xh[e].z * k2.z);
-                o.w = sc.w * (d[e].w - k1.w - xh[e].w * k2.w);
-                o4[u] = o;
+        for (int k = 0; k < NS; ++k) {
+            const float4 k2 = *(const float4*)&kk[1 + k][c4 * 4];
+            const float4 gm = *(const float4*)(a.gamma[k] + c4 * 4);
+            const float4 istd = *(const float4*)(a.invstd[k] + (int64_t)g * a.C + c4 * 4);
+            const float4 sc = make_float4(gm.x * istd.x, gm.y * istd.y, gm.z * istd.z, gm.w * istd.w);
+            float4* o4 = (float4*)a.dy[k] + (int64_t)g * units;
+#pragma unroll
+            for (int e = 0; e < E; ++e) {
+                const int64_t u = (int64_t)gt + (int64_t)e * S;
+                if (u < units) {
+                    float4 o;
+                    o.x = sc.x * (d[e].x - k1.x - xh[k][e].x * k2.x);
+                    o.y = sc.y * (d[e].y - k1.y - xh[k][e].y * k2.y);
+                    o.z = sc.z * (d[e].z - k1.z - xh[k][e].z * k2.z);
+                    o.w = sc.w * (d[e].w - k1.w - xh[k][e].w * k2.w);
+                    o4[u] = o;
+                }
             }
         }
     }
@@ -2255,7 +2280,7 @@ int launch_bn_bwd(const BnBwdArgs& a, hipStream_t s) {
         const char* e = getenv("OCL_BN_FUSED");
         g_bn_fused = e ? atoi(e) : 1;
     }
-    if (g_bn_fused && a.barrier && a.fsums && a.nsets == 1 && a.G <= 2 && a.C <= 160 && g_bn_bwd_phase == 0 && !a.frozen) {
+    if (g_bn_fused && a.barrier && a.fsums && (a.nsets == 1 || a.fsums_b) && a.G <= 2 && a.C <= 160 && g_bn_bwd_phase == 0 && !a.frozen) {
         if (!g_num_cus) {
             int dev = 0;
             hipDeviceProp_t prop;
@@ -2263,22 +2288,34 @@ int launch_bn_bwd(const BnBwdArgs& a, hipStream_t s) {
             OCL_HIP(hipGetDeviceProperties(&prop, dev));
             // residency: the grid never exceeds one workgroup per CU, and every instantiation must be admissible at that rate
             // (checked once against the occupancy query); a time-out at run time is reported through the asynchronous error word
-            int b3 = 0, b6 = 0, b12 = 0;
+            int b3 = 0, b6 = 0, b12 = 0, c3 = 0, c6 = 0;
             OCL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b3, bn_bwd_fused_kernel<3>, kBnFusedThreads, 0));
             OCL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b6, bn_bwd_fused_kernel<6>, kBnFusedThreads, 0));
             OCL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&b12, bn_bwd_fused_kernel<12>, kBnFusedThreads, 0));
-            if (std::min(b3, std::min(b6, b12)) < 1) g_bn_fused = 0;   // cannot be co-resident: two-kernel path
+            OCL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c3, (bn_bwd_fused_kernel<3, 2>), kBnFusedThreads, 0));
+            OCL_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&c6, (bn_bwd_fused_kernel<6, 2>), kBnFusedThreads, 0));
+            if (std::min(std::min(b3, std::min(b6, b12)), std::min(c3, c6)) < 1) g_bn_fused = 0;   // cannot be co-resident: two-kernel path
             g_num_cus = std::max(2, prop.multiProcessorCount);
         }
         // about 6 float4 per thread and tensor; never more workgroups than CUs (all must be resident), fewer for the small maps
         // (the arrival costs grow with the workgroup count, the small maps are latency-bound anyway)
         const int64_t total_units = a.m_per_group * C4 * a.G;
-        int grid = (int)std::min<int64_t>(g_num_cus, std::max<int64_t>(8, (total_units + kBnFusedThreads * 6 - 1) / (kBnFusedThreads * 6)));
+        const int per_thread = a.nsets == 2 ? 5 : 6;   // (two sets keep one more register array per unit: at most 6 units per thread)
+        int grid = (int)std::min<int64_t>(g_num_cus, std::max<int64_t>(8, (total_units + kBnFusedThreads * per_thread - 1) / (kBnFusedThreads * per_thread)));
         grid = std::max(a.G, grid / a.G * a.G);
         const int wpg = grid / a.G;
         const int64_t S = (int64_t)(wpg * kBnFusedThreads / C4) * C4;
         const int64_t need = (a.m_per_group * C4 + S - 1) / S;
-        if (need <= 12) {
+        if (a.nsets == 2 && need <= 6 && g_bn_fused) {   // two BatchNorms sharing dz (projection blocks)
+            ProfScope ps(PROF_BN, s);
+            BnBwdArgs af = a;
+            af.err = async_error_word_device();
+            if (need <= 3) hipLaunchKernelGGL((bn_bwd_fused_kernel<3, 2>), dim3(grid), dim3(kBnFusedThreads), 0, s, af);
+            else hipLaunchKernelGGL((bn_bwd_fused_kernel<6, 2>), dim3(grid), dim3(kBnFusedThreads), 0, s, af);
+            OCL_LAUNCH_CHECK();
+            return OCL_OK;
+        }
+        if (a.nsets == 1 && need <= 12 && g_bn_fused) {
             ProfScope ps(PROF_BN, s);
             BnBwdArgs af = a;
             af.err = async_error_word_device();

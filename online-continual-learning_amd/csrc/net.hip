@@ -848,10 +848,11 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
         }
         // sums are addressed [set][G][2][C] inside conv_a's arena of kGmax*2*C doubles: two sets need 2*G <= kGmax
         a.sums = bsums + n->bns[ca.bn].arena_off;
-        // one-pass kernel (one BatchNorm, <= 2 groups)
-        if (conv_b < 0 && G <= 2) {
+        // one-pass kernel (<= 2 groups; two BatchNorms sharing dz each bring their own accumulator arena)
+        if (G <= 2) {
             a.fsums = bsums + n->bns[ca.bn].fused_off;
             a.barrier = (unsigned*)(a.fsums + (int64_t)8 * 2 * 2 * ca.Cout);
+            if (conv_b >= 0) a.fsums_b = bsums + n->bns[n->convs[conv_b].bn].fused_off;
         }
         if (conv_b >= 0 && 2 * G > kGmax) {
             set_error("bn_bwd: groups=%d too large for a shared reduction arena", G);
