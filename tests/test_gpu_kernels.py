@@ -221,6 +221,28 @@ def test_scr_augment_kernel_properties(cuda):
     assert oc.min() >= 0 and oc.max() <= 1
 
 
+def test_upload_ring_keeps_every_payload(cuda):
+    """ocl_upload: small host arrays through the library's ring of pinned staging slots (128 slots of 64 KB), larger ones by a
+    plain copy.  400 uploads of changing sizes (the ring wraps three times; the host array is overwritten right after each call,
+    which the contract allows) must all arrive intact, on the stream they were issued on."""
+    from ocl_amd import ops
+    rng = np.random.default_rng(21)
+    kept = []
+    for i in range(400):
+        n = int(rng.choice([1, 7, 10, 100, 1000, 16384, 20000]))        # 20000 int64 = 160 KB: past the slot size
+        host = torch.from_numpy(rng.integers(-2**40, 2**40, n))
+        want = host.clone()
+        dev_t = ops.upload(host, cuda)
+        host.zero_()                                                     # the caller may reuse its array immediately
+        kept.append((dev_t, want))
+    torch.cuda.synchronize()
+    for dev_t, want in kept:
+        assert dev_t.is_cuda and torch.equal(dev_t.cpu(), want)
+    f = ops.upload(np.arange(12, dtype=np.float32).reshape(3, 4), cuda)
+    assert f.shape == (3, 4) and f.dtype == torch.float32 and torch.equal(f.cpu(), torch.arange(12.).reshape(3, 4))
+    assert ops.upload(torch.zeros(0, dtype=torch.long), cuda).numel() == 0
+
+
 def test_scr_augment_parameters_on_the_device_match_the_host_statement(cuda):
     """aug_params_kernel (crop attempts, fallback, position, jitter factors from raw uniform draws) against
     ScrAugment.params_from_uniform on the same draws; the fused call equals the two-step call on its own parameters."""
