@@ -147,6 +147,7 @@ static PyObject* py_cbrs_sample(PyObject* self, PyObject* args) {
             }
             if (PySet_GET_SIZE(slots) == 0) continue;
             ClassMemo* memo = NULL;
+            long long memo_version = 0;
             if (memo_ok && PyLong_Check(key)) {
                 const long long label = PyLong_AsLongLong(key);
                 if (label >= 0 && label < MEMO_LABELS && label < n_versions) {
@@ -170,8 +171,7 @@ static PyObject* py_cbrs_sample(PyObject* self, PyObject* args) {
                         for (Py_ssize_t j = 0; j < take; ++j) out[n_out++] = memo->members[perm[j]];
                         continue;
                     }
-                    memo->version = versions[label];
-                    memo->token = token;
+                    memo_version = versions[label];
                 }
             }
             PyObject* eligible = PyNumber_Subtract(slots, excluded);   /* a new set, exactly as `slots - excluded` */
@@ -197,10 +197,12 @@ static PyObject* py_cbrs_sample(PyObject* self, PyObject* args) {
             Py_DECREF(eligible);
             if (memo) {   /* keep the order for the next draw of this (unchanged) class */
                 int64_t* mm = (int64_t*)PyMem_RawRealloc(memo->members, sizeof(int64_t) * (size_t)(n ? n : 1));
-                if (mm) {
+                if (mm) {   /* (version and token are stamped only with a complete entry) */
                     memcpy(mm, members, sizeof(int64_t) * (size_t)n);
                     memo->members = mm;
                     memo->n = n;
+                    memo->version = memo_version;
+                    memo->token = token;
                 } else {
                     PyMem_RawFree(memo->members);
                     memo->members = NULL;
