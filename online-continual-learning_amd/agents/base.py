@@ -12,7 +12,7 @@ import torch
 
 from .. import ops
 from .. import debug
-from ..loss import SupConLoss, cross_entropy_mean, cross_entropy_segmented_mean
+from ..loss import SupConLoss, cross_entropy_mean, cross_entropy_segmented_mean, unit_gradient
 from ..kd_manager import KdManager
 from ..utils import maybe_cuda, AverageMeter
 
@@ -88,7 +88,7 @@ class ContinualLearner(torch.nn.Module, metaclass=abc.ABCMeta):
                         if debug.on():
                             debug.emit("review", indices=idx.cpu().numpy().copy(), loss=float(loss.detach()))
                         self.opt.zero_grad()
-                        loss.backward()
+                        loss.backward(unit_gradient(loss))
                         self._step_scaled(0.1)   # grads / 10 (base.py:84-87)
         if self.params.trick['kd_trick'] or self.params.agent == 'LWF':   # base.py:90-91 (kd_trick_star alone never gets a teacher)
             self.kd_manager.update_teacher(self.model)

@@ -17,6 +17,7 @@ from .. import debug
 from ..buffer import Buffer
 from ..data import DeviceLoader
 from ..utils import maybe_cuda, AverageMeter
+from ..loss import unit_gradient
 from .base import ContinualLearner
 
 
@@ -66,7 +67,8 @@ class ExperienceReplay(ContinualLearner):
         self._emit("er_loss", loss)
         self._emit("er_loss_mem", loss_mem)
         self.opt.zero_grad()
-        (loss + loss_mem).backward()
+        total = loss + loss_mem
+        total.backward(unit_gradient(total))
         self.opt.step()
 
     def _two_pass_step(self, batch_x, batch_y, batch_y_host, meters, aser, retrieved=None, logits=None):
@@ -77,7 +79,7 @@ class ExperienceReplay(ContinualLearner):
         self._emit("er_loss", loss)
         self.opt.zero_grad()
         if not aser or self.params.retrieve == 'MIR':   # ASER mode discards this gradient; MIR reads it
-            loss.backward()
+            loss.backward(unit_gradient(loss))
 
         mem_x, mem_y = retrieved if retrieved is not None else self.buffer.retrieve(x=batch_x, y=batch_y)
         if mem_x.size(0) > 0:
@@ -87,7 +89,7 @@ class ExperienceReplay(ContinualLearner):
             self._track(meters[1], mem_logits, mem_y, loss_mem)
             self._emit("er_loss_mem", loss_mem)
             if not aser:
-                loss_mem.backward()
+                loss_mem.backward(unit_gradient(loss_mem))
 
         if aser:
             # exp_replay.py:76-84: the update comes from one more pass over memory + batch; passes 1 and 2 only leave their
@@ -99,7 +101,7 @@ class ExperienceReplay(ContinualLearner):
                 combined_labels.host = np.concatenate((np.asarray(mem_y.host), np.asarray(batch_y_host)))
             loss_combined = self.criterion(self.model.forward(combined_batch), combined_labels)
             self._emit("er_loss_combined", loss_combined)
-            loss_combined.backward()
+            loss_combined.backward(unit_gradient(loss_combined))
         self.opt.step()
 
     # ---- the loop ------------------------------------------------------------------------------------------------------

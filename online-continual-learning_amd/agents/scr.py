@@ -15,6 +15,7 @@ from ..buffer import Buffer
 from ..data import DeviceLoader
 from ..setup_elements import input_size_match
 from ..utils import maybe_cuda, AverageMeter
+from ..loss import unit_gradient
 from .base import ContinualLearner
 
 
@@ -176,7 +177,7 @@ class SupContrastReplay(ContinualLearner):
                         if debug.on():
                             debug.emit("scr_loss", loss=float(loss.detach()))
                         self.opt.zero_grad()
-                        loss.backward()
+                        loss.backward(unit_gradient(loss))
                         self.opt.step()
 
                 # update mem

@@ -5,6 +5,27 @@ import torch.nn as nn
 from . import ops
 
 
+# loss.backward() seeds the graph with a freshly filled tensor of ones and every loss node multiplies its saved gradient by it: two
+# tiny launches per step that change nothing.  The agents pass `unit_gradient(loss)` (one cached scalar 1.0 per device) as the
+# seed instead; a node that receives exactly that tensor returns its saved gradient as it is.
+_UNIT = {}
+
+
+def unit_gradient(loss):
+    key = (loss.device, loss.dtype)
+    one = _UNIT.get(key)
+    if one is None:
+        one = _UNIT[key] = torch.ones((), device=loss.device, dtype=loss.dtype)
+    return one
+
+
+def _scaled(saved, g):
+    one = _UNIT.get((g.device, g.dtype))
+    if one is not None and g.dim() == 0 and g.data_ptr() == one.data_ptr():
+        return saved
+    return saved * g
+
+
 class _CEFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, labels):
@@ -15,7 +36,7 @@ class _CEFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dl,) = ctx.saved_tensors
-        return dl * g, None
+        return _scaled(dl, g), None
 
 
 def cross_entropy_mean(logits, labels):
@@ -33,7 +54,7 @@ class _CESegFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dl,) = ctx.saved_tensors
-        return dl * g, None, None
+        return _scaled(dl, g), None, None
 
 
 def cross_entropy_segmented_mean(logits, labels, seg):
@@ -52,7 +73,7 @@ class _KDFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (ds,) = ctx.saved_tensors
-        return ds * g, None, None
+        return _scaled(ds, g), None, None
 
 
 def loss_fn_kd(scores, target_scores, T=2.):
@@ -70,7 +91,7 @@ class _SupConFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (df,) = ctx.saved_tensors
-        return df * g, None, None, None
+        return _scaled(df, g), None, None, None
 
 
 class SupConLoss(nn.Module):
