@@ -21,7 +21,6 @@ enum ConvEpi : int {
 
 struct ConvArgs {
     const float* in;
-    const float* w;       // packed [tap][Cin][WP]
     float* out;
     const float* scale;
     const float* shift;
@@ -31,26 +30,20 @@ struct ConvArgs {
     int64_t stat_rep_stride;
     int N, Hin, Win, Cin;
     int Hout, Wout, Cout;
-    int CoutP;                  // n_splits * 16*NT (columns the grid covers)
-    int WP;                     // row stride of the weight pack (multiple of 16, >= Cout)
+    int CoutP;                  // n_splits * 16*MT (channels the grid covers)
     int LH, LW, os, oy0, ox0;   // output lattice: (oy,ox) = (ly*os+oy0, lx*os+ox0)
     int is;                     // input step per lattice step
     int ntaps;
     int tdy[9], tdx[9], tw[9];  // input offset of each tap and its index in the weight pack
     int tpo[9];                 // LDS patch offset of each tap (floats)
     int d_c4, d_pc, d_row;      // patch-staging walk: 256 units = d_row rows + d_pc pixels + d_c4 float4s
-    float inv_PR;
     int min_dy, min_dx, max_dy, max_dx;
     int KC, CP, PC, PR;         // channels per LDS chunk, LDS pixel stride, patch cols, patch rows
     int ppi, imgs, tiles_per_img;
     int groups, group_size, tiles_per_group;
-    int BNP;                    // LDS weight row stride (floats)
-    int wreg;                   // 1: register-resident weights variant (conv_gemm_kernel<32,1,1,PF,true>)
-    int KU;                     // k-steps issued per unrolled group (5 when KC/4 is a multiple of 5)
-    int TG, gpc, WS;            // taps per weight stage, stages per channel chunk, floats per stage buffer
     int flags;
     int n_splits;               // grid.y
-    // ---- conv_t_kernel (channels x pixels orientation, K-contiguous operands; plan.kind == 1) --------------------------
+    // ---- channels x pixels orientation, K-contiguous operands --------------------------------------------------------
     const float* wT;            // K-grouped weight pack [tap][Cin/4][WPT][4]
     int C4tot, WPT;             // Cin/4 of the whole convolution; row stride (channels) of the pack
     int Qc, Qpad;               // (tap, channel-quad) groups of one channel chunk; rounded up to whole rounds of 4
@@ -66,8 +59,7 @@ struct ConvArgs {
 
 struct ConvPlan {
     ConvArgs a;
-    int kind;                   // 0: conv_gemm_kernel (pixels x channels tiles), 1: conv_t_kernel (channels x pixels, K-grouped operands)
-    int W, MT, NT;              // MFMA tile width (16: 16x16x4, 32: 32x32x2) and tiles per wave (kind 1: MT channel tiles, NT pixel tiles)
+    int MT, NT;                 // 16-channel tiles and 16-pixel tiles per wave (conv_t_kernel<MT, NT, ...>)
     int grid_x, grid_y;
     size_t lds_bytes;
 };
@@ -80,12 +72,9 @@ struct ConvGeomDesc {
     int LH, LW, os, oy0, ox0, is;
     int ntaps;
     int tdy[9], tdx[9], tw[9];
-    int WP;                     // weight pack row stride (0: the plan's own CoutP)
-    int no_wreg;                // benchmarks: disable the register-resident-weights variant
-    int force_W, force_MT, force_NT, force_bpc;   // 0 = planner's choice (benchmarks / tests)
-    int force_kind;             // 0 = planner's choice, 1 = conv_gemm_kernel, 2 = conv_t_kernel
-    int WPT;                    // row stride of the K-grouped pack (0: the plan's own CoutP)
-    int ncls;                   // > 1: output classes of one launch (conv_t_kernel only), taps listed class by class
+    int force_MT, force_NT, force_bpc;   // 0 = planner's choice (benchmarks / tests)
+    int WPT;                    // row stride of the K-grouped weight pack (0: the plan's own CoutP)
+    int ncls;                   // > 1: output classes of one launch, taps listed class by class
     int cls_ntaps[4], cls_oy[4], cls_ox[4];
 };
 
@@ -153,19 +142,15 @@ void wgrad_reduce_layer(const WgradPlan& p, int64_t partial_off, int64_t grad_of
 int launch_wgrad_reduce_multi(WgradReduceMulti m, hipStream_t s);
 
 // ---- weight packing -----------------------------------------------------------------------------------
-// fwd pack:   wf[t][ci][coP] = w[co][ci][t]          (ci padded with zero rows up to CinP)
-// dgrad pack: wd[t][co][ciP] = w[co][ci][t]
-// K-grouped packs (conv_t_kernel):
-// fwd:   wTf[t][ci/4][coP][ci%4] = w[co][ci][t]      dgrad: wTd[t][co/4][ciP][co%4] = w[co][ci][t]
+// K-grouped packs (the A operand of conv_t_kernel: 4 consecutive input channels of a (tap, channel quad) group contiguous):
+// fwd:   wTf[t][ci/4][coP][ci%4] = w[co][ci][t]  (ci padded with zero quads up to CinP)      dgrad: wTd[t][co/4][ciP][co%4] = w[co][ci][t]
 struct PackDesc {
     int64_t w_off;      // offset of the OIHW tensor in the flat parameter array
-    int64_t f_off;      // offset in the pack arena (fwd), -1 = none
-    int64_t d_off;      // offset in the pack arena (dgrad), -1 = none
-    int64_t tf_off;     // K-grouped fwd pack, -1 = none
-    int64_t td_off;     // K-grouped dgrad pack, -1 = none
+    int64_t tf_off;     // fwd pack in the arena, -1 = none
+    int64_t td_off;     // data-gradient pack, -1 = none
     int Cout, Cin, ntaps, CinP, CoutP, CiP;
 };
-enum { PACK_F = 1, PACK_D = 2, PACK_TF = 4, PACK_TD = 8, PACK_ALL = 15 };   // which packs a launch writes
+enum { PACK_TF = 1, PACK_TD = 2, PACK_ALL = 3 };   // which packs a launch writes
 // zero_a / zero_b: two arrays of doubles cleared by the same launch (the BatchNorm statistics arenas of the pass), may be null / 0
 int launch_pack_weights(const float* params, float* arena, const PackDesc* descs_dev, int n_layers, int max_elems,
                         hipStream_t s, int mask = PACK_ALL, double* zero_a = nullptr, int64_t zero_a_n = 0, double* zero_b = nullptr,

@@ -1,11 +1,11 @@
 // K1-K4: Reduced-ResNet18 convolution / batch-norm kernels for gfx950.
 //
-//  conv_gemm_kernel   implicit-GEMM 3x3 / 1x1 convolution on exact-fp32 MFMA (v_mfma_f32_16x16x4_f32).
-//                     One generic "tap list + output lattice" geometry covers forward (stride 1/2), data
-//                     gradient (stride 1, and stride 2 as four dense parity classes) and the 1x1 shortcut.
-//                     The input patch (with halo) of a 64/128-pixel tile is staged ONCE in LDS and reused by
-//                     all taps; weights stream through LDS per (tap, channel chunk).  Epilogues: BN batch
-//                     statistics (fp64 atomics), folded eval-mode BN, residual, ReLU, masked residual.
+//  conv_t_kernel      implicit-GEMM 3x3 / 1x1 convolution on exact-fp32 MFMA (v_mfma_f32_16x16x4_f32), D[channel][pixel] tiles with
+//                     K-grouped operands.  One generic "tap list + output lattice" geometry covers forward (stride 1/2), data
+//                     gradient (stride 1; stride 2 as four parity classes, in one launch where the lattices coincide) and the
+//                     1x1 shortcut.  The input patch (with halo) of a 64/128-pixel tile is staged ONCE in LDS and reused by
+//                     all taps; weights are resident in LDS or stream through a double-buffered stage.  Epilogues from
+//                     registers: BN batch statistics (fp64 atomics), folded eval-mode BN, residual, ReLU, masked residual.
 //  conv_wgrad_kernel  weight gradient as a (tap,ci) x co GEMM reduced over pixels, split-K over pixel tiles,
 //                     partials summed by wgrad_reduce_kernel straight into PyTorch's OIHW gradient.
 //  bn_*               train-mode BatchNorm forward (normalise+residual+ReLU, running-stat update) and backward.
@@ -20,16 +20,11 @@
 namespace ocl {
 
 static const size_t kLdsLimit = 160 * 1024;      // hardware: 160 KiB per workgroup
-static const size_t kLdsTarget = 72 * 1024;      // planner target (2 workgroups per CU)
+static const size_t kLdsTarget = 72 * 1024;      // weight-gradient planner target (2 workgroups per CU)
 
 // =====================================================================================================
-// implicit-GEMM convolution
+// helpers shared by the convolution and the weight-gradient kernels
 // =====================================================================================================
-// Block = 4 waves stacked along M (64*MT output pixels) x 16*NT output channels.  K runs over (channel chunk, tap).
-// The input patch of a chunk is staged once and shared by all taps; weights stream through a DOUBLE-BUFFERED LDS
-// stage of TG taps: the global loads of stage s+1 are issued before the MFMAs of stage s and land in registers
-// while they run, so the only exposed global latency is the first stage's (one __syncthreads per stage).
-// LDS banking (ds_read_b32: 32 banks, two 32-lane halves): A reads want CP = 2 (mod 4), B reads BNP = 16 (mod 32).
 // exact u / d for 0 <= u < 2^22 with a precomputed float reciprocal (one correction step either way)
 __device__ __forceinline__ int fdiv(int u, int d, float inv, int& rem) {
     int q = (int)((float)u * inv);
@@ -52,8 +47,6 @@ __device__ __forceinline__ float4 buf_load16(__amdgpu_buffer_rsrc_t r, int byte_
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
 
-constexpr int kMaxStageFloats = 4096;   // 16 KiB per weight stage buffer -> <= 4 float4 prefetch registers per thread
-
 // value of a small per-tap table at a block-uniform index, without dynamic indexing of the kernel-argument struct
 // (which would spill it to scratch): a 9-way select chain on scalars.
 __device__ __forceinline__ int tap_sel(const int (&tab)[9], int t) {
@@ -63,419 +56,8 @@ __device__ __forceinline__ int tap_sel(const int (&tab)[9], int t) {
     return v;
 }
 
-// Persistent implicit-GEMM block: walks output tiles blockIdx.x, blockIdx.x + gridDim.x, ... of its channel split.
-// Software pipeline (all global latency except the very first patch hidden behind MFMAs):
-//   patch stage  = (tile, channel chunk): the input patch is fetched into REGISTERS one patch stage ahead and written
-//                  to LDS after the consumers of the previous patch have passed a barrier;
-//   weight stage = TG taps of a chunk: double-buffered in LDS, fetched into registers one weight stage ahead.
-constexpr int kPatchPF = 8;     // max float4 patch-prefetch registers per thread of the wgrad kernels
-constexpr int kConvPatchPF = 8;  // ... of the conv kernels (planner: patch units <= 256*kConvPatchPF)
-
-struct TileGeom {
-    int grp, img0, p0, ly0, nrows, grp_end;
-};
-
-// W = 16: v_mfma_f32_16x16x4_f32 (wave tile 16*MT x 16*NT, 4 channels per MFMA);
-// W = 32: v_mfma_f32_32x32x2_f32 (wave tile 32*MT x 32*NT, 2 channels per MFMA).  On MI355X the 32x32x2 form issues at
-// its nominal 64 cycles (146-155 TF/s in kbench's register-only stream) while 16x16x4 sustains only ~40-50 cycles per
-// instruction instead of 32 (99-134 TF/s): profiles/r1_mfma_peak_calibration.txt.  W = 32 is used wherever the output
-// channel count pads well to 32 and there are enough pixels for 128-row tiles.
-// WREG (only <32,1,1>: 3x3 stride-1 convolutions of the 20-channel layers, one channel chunk of 20): every weight the lane
-// ever multiplies by (9 taps x 5 channel groups x 2 = 90 values of B[k][lane & 31]) lives in registers for the lifetime of the
-// persistent workgroup: no weight stages, no B reads, two barriers less per tile, and the 90-MFMA tap loop is straight-line.
-template <int W, int MT, int NT, int PF, bool WREG = false>   // PF: float4 patch-prefetch registers per thread
-__global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    constexpr int BM = 4 * W * MT;
-    constexpr int BN = W * NT;
-    constexpr int NR = W == 16 ? 4 : 16;            // accumulator registers per MFMA tile
-    typedef float accv __attribute__((ext_vector_type(NR)));
-    constexpr int Q = BN / 4;                       // float4 per weight row
-    constexpr int CS = BN + 4;                      // row stride of the epilogue tile: 4*CS = 16 (mod 32) -> conflict-free
-    int* tapw = (int*)lds_raw;                      // [16] weight-pack index of each tap
-    int* rowoff = tapw + 16;                        // [BM]
-    float* wl = (float*)(rowoff + BM);              // [2][WS] weight stages
-    float* patch = wl + 2 * a.WS;                   // [imgs][PR][PC][CP]
-    float* ct = wl;                                 // epilogue alias: output tile [BM][CS] (+ fp64 stat scratch)
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r16 = lane & (W - 1), g = lane / W;   // row/column inside the MFMA tile, k slot (0..3 / 0..1)
-    const int n0 = blockIdx.y * BN;
-    const int LP = a.LH * a.LW;
-    const int ntiles = a.groups * a.tiles_per_group;
-    if ((int)blockIdx.x >= ntiles) return;
-    if (tid < 9) tapw[tid] = tap_sel(a.tw, tid);
-    __syncthreads();
-    float breg[WREG ? 9 : 1][WREG ? 5 : 1][2];
-    if constexpr (WREG) {
-        const int col = n0 + r16;                       // this lane's output channel (the pack is zero beyond Cout)
-        const bool colok = col < a.WP;
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int gq = 0; gq < 5; ++gq)
-#pragma unroll
-                for (int e = 0; e < 2; ++e) {
-                    const int c = 4 * gq + 2 * g + e;   // lane half g multiplies channels 2g, 2g+1 of each group of 4
-                    breg[t][gq][e] = colok ? a.w[((int64_t)a.tw[t] * a.Cin + c) * a.WP + col] : 0.f;
-                }
-    }
-
-    // tile -> (group, first image, first lattice pixel, ...): divisions by block-uniform plan constants through float
-    // reciprocals (a 32-bit integer division costs ~40 instructions and this runs twice per tile)
-    const float inv_tpg = 1.0f / (float)a.tiles_per_group, inv_tpi = 1.0f / (float)a.tiles_per_img, inv_lw0 = 1.0f / (float)a.LW;
-    auto geom = [&](int tile) __attribute__((always_inline)) -> TileGeom {
-        TileGeom t;
-        int tg_, tp, rem;
-        t.grp = fdiv(tile, a.tiles_per_group, inv_tpg, tg_);
-        const int ti = fdiv(tg_, a.tiles_per_img, inv_tpi, tp);
-        t.img0 = t.grp * a.group_size + ti * a.imgs;
-        t.p0 = tp * a.ppi;
-        t.grp_end = min(a.N, (t.grp + 1) * a.group_size);
-        t.ly0 = fdiv(t.p0, a.LW, inv_lw0, rem);
-        const int pend = min(t.p0 + a.ppi, LP);
-        const int ly1 = fdiv(pend - 1, a.LW, inv_lw0, rem);
-        // patch rows to stage: one image's used rows, or (imgs > 1: whole images of PR rows) the images inside the group
-        t.nrows = a.imgs > 1 ? min(a.imgs, t.grp_end - t.img0) * a.PR : (ly1 - t.ly0) * a.is + (a.max_dy - a.min_dy) + 1;
-        return t;
-    };
-
-    // ---- patch prefetch bookkeeping: this thread's units tid + i*256 of the flat [row][pc][c4] space are the same for
-    // every tile; their (il, pr, pc, c4) coordinates are packed into one register each.
-    const int kc4 = a.KC >> 2;
-    int pu_pos[PF];   // il << 24 | pr << 16 | pc << 8 | c4   (planner: il < 128, pr/pc < 256, c4 < 256)
-    {
-        int c4, pc;
-        const int pix = fdiv(tid, kc4, 1.0f / (float)kc4, c4);
-        int row = fdiv(pix, a.PC, 1.0f / (float)a.PC, pc);
-#pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            int il = 0, pr = row;
-            if (a.imgs > 1) il = fdiv(row, a.PR, a.inv_PR, pr);
-            pu_pos[i] = (il << 24) | (pr << 16) | (pc << 8) | c4;
-            if (il >= 128 || pr >= 256) pu_pos[i] = 0x7fff0000;   // past any tile's last row
-            c4 += a.d_c4;                                   // advance by 256 units
-            pc += a.d_pc;
-            if (c4 >= kc4) { c4 -= kc4; pc += 1; }
-            row += a.d_row;
-            if (pc >= a.PC) { pc -= a.PC; row += 1; }
-        }
-    }
-    float4 pv[PF];
-    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in), rs_w = make_rsrc(a.w);
-    auto load_patch = [&](const TileGeom& t, int c0) __attribute__((always_inline)) {
-        const int iy0 = t.ly0 * a.is + a.min_dy;
-        const int base = (((t.img0 * a.Hin + iy0) * a.Win + a.min_dx) * a.Cin + c0) * 4;   // bytes; may be negative (halo)
-#pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            const int il = pu_pos[i] >> 24, pr = (pu_pos[i] >> 16) & 255, pc = (pu_pos[i] >> 8) & 255, c4 = pu_pos[i] & 255;
-            const int iy = iy0 + pr, ix = a.min_dx + pc;
-            const bool ok = (il * a.PR + pr < t.nrows) & (iy >= 0) & (iy < a.Hin) & (ix >= 0) & (ix < a.Win);   // no short-circuit branches
-            pv[i] = buf_load16(rs_in, ok ? base + (((il * a.Hin + pr) * a.Win + pc) * a.Cin + c4 * 4) * 4 : kOob);
-        }
-    };
-    auto store_patch = [&](const TileGeom& t) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            const int il = pu_pos[i] >> 24, pr = (pu_pos[i] >> 16) & 255, pc = (pu_pos[i] >> 8) & 255, c4 = pu_pos[i] & 255;
-            const int row = il * a.PR + pr;
-            if (row < t.nrows) {
-                float* d = patch + (row * a.PC + pc) * a.CP + c4 * 4;  // 8-B aligned (CP even)
-                *(float2*)d = make_float2(pv[i].x, pv[i].y);
-                *(float2*)(d + 2) = make_float2(pv[i].z, pv[i].w);
-            }
-        }
-    };
-
-    // the first tile's patch is requested before anything else: its latency overlaps the rest of the set-up
-    TileGeom cur = geom(blockIdx.x);
-    load_patch(cur, 0);
-
-    // ---- weight-stage prefetch bookkeeping: unit u = tid + q*256 -> (tap-in-group, kc, float4 column) -------------
-    const int rows_full = a.TG * a.KC;              // weight rows of a full stage
-    int pf_tg[4], pf_src[4], pf_dst[4];
-    {
-        const float inv_q = 1.0f / (float)Q, inv_kc = 1.0f / (float)a.KC;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int u = tid + q * 256;
-            int q4, kc;
-            const int row = fdiv(u, Q, inv_q, q4);
-            const int tgi = fdiv(row, a.KC, inv_kc, kc);
-            pf_tg[q] = (row < rows_full && n0 + q4 * 4 < a.WP) ? tgi : -1;   // columns past the pack's row stride: never stored
-            pf_src[q] = kc * a.WP + q4 * 4;
-            pf_dst[q] = row * a.BNP + q4 * 4;
-        }
-    }
-    // The four prefetch registers are named variables (not an array): with the nested select chain the array form is
-    // left in scratch memory by the compiler, which serialises every load behind an s_waitcnt.
-    float4 pf0, pf1, pf2, pf3;
-#define OCL_PF_LOAD(Q, REG)                                                                               \
-    {                                                                                                     \
-        const int t = t0_ + pf_tg[Q];                                                                     \
-        const bool ok = (pf_tg[Q] >= 0) & (t < a.ntaps);                                                  \
-        const int wt = tapw[ok ? t : 0];                                                                  \
-        REG = buf_load16(rs_w, ok ? ((wt * a.Cin + c0_) * a.WP + n0 + pf_src[Q]) * 4 : kOob);             \
-    }
-#define OCL_PF_STORE(Q, REG)                                                           \
-    {                                                                                  \
-        const int t = t0_ + pf_tg[Q];                                                  \
-        if (pf_tg[Q] >= 0 && t < a.ntaps) *(float4*)(dst_ + pf_dst[Q]) = REG;          \
-    }
-    auto prefetch = [&](int t0_, int c0_) __attribute__((always_inline)) {
-        OCL_PF_LOAD(0, pf0) OCL_PF_LOAD(1, pf1) OCL_PF_LOAD(2, pf2) OCL_PF_LOAD(3, pf3)
-    };
-    auto commit = [&](int t0_, int buf) __attribute__((always_inline)) {
-        float* dst_ = wl + buf * a.WS;
-        OCL_PF_STORE(0, pf0) OCL_PF_STORE(1, pf1) OCL_PF_STORE(2, pf2) OCL_PF_STORE(3, pf3)
-    };
-#undef OCL_PF_LOAD
-#undef OCL_PF_STORE
-
-    const float inv_ppi = 1.0f / (float)a.ppi, inv_lw = 1.0f / (float)a.LW;
-    const int bbase = (W == 16 ? g : 2 * g) * a.BNP + r16;
-    const int nchunks = a.Cin / a.KC;
-    const int flags = a.flags;
-    double run1 = 0.0, run2 = 0.0;   // threads < BN: running BatchNorm sums of channel n0+tid over this block's tiles
-    int run_grp = -1;
-    auto flush_stats = [&]() __attribute__((always_inline)) {
-        if (tid < BN && run_grp >= 0) {
-            const int co = n0 + tid;
-            if (co < a.Cout) {
-                // kStatReps replicas of the accumulators spread the same-address atomics (they serialise at the L2)
-                double* st_ = a.stats + (int64_t)(blockIdx.x % kStatReps) * a.stat_rep_stride;
-                atomicAdd(&st_[((int64_t)run_grp * 2 + 0) * a.Cout + co], run1);
-                atomicAdd(&st_[((int64_t)run_grp * 2 + 1) * a.Cout + co], run2);
-            }
-        }
-        run1 = run2 = 0.0;
-    };
-
-    int st = 0;
-    if constexpr (!WREG) prefetch(0, 0);
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int next_tile = tile + gridDim.x;
-        TileGeom nxt = cur;
-        if (next_tile < ntiles) nxt = geom(next_tile);
-
-        // per-row decode: LDS patch offset of the pixel's origin and output element offset
-        auto decode = [&](int r, int& poff, int& ooff) __attribute__((always_inline)) -> bool {
-            int pl, lx;
-            const int il = fdiv(r, a.ppi, inv_ppi, pl);
-            const int p = cur.p0 + pl;
-            const int n = cur.img0 + il;
-            const bool v = (il < a.imgs) & (n < cur.grp_end) & (p < LP);
-            const int ly = fdiv(p, a.LW, inv_lw, lx);
-            poff = v ? ((il * a.PR + (ly - cur.ly0) * a.is) * a.PC + lx * a.is) * a.CP : 0;
-            ooff = ((n * a.Hout + ly * a.os + a.oy0) * a.Wout + lx * a.os + a.ox0) * a.Cout;
-            return v;
-        };
-        int abase[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            int po, oo;
-            decode(wave * W * MT + mt * W + r16, po, oo);
-            abase[mt] = po + (W == 16 ? g : 2 * g);   // W = 32: lane half g owns channels {2g, 2g+1} of each group of 4
-        }
-        accv acc[MT][NT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int r = 0; r < NR; ++r) acc[mt][nt][r] = 0.f;
-
-        for (int chunk = 0; chunk < nchunks; ++chunk) {
-            const int c0 = chunk * a.KC;
-            __syncthreads();  // consumers of the previous patch / of the previous tile's epilogue tile are done
-            if (chunk == 0 && tid < BM) {
-                int po, oo;
-                const bool v = decode(tid, po, oo);
-                rowoff[tid] = v ? oo : -1;
-            }
-            store_patch(cur);
-            // next patch stage: next chunk of this tile, or the first chunk of this block's next tile
-            if (chunk + 1 < nchunks) load_patch(cur, c0 + a.KC);
-            else if (next_tile < ntiles) load_patch(nxt, 0);
-            auto mfma_taps = [&](const float* wbase, int t0, int tcnt) __attribute__((always_inline)) {
-                for (int tt = 0; tt < tcnt; ++tt) {
-                    const float* pa = patch + tap_sel(a.tpo, t0 + tt);
-                    const float* pb = wbase + tt * a.KC * a.BNP;
-                    // one group = 4 input channels: W = 16 one MFMA (k = lane>>4), W = 32 two MFMAs (lane half g
-                    // multiplies channels 2g then 2g+1; the A pair is one 8-byte LDS read, conflict-free for CP = 2 mod 4)
-                    auto kgroups = [&](int s, auto UC) __attribute__((always_inline)) {
-                        constexpr int U = decltype(UC)::value;
-                        if constexpr (W == 16) {
-                            float av[U][MT], bv[U][NT];
-#pragma unroll
-                            for (int u = 0; u < U; ++u) {
-#pragma unroll
-                                for (int mt = 0; mt < MT; ++mt) av[u][mt] = pa[abase[mt] + s + 4 * u];
-#pragma unroll
-                                for (int nt = 0; nt < NT; ++nt) bv[u][nt] = pb[(s + 4 * u) * a.BNP + nt * 16];
-                            }
-#pragma unroll
-                            for (int u = 0; u < U; ++u)
-#pragma unroll
-                                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                                    for (int nt = 0; nt < NT; ++nt)
-                                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][mt], bv[u][nt], acc[mt][nt], 0, 0, 0);
-                        } else {
-                            float2 av[U][MT];
-                            float bv[U][NT][2];
-#pragma unroll
-                            for (int u = 0; u < U; ++u) {
-#pragma unroll
-                                for (int mt = 0; mt < MT; ++mt) av[u][mt] = *(const float2*)(pa + abase[mt] + s + 4 * u);
-#pragma unroll
-                                for (int nt = 0; nt < NT; ++nt) {
-                                    bv[u][nt][0] = pb[(s + 4 * u) * a.BNP + nt * 32];
-                                    bv[u][nt][1] = pb[(s + 4 * u + 1) * a.BNP + nt * 32];
-                                }
-                            }
-#pragma unroll
-                            for (int u = 0; u < U; ++u)
-#pragma unroll
-                                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                                    for (int nt = 0; nt < NT; ++nt) {
-                                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][mt].x, bv[u][nt][0], acc[mt][nt], 0, 0, 0);
-                                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][mt].y, bv[u][nt][1], acc[mt][nt], 0, 0, 0);
-                                    }
-                        }
-                    };
-                    // 16x16x4: five k-groups in flight, then the remainder one at a time (main + remainder loops in sequence, not an
-                    // if / else on the trip count: the two arms of a branch got their accumulators in different registers and 24
-                    // v_accvgpr_mov + MFMA-hazard nops per tap to reconcile them); 32x32x2 (64-cycle MFMAs): one group is enough.
-                    // (Reading the LDS operands of group q+1 ahead of the MFMAs of group q by hand was measured too: +6 % on
-                    // layer 3, nothing elsewhere -- two waves per SIMD already cover that latency.)
-                    int s = 0;
-                    if constexpr (W == 16)
-                        for (; s + 20 <= a.KC; s += 20) kgroups(s, std::integral_constant<int, 5>());
-                    for (; s < a.KC; s += 4) kgroups(s, std::integral_constant<int, 1>());
-                }
-            };
-            if constexpr (WREG) {
-                __syncthreads();      // patch visible
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const float* pa = patch + a.tpo[t];
-#pragma unroll
-                    for (int gq = 0; gq < 5; ++gq) {
-                        const float2 av = *(const float2*)(pa + abase[0] + 4 * gq);
-                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, breg[t][gq][0], acc[0][0], 0, 0, 0);
-                        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, breg[t][gq][1], acc[0][0], 0, 0, 0);
-                    }
-                }
-            } else
-            for (int t0 = 0; t0 < a.ntaps; t0 += a.TG, ++st) {
-                commit(t0, st & 1);
-                __syncthreads();      // stage st's weights (and the patch) visible; everyone is done with stage st-1
-                {   // prefetch the next weight stage (next tap group, next chunk, or the next tile's first)
-                    int nt0 = t0 + a.TG, nc0 = c0;
-                    if (nt0 >= a.ntaps) { nt0 = 0; nc0 = c0 + a.KC; }
-                    if (nc0 >= a.Cin) nc0 = next_tile < ntiles ? 0 : -1;
-                    if (nc0 >= 0) prefetch(nt0, nc0);
-                }
-                mfma_taps(wl + (st & 1) * a.WS + bbase, t0, min(a.TG, a.ntaps - t0));
-            }
-        }
-
-        // ---- epilogue ---------------------------------------------------------------------------------------------------
-        // D layout: col = lane&15, row = (lane>>4)*4 + reg.  BatchNorm statistics from the registers (fp32 partials over
-        // a lane's <= 16 rows, fp64 from there on), then the tile goes through LDS so that global traffic is 16-B
-        // vectors along the channel axis, with the affine / residual / ReLU epilogues applied in that pass.
-        __syncthreads();  // weight stages and patch are dead: `ct` aliases them
-        float s1[NT], s2[NT];
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) s1[nt] = s2[nt] = 0.f;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int reg = 0; reg < NR; ++reg) {
-                // D layout: column = lane % W; row = 4*(lane / W) + reg (16x16), 8*(reg/4) + 4*(lane / 32) + reg%4 (32x32)
-                const int row = wave * W * MT + mt * W + (W == 16 ? g * 4 + reg : (reg >> 2) * 8 + g * 4 + (reg & 3));
-                const bool valid = rowoff[row] >= 0;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const float v = acc[mt][nt][reg];
-                    ct[row * CS + nt * W + r16] = v;
-                    if (valid) {
-                        s1[nt] += v;
-                        s2[nt] = fmaf(v, v, s2[nt]);
-                    }
-                }
-            }
-        if (flags & EPI_STATS) {
-            double* red = (double*)(ct + BM * CS);   // [4 waves][2][BN] doubles, after the tile
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                double x = (double)s1[nt], y = (double)s2[nt];
-                if (W == 16) {
-                    x += __shfl_xor(x, 16, 64);
-                    y += __shfl_xor(y, 16, 64);
-                }
-                x += __shfl_xor(x, 32, 64);
-                y += __shfl_xor(y, 32, 64);
-                if (g == 0) {
-                    red[(wave * 2 + 0) * BN + nt * W + r16] = x;
-                    red[(wave * 2 + 1) * BN + nt * W + r16] = y;
-                }
-            }
-        }
-        __syncthreads();
-        if (flags & EPI_STATS) {
-            if (cur.grp != run_grp) {   // block-uniform: a block's tiles are visited in ascending group order
-                flush_stats();
-                run_grp = cur.grp;
-            }
-            if (tid < BN) {
-                const double* red = (const double*)(ct + BM * CS);
-                run1 += red[0 * BN + tid] + red[2 * BN + tid] + red[4 * BN + tid] + red[6 * BN + tid];
-                run2 += red[1 * BN + tid] + red[3 * BN + tid] + red[5 * BN + tid] + red[7 * BN + tid];
-            }
-        }
-        // vectorised store pass: unit = (row, float4 column)
-        const int ncol4 = min(BN, a.Cout - n0) >> 2;     // valid float4 columns of this block (Cout % 4 == 0)
-        if (ncol4 > 0) {
-            const float inv_nc = 1.0f / (float)ncol4;
-            const int units = BM * ncol4;
-            for (int u = tid; u < units; u += 256) {
-                int c4;
-                const int row = fdiv(u, ncol4, inv_nc, c4);
-                const int off = rowoff[row];
-                if (off < 0) continue;
-                const int co = n0 + c4 * 4;
-                float4 v = *(const float4*)(ct + row * CS + c4 * 4);
-                float* op = a.out + (int64_t)off + co;
-                if (flags & EPI_AFFINE) {
-                    const float4 sc = *(const float4*)(a.scale + co), sh = *(const float4*)(a.shift + co);
-                    v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
-                }
-                if (flags & EPI_RES) {
-                    const float4 r = *(const float4*)(a.res + (int64_t)off + co);
-                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-                }
-                if (flags & EPI_RESMASK) {
-                    const float4 r = *(const float4*)(a.res + (int64_t)off + co);
-                    const float4 m = *(const float4*)(a.resmask + (int64_t)off + co);
-                    v.x += m.x > 0.f ? r.x : 0.f; v.y += m.y > 0.f ? r.y : 0.f; v.z += m.z > 0.f ? r.z : 0.f; v.w += m.w > 0.f ? r.w : 0.f;
-                }
-                if (flags & EPI_ACCUM) {
-                    const float4 o = *(const float4*)op;
-                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-                }
-                if (flags & EPI_RELU) {
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                }
-                *(float4*)op = v;
-            }
-        }
-        cur = nxt;
-    }
-    if (flags & EPI_STATS) flush_stats();
-}
+constexpr int kPatchPF = 8;      // max float4 patch-prefetch registers per thread of the wgrad kernels
+constexpr int kConvPatchPF = 8;  // ... of the conv kernel (planner: patch units <= 256*kConvPatchPF)
 
 // =====================================================================================================
 // conv_t_kernel: channels x pixels orientation with K-grouped operands
@@ -485,12 +67,12 @@ __global__ void __launch_bounds__(256) conv_gemm_kernel(const ConvArgs a) {
 //    j of the round multiplies channel 4*c4(q_g) + j.  Any one-to-one assignment of k slots works as long as A and B agree, and
 //    this one makes the 4 operands a lane needs for a round ONE 16-byte LDS read each: B from the pixel-major patch (channels
 //    contiguous), A from the K-grouped pack [q][channel][4].  Per round a wave issues 1 + NT + MT LDS reads for 4*MT*NT MFMAs
-//    (conv_gemm_kernel: 4*(MT+NT) 4-byte reads and their address arithmetic).
+//    (the round-1 kernel, pixels x channels tiles: 4*(MT+NT) 4-byte reads and their address arithmetic).
 //  * A lane's 4 accumulator registers are 4 CONSECUTIVE output channels of one pixel: the epilogue (statistics, folded BatchNorm,
 //    residual, mask, ReLU, accumulate) works on registers and stores 16-byte vectors straight to the NHWC tensor: no LDS
 //    transpose, no barriers after the MFMAs.
 //  * Weights of the small layers (<= kResidentBytes per channel split) are copied to LDS ONCE per persistent workgroup; the others
-//    stream through a double-buffered stage of QS groups, fetched one stage ahead into registers (as conv_gemm_kernel does).
+//    stream through a double-buffered stage of QS groups, fetched one stage ahead into registers.
 //  * BatchNorm statistics: fp32 per-lane partials over the workgroup's tiles, fp64 from the cross-lane reduction on, flushed with
 //    one fp64 atomic per channel per workgroup (8 replicas, as above).
 // x / d for a plan constant d through its precomputed M = ceil(2^32 / d): exact for x * d < 2^32 (checked by the planner)
@@ -942,103 +524,6 @@ static conv_fn_t convt_fn(int MT, int NT, int PF, int res, int cls = 0) {
 }
 static int convt_pf_for(int units) { return units <= 1024 ? 4 : 8; }
 
-// instantiated tilings (chosen from the kbench sweeps, profiles/): MFMA width x (MT, NT) x patch-prefetch depth
-#define OCL_CONV_TILINGS16(X) X(16, 1, 1) X(16, 1, 2) X(16, 1, 3) X(16, 1, 5) X(16, 2, 1) X(16, 2, 2) X(16, 2, 3) X(16, 4, 2)
-#define OCL_CONV_TILINGS32(X) X(32, 1, 1) X(32, 1, 2) X(32, 1, 3) X(32, 2, 1) X(32, 2, 2)
-static conv_fn_t conv_fn_wreg(int PF) {
-    if (PF == 4) return conv_gemm_kernel<32, 1, 1, 4, true>;
-    if (PF == 6) return conv_gemm_kernel<32, 1, 1, 6, true>;
-    if (PF == 8) return conv_gemm_kernel<32, 1, 1, 8, true>;
-    return nullptr;
-}
-static conv_fn_t conv_fn(int W, int MT, int NT, int PF) {
-#define OCL_CASE(WW, M, N)                                                  \
-    if (W == WW && MT == M && NT == N) {                                    \
-        if (PF == 4) return conv_gemm_kernel<WW, M, N, 4>;                  \
-        if (PF == 6) return conv_gemm_kernel<WW, M, N, 6>;                  \
-        if (PF == 8) return conv_gemm_kernel<WW, M, N, 8>;                  \
-    }
-    OCL_CONV_TILINGS16(OCL_CASE)
-    OCL_CONV_TILINGS32(OCL_CASE)
-#undef OCL_CASE
-    return nullptr;
-}
-static int conv_pf_for(int units) { return units <= 1024 ? 4 : units <= 1536 ? 6 : 8; }
-
-static int bnp_for(int bn) {  // LDS weight row stride with (stride mod 32) == 16: B reads conflict-free
-    int p = bn;
-    while ((p & 31) != 16) p += 16;
-    return p;
-}
-
-// LDS bytes of a tile: row table + max(main loop: 2 weight stages + patch, epilogue: output tile + fp64 stat scratch)
-static size_t conv_lds_bytes(const ConvArgs& a, int BM, int BN) {
-    const size_t w_b = (size_t)2 * a.WS * 4;
-    const size_t main_b = w_b + (size_t)a.imgs * a.PR * a.PC * a.CP * 4;
-    const size_t epi_b = (size_t)BM * (BN + 4) * 4 + (size_t)8 * BN * 8;
-    return (size_t)64 + (size_t)BM * 4 + std::max(main_b, epi_b);
-}
-
-// Fills the tile-dependent fields of `a` for a given (MT, NT); returns the LDS bytes (0 = does not fit).
-static size_t conv_tile_layout(const ConvGeomDesc& g, ConvArgs& a, int W, int MT, int NT) {
-    const int ntilesW = cdiv(g.Cout, W);
-    const int splits = cdiv(ntilesW, NT);
-    const int BN = W * NT;
-    a.n_splits = splits;
-    a.CoutP = splits * BN;
-    a.BNP = W == 16 ? bnp_for(BN) : BN;     // 32-wide B reads: 32 consecutive floats per lane half, any row stride
-    a.group_size = g.N / g.groups;
-    const int LP = g.LH * g.LW;
-    const int BM = 4 * W * MT;
-    if (LP >= BM) {
-        a.imgs = 1; a.ppi = BM; a.tiles_per_img = cdiv(LP, BM);
-    } else {
-        a.imgs = std::min(BM / LP, a.group_size); a.ppi = LP; a.tiles_per_img = 1;
-    }
-    a.PC = (g.LW - 1) * g.is + (a.max_dx - a.min_dx) + 1;
-    const int rows_l = (a.imgs == 1 && LP >= BM) ? std::min(g.LH, (BM + g.LW - 2) / g.LW + 1) : g.LH;
-    a.PR = (rows_l - 1) * g.is + (a.max_dy - a.min_dy) + 1;
-    // channel chunk: largest divisor of Cin (multiple of 4) whose patch + weight stages fit the LDS target
-    int KC = g.Cin;
-    size_t bytes = 0;
-    for (;;) {
-        a.KC = KC; a.CP = KC + 2;
-        bool ok = false;
-        if (KC * a.BNP <= kMaxStageFloats) {
-            // largest balanced tap group (fewest weight stages per chunk) that fits: 9 taps as 9, 5+4, 3x3, ..., 1x9
-            for (int gpc = 1; gpc <= g.ntaps; ++gpc) {
-                const int TG = cdiv(g.ntaps, gpc);
-                if (TG * KC * a.BNP > kMaxStageFloats) continue;
-                a.TG = TG;
-                a.gpc = cdiv(g.ntaps, TG);
-                a.WS = (int)round_up(TG * KC * a.BNP, 4);
-                bytes = conv_lds_bytes(a, BM, BN);
-                if (bytes <= kLdsTarget && a.imgs * a.PR * a.PC * (KC / 4) <= 256 * kConvPatchPF) { ok = true; break; }
-            }
-        }
-        if (ok) break;
-        // next smaller channel chunk: the largest divisor of Cin below KC that is a multiple of 4
-        int nk = 0;
-        for (int d = KC - 4; d >= 4; d -= 4)
-            if (g.Cin % d == 0) { nk = d; break; }
-        if (nk) { KC = nk; continue; }
-        if (KC * a.BNP <= kMaxStageFloats) {   // nothing meets the 2-workgroups-per-CU target: single-tap stages, full LDS
-            a.TG = 1; a.gpc = g.ntaps; a.WS = (int)round_up(KC * a.BNP, 4);
-            bytes = conv_lds_bytes(a, BM, BN);
-            break;
-        }
-        return 0;
-    }
-    while ((bytes > kLdsLimit - 1024 || a.imgs * a.PR * a.PC * (a.KC / 4) > 256 * kConvPatchPF) && a.imgs > 1) {
-        a.imgs -= 1;   // shrink the tile (fewer images per block)
-        bytes = conv_lds_bytes(a, BM, BN);
-    }
-    if (bytes > kLdsLimit - 1024 || a.imgs * a.PR * a.PC * (a.KC / 4) > 256 * kConvPatchPF) return 0;
-    if (a.imgs > 127 || a.PR >= 256 || a.PC >= 256 || a.KC / 4 >= 256) return 0;   // packed (il, pr, pc, c4) prefetch bookkeeping
-    a.tiles_per_group = cdiv(a.group_size, a.imgs) * a.tiles_per_img;
-    return bytes;
-}
-
 // ---- conv_t_kernel layout: fills the tile-dependent fields for (MT channel tiles, NT pixel tiles); returns LDS bytes (0: no fit)
 static size_t convt_layout(const ConvGeomDesc& g, ConvArgs& a, int MT, int NT) {
     const int nt16 = cdiv(g.Cout, 16);
@@ -1088,14 +573,6 @@ found:
     return bytes;
 }
 
-static int conv_kind_default() {
-    static const int k = [] {
-        const char* e = getenv("OCL_CONV_T");
-        return e ? atoi(e) : 1;
-    }();
-    return k;
-}
-
 static int plan_conv_t(const ConvGeomDesc& g, ConvPlan* p) {
     ConvArgs& a = p->a;
     const int nt16 = cdiv(g.Cout, 16);
@@ -1122,11 +599,9 @@ static int plan_conv_t(const ConvGeomDesc& g, ConvPlan* p) {
         a.cls_pack |= (g.ncls > 1 ? g.cls_ntaps[c] : g.ntaps) << (4 + 4 * c);
         if (g.ncls > 1) a.cls_oyx |= (g.cls_oy[c] << (2 * c)) | (g.cls_ox[c] << (2 * c + 1));
     }
-    p->kind = 1;
-    p->W = 16; p->MT = MT; p->NT = NT;
+    p->MT = MT; p->NT = NT;
     p->lds_bytes = lds;
     a.WPT = g.WPT > 0 ? g.WPT : a.CoutP;
-    a.WP = a.WPT;
     for (int t = 0; t < 9; ++t) a.tpo[t] = t < a.ntaps ? ((a.tdy[t] - a.min_dy) * a.PC + (a.tdx[t] - a.min_dx)) * a.CP : 0;
     {
         const int kc4 = a.KC / 4;
@@ -1134,7 +609,6 @@ static int plan_conv_t(const ConvGeomDesc& g, ConvPlan* p) {
         const int d_pix = 256 / kc4;
         a.d_pc = d_pix % a.PC;
         a.d_row = d_pix / a.PC;
-        a.inv_PR = 1.0f / (float)a.PR;
     }
     a.groups = g.groups;
     {
@@ -1177,91 +651,11 @@ int plan_conv(const ConvGeomDesc& g, ConvPlan* p) {
         a.min_dy = std::min(a.min_dy, g.tdy[t]); a.max_dy = std::max(a.max_dy, g.tdy[t]);
         a.min_dx = std::min(a.min_dx, g.tdx[t]); a.max_dx = std::max(a.max_dx, g.tdx[t]);
     }
-    const int want_kind = g.force_kind ? g.force_kind - 1 : conv_kind_default();
-    if (want_kind == 1 && !g.force_W) {
-        if (plan_conv_t(g, p) == OCL_OK) return OCL_OK;
-        if (g.force_kind == 2) { set_error("plan_conv: no conv_t tiling for MT=%d NT=%d", g.force_MT, g.force_NT); return OCL_ERR_ARG; }
-        if (g.ncls > 1) { set_error("plan_conv: no conv_t tiling for a %d-class geometry", g.ncls); return OCL_ERR_ARG; }
-        // fall through to conv_gemm_kernel with a clean plan
-        ConvArgs keep = a;
-        memset(p, 0, sizeof(*p));
-        a = keep;
-        a.n_splits = a.CoutP = a.group_size = a.imgs = a.ppi = a.tiles_per_img = a.PC = a.PR = a.KC = a.CP = 0;
+    if (plan_conv_t(g, p) != OCL_OK) {
+        set_error("plan_conv: no tiling fits (Hin=%d Win=%d Cin=%d Cout=%d taps=%d classes=%d, forced MT=%d NT=%d)", g.Hin, g.Win, g.Cin, g.Cout,
+                  g.ntaps, g.ncls, g.force_MT, g.force_NT);
+        return OCL_ERR_ARG;
     }
-    if (g.ncls > 1) { set_error("plan_conv: output classes need conv_t_kernel"); return OCL_ERR_ARG; }
-    // ---- tile choice ---------------------------------------------------------------------------------------------
-    // Rules distilled from the kbench sweeps on MI355X (profiles/r1_kbench_conv_sweep*.txt):
-    //  * enough pixels for 128-row tiles -> 32x32x2 MFMA (W = 32), all output channels of a 32/64/96-wide block per
-    //    workgroup; else 16x16x4 with 48-channel blocks (NT = 3), 128-pixel tiles once there are >= 512 64-pixel tiles;
-    //  * small problems (replay batches of 10-20 images) are latency-bound on a wave's serial MFMA chain: narrower
-    //    column blocks until there are >= 128 workgroups;
-    //  * persistent grid of two workgroups per CU.  Whatever does not fit the LDS / prefetch-register budget falls back
-    //    to the nearest tiling that does.
-    int bestW = 0, bestMT = 0, bestNT = 0, bestG = 0;
-    {
-        const int LPx = g.LH * g.LW;
-        const int64_t tiles64 = (int64_t)g.groups * (LPx >= 64 ? (int64_t)(g.N / g.groups) * cdiv(LPx, 64)
-                                                                : cdiv(g.N / g.groups, std::max(1, 64 / LPx)));
-        const int nt16 = cdiv(g.Cout, 16), nt32 = cdiv(g.Cout, 32);
-        int pref_w = (g.Cout <= 32 && tiles64 >= 1024) ? 32 : 16;   // sweep: 32x32x2 wins only where 20 channels pad to 32 anyway
-        if (g.force_W) pref_w = g.force_W;
-        int pref_nt, pref_mi;
-        if (pref_w == 32) {
-            pref_nt = nt32 <= 3 ? nt32 : (nt32 % 2 == 0 ? 2 : 1);     // 160 channels: five 32-wide blocks
-            pref_mi = 0;
-        } else {
-            pref_nt = std::min(3, nt16);
-            while (pref_nt > 1 && tiles64 * cdiv(nt16, pref_nt) < 128) --pref_nt;
-            pref_mi = tiles64 >= 512 ? 1 : 0;
-        }
-        double best = 1e30;
-        const int MTs[3] = {1, 2, 4};
-        for (int W = 16; W <= 32; W += 16)
-            for (int mi = 0; mi < 3; ++mi)
-                for (int NT = 1; NT <= 5; ++NT) {
-                    const int MT = MTs[mi];
-                    if (g.force_W && W != g.force_W) continue;
-                    if (g.force_MT && MT != g.force_MT) continue;
-                    if (g.force_NT && NT != g.force_NT) continue;
-                    if (!conv_fn(W, MT, NT, 8)) continue;
-                    if (NT > cdiv(g.Cout, W)) continue;
-                    ConvArgs t = a;
-                    const size_t lds = conv_tile_layout(g, t, W, MT, NT);
-                    if (!lds) continue;
-                    // distance from the preferred tiling; shallow channel chunks (many patch stages) are penalised
-                    const double cost = (W != pref_w ? 10.0 : 0.0) + std::abs(NT - pref_nt) * 1.0 + std::abs(mi - pref_mi) * 1.5 +
-                                        (g.Cin / t.KC - 1) * 0.4 + (t.KC < std::min(20, g.Cin) ? 3.0 : 0.0);
-                    if (cost < best) { best = cost; bestW = W; bestMT = MT; bestNT = NT; }
-                }
-        if (bestMT) {
-            ConvArgs t = a;
-            const size_t lds = conv_tile_layout(g, t, bestW, bestMT, bestNT);
-            const int ntiles = g.groups * t.tiles_per_group;
-            int bpc = (int)std::min<size_t>(2, kLdsLimit / (lds + 512));
-            if (g.force_bpc) bpc = g.force_bpc;
-            bestG = std::max(1, std::min(ntiles, (256 * std::max(1, bpc)) / t.n_splits));
-        }
-    }
-    OCL_REQUIRE(bestMT > 0, "plan_conv: no tile fits the LDS (Hin=%d Win=%d Cin=%d Cout=%d)", g.Hin, g.Win, g.Cin, g.Cout);
-    p->lds_bytes = conv_tile_layout(g, a, bestW, bestMT, bestNT);
-    p->W = bestW;
-    // register-resident weights: 3x3 (9 taps), 20 input channels in one chunk, <= 32 output channels, 32x32x2 tiles
-    a.wreg = (bestW == 32 && bestMT == 1 && bestNT == 1 && g.ntaps == 9 && g.Cin == 20 && a.KC == 20 && g.Cout <= 32 && !g.no_wreg) ? 1 : 0;
-    a.WP = g.WP > 0 ? g.WP : a.CoutP;
-    a.KU = ((a.KC / 4) % 5 == 0) ? 5 : 1;
-    for (int t = 0; t < 9; ++t) a.tpo[t] = t < a.ntaps ? ((a.tdy[t] - a.min_dy) * a.PC + (a.tdx[t] - a.min_dx)) * a.CP : 0;
-    {   // patch staging walks its flat [row][pc][c4] unit space in steps of 256 units
-        const int kc4 = a.KC / 4;
-        a.d_c4 = 256 % kc4;
-        const int d_pix = 256 / kc4;
-        a.d_pc = d_pix % a.PC;
-        a.d_row = d_pix / a.PC;
-        a.inv_PR = 1.0f / (float)a.PR;
-    }
-    p->MT = bestMT; p->NT = bestNT;
-    a.groups = g.groups;
-    p->grid_x = bestG;
-    p->grid_y = a.n_splits;
     return OCL_OK;
 }
 
@@ -1273,7 +667,6 @@ void geom_fwd(const ConvShape& c, int N, int groups, ConvGeomDesc* g) {
     g->Hin = c.Hin; g->Win = c.Win; g->Cin = c.CinT;
     g->Hout = c.Ho; g->Wout = c.Wo; g->Cout = c.Cout;
     g->LH = c.Ho; g->LW = c.Wo; g->os = 1; g->oy0 = 0; g->ox0 = 0; g->is = c.stride;
-    g->WP = c.CoutP;
     g->WPT = c.CoutP;
     const int pad = c.k == 3 ? 1 : 0;
     g->ntaps = c.k * c.k;
@@ -1292,7 +685,6 @@ void geom_dgrad(const ConvShape& c, int N, std::vector<ConvGeomDesc>* out, bool 
     g.Hin = c.Ho; g.Win = c.Wo; g.Cin = c.Cout;
     g.Hout = c.Hin; g.Wout = c.Win; g.Cout = c.Cin;
     g.is = 1;
-    g.WP = c.CiP;
     g.WPT = c.CiP;
     if (c.stride == 1) {
         g.LH = c.Hin; g.LW = c.Win; g.os = 1;
@@ -1361,11 +753,9 @@ void geom_dgrad(const ConvShape& c, int N, std::vector<ConvGeomDesc>* out, bool 
 }
 
 int launch_conv(const ConvPlan& p, hipStream_t s) {
-    const int pfu = conv_pf_for(p.a.imgs * p.a.PR * p.a.PC * (p.a.KC / 4));
-    conv_fn_t fn = p.kind == 1 ? convt_fn(p.MT, p.NT, convt_pf_for(p.a.imgs * p.a.PR * p.a.PC * (p.a.KC / 4)), p.a.wres, (p.a.cls_pack & 15) > 1)
-                               : p.a.wreg ? conv_fn_wreg(pfu) : conv_fn(p.W, p.MT, p.NT, pfu);
+    conv_fn_t fn = convt_fn(p.MT, p.NT, convt_pf_for(p.a.imgs * p.a.PR * p.a.PC * (p.a.KC / 4)), p.a.wres, (p.a.cls_pack & 15) > 1);
     if (!fn) {
-        set_error("launch_conv: no kernel for W=%d MT=%d NT=%d", p.W, p.MT, p.NT);
+        set_error("launch_conv: no kernel for MT=%d NT=%d", p.MT, p.NT);
         return OCL_ERR_STATE;
     }
     ProfScope ps(PROF_CONV, s);
@@ -1801,8 +1191,6 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const float* __restri
     }
     PackDesc d = descs[blockIdx.y];
     // the scattered stores are the cost of this kernel: a pass writes only the packs it reads (PACK_* bits)
-    if (!(mask & PACK_F)) d.f_off = -1;
-    if (!(mask & PACK_D)) d.d_off = -1;
     if (!(mask & PACK_TF)) d.tf_off = -1;
     if (!(mask & PACK_TD)) d.td_off = -1;
     const int total = d.Cout * d.Cin * d.ntaps;
@@ -1811,8 +1199,6 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const float* __restri
         const int rem = e - co * d.Cin * d.ntaps;
         const int ci = rem / d.ntaps, t = rem - ci * d.ntaps;
         const float v = params[d.w_off + e];
-        if (d.f_off >= 0) arena[d.f_off + ((int64_t)t * d.CinP + ci) * d.CoutP + co] = v;
-        if (d.d_off >= 0) arena[d.d_off + ((int64_t)t * d.Cout + co) * d.CiP + ci] = v;
         if (d.tf_off >= 0) arena[d.tf_off + ((((int64_t)t * (d.CinP >> 2) + (ci >> 2)) * d.CoutP + co) << 2) + (ci & 3)] = v;
         if (d.td_off >= 0) arena[d.td_off + ((((int64_t)t * (d.Cout >> 2) + (co >> 2)) * d.CiP + ci) << 2) + (co & 3)] = v;
     }
@@ -2481,19 +1867,10 @@ int launch_fill(float* p, int64_t n, float v, hipStream_t s) {
 int conv_kernels_init() {
     static bool done = false;
     if (done) return OCL_OK;
-    for (int w = 16; w <= 32; w += 16)
-        for (int m = 1; m <= 4; ++m)
-            for (int n = 1; n <= 5; ++n)
-                for (int pf = 4; pf <= 8; pf += 2)
-                    if (conv_fn(w, m, n, pf))
-                        OCL_HIP(hipFuncSetAttribute((const void*)conv_fn(w, m, n, pf), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                    (int)kLdsLimit));
     for (int m = 1; m <= 4; ++m)
         for (int n = 1; n <= 5; ++n)
             for (int pf = 4; pf <= 8; pf += 4)
                 OCL_HIP(hipFuncSetAttribute((const void*)wgrad_fn(m, n, pf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
-    for (int pf = 4; pf <= 8; pf += 2)
-        OCL_HIP(hipFuncSetAttribute((const void*)conv_fn_wreg(pf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     for (int m = 1; m <= 5; ++m)
         for (int n = 1; n <= 2; ++n)
             for (int pf = 4; pf <= 8; pf += 4)

@@ -125,61 +125,78 @@ static float* make_packT(const float* w_dev, int Cin, int WP) {
     return d;
 }
 
+// Reference result for the conv kernel: one thread per output element, plain fp32 FMAs over (tap, input channel) of the row pack
+// w[tap][Cin][WP] (independent of conv_t_kernel's tiling, operand layout and epilogue).
+__global__ void conv_ref_kernel(ConvGeomDesc g, const float* __restrict__ in, const float* __restrict__ w, int WP, float* __restrict__ out) {
+    const int64_t total = (int64_t)g.N * g.LH * g.LW * g.Cout;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int co = (int)(i % g.Cout);
+        int64_t r = i / g.Cout;
+        const int lx = (int)(r % g.LW); r /= g.LW;
+        const int ly = (int)(r % g.LH);
+        const int n = (int)(r / g.LH);
+        float acc = 0.f;
+        for (int t = 0; t < g.ntaps; ++t) {
+            const int iy = ly * g.is + g.tdy[t], ix = lx * g.is + g.tdx[t];
+            if (iy < 0 || iy >= g.Hin || ix < 0 || ix >= g.Win) continue;
+            const float* xp = in + (((int64_t)n * g.Hin + iy) * g.Win + ix) * g.Cin;
+            const float* wp = w + (int64_t)g.tw[t] * g.Cin * WP + co;
+            for (int ci = 0; ci < g.Cin; ++ci) acc = fmaf(xp[ci], wp[(int64_t)ci * WP], acc);
+        }
+        out[(((int64_t)n * g.Hout + ly * g.os + g.oy0) * g.Wout + lx * g.os + g.ox0) * g.Cout + co] = acc;
+    }
+}
+
 static void bench_geom(const char* lname, const char* kind, ConvGeomDesc g, const float* in, const float* w, float* out,
                        float* out_ref, double* stats, int flags, double flops, size_t out_elems, bool sweep) {
-    ConvPlan p0;
-    g.force_kind = 1;   // reference result: conv_gemm_kernel
-    OK(plan_conv(g, &p0));
-    g.WPT = g.WP;
-    float* wT = make_packT(w, g.Cin, g.WP);
+    float* wT = make_packT(w, g.Cin, g.WPT);
     auto run = [&](ConvPlan p, float* o) {
-        p.a.in = in; p.a.w = w; p.a.wT = wT; p.a.out = o; p.a.flags = flags; p.a.stats = stats; p.a.stat_rep_stride = 8 * 2 * 1024;
+        p.a.in = in; p.a.wT = wT; p.a.out = o; p.a.flags = flags; p.a.stats = stats; p.a.stat_rep_stride = 8 * 2 * 1024;
         OK(launch_conv(p, 0));
     };
     CK(hipMemset(out_ref, 0, out_elems * 4));
-    run(p0, out_ref);
-    const double t0 = time_us([&] { run(p0, out_ref); });
-    printf("%-20s %-7s M=%7d N=%3d K=%4d  auto W=%d MT=%d NT=%d grid=%5dx%d lds=%6zu KC=%3d TG=%d  %7.1f us %6.1f TF/s\n", lname, kind,
-           g.N * g.LH * g.LW, g.Cout, g.ntaps * g.Cin, p0.W, p0.MT, p0.NT, p0.grid_x, p0.grid_y, p0.lds_bytes, p0.a.KC, p0.a.TG, t0,
-           flops / t0 * 1e-6);
-    if (p0.a.wreg) {   // A/B: the same tiling with staged (LDS) weights
-        ConvGeomDesc gn = g;
-        gn.no_wreg = 1;
-        ConvPlan pn;
-        OK(plan_conv(gn, &pn));
-        CK(hipMemset(out, 0, out_elems * 4));
-        run(pn, out);
-        const double d = max_diff(out, out_ref, out_elems);
-        const double t = time_us([&] { run(pn, out); });
-        printf("    (weights staged through LDS instead of registers: %7.1f us, maxdiff vs register variant %.2e)\n", t, d);
+    hipLaunchKernelGGL(conv_ref_kernel, dim3(2048), dim3(256), 0, 0, g, in, w, g.WPT, out_ref);
+    CK(hipDeviceSynchronize());
+    // reference statistics (per BatchNorm group and channel: sum, sum of squares) from the reference output, in fp64 on the host
+    std::vector<double> ref_stats((size_t)g.groups * 2 * g.Cout, 0.0);
+    if (flags & EPI_STATS) {
+        std::vector<float> h(out_elems);
+        CK(hipMemcpy(h.data(), out_ref, out_elems * 4, hipMemcpyDeviceToHost));
+        const int64_t per_img = (int64_t)g.Hout * g.Wout * g.Cout;
+        const int gsz = g.N / g.groups;
+        for (int n = 0; n < g.N; ++n)
+            for (int64_t e = 0; e < per_img; ++e) {
+                const double v = h[(size_t)n * per_img + e];
+                const int c = (int)(e % g.Cout), gg = n / gsz;
+                ref_stats[((size_t)gg * 2 + 0) * g.Cout + c] += v;
+                ref_stats[((size_t)gg * 2 + 1) * g.Cout + c] += v * v;
+            }
     }
+    printf("%-20s %-7s M=%7d N=%3d K=%4d\n", lname, kind, g.N * g.LH * g.LW, g.Cout, g.ntaps * g.Cin);
     {   // conv_t_kernel: planner's choice and (sweep) every admissible (MT, NT)
         double* stats2;
         CK(hipMalloc(&stats2, kStatReps * 8 * 2 * 1024 * 8));
         for (int mt = 0; mt <= (sweep ? 5 : 0); ++mt)
             for (int nt = (mt ? 1 : 0); nt <= (mt ? 2 : 0); ++nt) {
                 ConvGeomDesc gt = g;
-                gt.force_kind = 2; gt.force_MT = mt; gt.force_NT = nt;
+                gt.force_MT = mt; gt.force_NT = nt;
                 ConvPlan pt;
                 if (plan_conv(gt, &pt) != OCL_OK) continue;
                 CK(hipMemset(out, 0, out_elems * 4));
                 CK(hipMemset(stats2, 0, kStatReps * 8 * 2 * 1024 * 8));
-                CK(hipMemset(stats, 0, kStatReps * 8 * 2 * 1024 * 8));
-                run(p0, out_ref);
                 double* keep = stats;
                 stats = stats2;
                 run(pt, out);
                 stats = keep;
                 const double d = max_diff(out, out_ref, out_elems);
                 double ds = 0.0;
-                if (flags & EPI_STATS) {   // statistics: sum the replicas of both runs
-                    std::vector<double> a(kStatReps * 8 * 2 * 1024), b(a.size());
-                    CK(hipMemcpy(a.data(), stats, a.size() * 8, hipMemcpyDeviceToHost));
+                if (flags & EPI_STATS) {   // statistics: the kernel's replicas summed, against the fp64 sums of the reference output
+                    std::vector<double> b(kStatReps * 8 * 2 * 1024);
                     CK(hipMemcpy(b.data(), stats2, b.size() * 8, hipMemcpyDeviceToHost));
                     for (int i = 0; i < g.groups * 2 * g.Cout; ++i) {
-                        double x = 0, y = 0;
-                        for (int r = 0; r < kStatReps; ++r) { x += a[(size_t)r * 8 * 2 * 1024 + i]; y += b[(size_t)r * 8 * 2 * 1024 + i]; }
-                        ds = fmax(ds, fabs(x - y) / (1.0 + fabs(x)));
+                        double y = 0;
+                        for (int r = 0; r < kStatReps; ++r) y += b[(size_t)r * 8 * 2 * 1024 + i];
+                        ds = fmax(ds, fabs(ref_stats[i] - y) / (1.0 + fabs(ref_stats[i])));
                     }
                 }
                 double* keep2 = stats;
@@ -245,30 +262,6 @@ static void bench_geom(const char* lname, const char* kind, ConvGeomDesc g, cons
         CK(hipFree(stats2));
     }
     CK(hipFree(wT));
-    if (!sweep) return;
-    g.force_kind = 1;
-    const int MTs[3] = {1, 2, 4};
-    const int ntile16 = (g.Cout + 15) / 16;
-    for (int W = 16; W <= 32; W += 16)
-    for (int mi = 0; mi < 3; ++mi)
-        for (int NT = 1; NT <= std::min(5, ntile16); ++NT)
-          for (int bpc = 1; bpc <= 2; ++bpc) {
-            ConvGeomDesc gf = g;
-            gf.force_kind = 1;
-            gf.force_W = W;
-            gf.force_MT = MTs[mi];
-            gf.force_NT = NT;
-            gf.force_bpc = bpc;
-            ConvPlan p;
-            if (plan_conv(gf, &p) != OCL_OK) continue;
-            CK(hipMemset(out, 0, out_elems * 4));
-            run(p, out);
-            const double d = max_diff(out, out_ref, out_elems);
-            const double t = time_us([&] { run(p, out); });
-            if (p.W != W || p.MT != MTs[mi] || p.NT != NT) continue;
-            printf("    W=%d MT=%d NT=%d grid=%5dx%d lds=%6zu KC=%3d TG=%d  %7.1f us %6.1f TF/s  maxdiff=%.2e%s\n", p.W, p.MT, p.NT, p.grid_x,
-                   p.grid_y, p.lds_bytes, p.a.KC, p.a.TG, t, flops / t * 1e-6, d, d > 1e-3 ? "  <-- MISMATCH" : "");
-        }
 }
 
 // ---- calibration: what the f32 MFMA pipe delivers on this box ---------------------------------------------------------
@@ -466,14 +459,14 @@ int main(int argc, char** argv) {
             ConvGeomDesc g;
             geom_fwd(c, N, groups, &g);
             std::vector<ConvGeomDesc> all(1, g), dg;
-            if (c.Cin != 3) geom_dgrad(c, N, &dg);
+            if (c.Cin != 3) geom_dgrad(c, N, &dg, true);
             all.insert(all.end(), dg.begin(), dg.end());
             for (size_t i = 0; i < all.size(); ++i) {
                 ConvPlan p;
                 OK(plan_conv(all[i], &p));
-                printf("%-20s %-6s M=%7d N=%3d K=%4d  W=%d MT=%d NT=%d grid=%5dx%d lds=%6zu KC=%3d CP=%3d TG=%d gpc=%d WS=%d imgs=%d ppi=%d PR=%d PC=%d\n",
+                printf("%-20s %-6s M=%7d N=%3d K=%4d  MT=%d NT=%d grid=%5dx%d lds=%6zu KC=%3d CP=%3d Qpad=%d QS=%d res=%d classes=%d imgs=%d ppi=%d PR=%d PC=%d\n",
                        l.name.c_str(), i == 0 ? "fwd" : "dgrad", all[i].N * all[i].LH * all[i].LW, all[i].Cout, all[i].ntaps * all[i].Cin,
-                       p.W, p.MT, p.NT, p.grid_x, p.grid_y, p.lds_bytes, p.a.KC, p.a.CP, p.a.TG, p.a.gpc, p.a.WS, p.a.imgs, p.a.ppi, p.a.PR, p.a.PC);
+                       p.MT, p.NT, p.grid_x, p.grid_y, p.lds_bytes, p.a.KC, p.a.CP, p.a.Qpad, p.a.QS, p.a.wres, p.a.cls_pack & 15, p.a.imgs, p.a.ppi, p.a.PR, p.a.PC);
             }
             WgradPlan wp;
             OK(plan_wgrad(N, c.Hin, c.Win, c.CinT, c.Ho, c.Wo, c.Cout, c.k, c.stride, &wp));
@@ -547,17 +540,16 @@ int main(int argc, char** argv) {
                 geom_dgrad(c, N, &dm, true);
                 if (dg.size() == 4 && dm.size() == 1 && dm[0].ncls > 1) {   // the four parity classes as ONE launch vs four
                     const size_t out_elems = (size_t)N * c.Hin * c.Win * c.Cin;
-                    float* wT = make_packT(w, dm[0].Cin, dm[0].WP);
+                    float* wT = make_packT(w, dm[0].Cin, dm[0].WPT);
                     std::vector<ConvPlan> p4(4);
-                    for (int i = 0; i < 4; ++i) { dg[i].WPT = dg[i].WP; OK(plan_conv(dg[i], &p4[i])); }
+                    for (int i = 0; i < 4; ++i) OK(plan_conv(dg[i], &p4[i]));
                     for (int fmt = 0; fmt <= (sweep ? 5 : 0); ++fmt) {
                     ConvGeomDesc gm = dm[0];
-                    gm.WPT = gm.WP;
                     gm.force_MT = fmt;
                     ConvPlan pm;
                     if (plan_conv(gm, &pm) == OCL_OK) {
                         auto run = [&](ConvPlan p, float* o) {
-                            p.a.in = bufA; p.a.w = w; p.a.wT = wT; p.a.out = o; p.a.flags = 0; p.a.stats = stats; p.a.stat_rep_stride = 8 * 2 * 1024;
+                            p.a.in = bufA; p.a.wT = wT; p.a.out = o; p.a.flags = 0; p.a.stats = stats; p.a.stat_rep_stride = 8 * 2 * 1024;
                             OK(launch_conv(p, 0));
                         };
                         CK(hipMemset(bufC, 0, out_elems * 4));

@@ -35,8 +35,7 @@ struct BnInfo {
 struct ConvInfo : ConvShape {
     int w_t;          // weight tensor index
     int bn;           // following BatchNorm
-    int64_t f_off, d_off;  // pack arena offsets (floats)
-    int64_t tf_off, td_off;  // K-grouped packs (conv_t_kernel)
+    int64_t tf_off, td_off;  // K-grouped weight packs in the arena (floats): forward, data gradient
     int64_t y_off;    // raw output inside a slot (floats)
 };
 struct BlockInfo {
@@ -93,7 +92,7 @@ struct ocl_net {
     const float* pack_src = nullptr;   // parameter array the weight-pack arena was last written from (by a forward)
     int pack_have = 0;                 // PACK_* bits of the packs that hold `pack_src`'s weights
     bool bsums_clean = false;          // the backward's statistics arena was cleared by the last forward's pack launch and not used since
-    int pack_need_fwd = 0, pack_need_bwd = 0;   // packs the plans made so far read (the round-1 kernel's layouts only where it is planned)
+    int pack_need_fwd = 0, pack_need_bwd = 0;   // packs the plans made so far read (forward pack; data-gradient pack once a backward is planned)
 
     int dbg_stop = -1;            // debug: return from backward right after stage (block*10 + step)
     float* dbg_role[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -231,21 +230,15 @@ static int build_layout(ocl_net* n) {
     int64_t pk = 0;
     for (auto& cv : n->convs) {
         cv.CoutP = pack_width(cv.Cout);
-        cv.f_off = pk;
-        pk += (int64_t)cv.k * cv.k * cv.CinT * cv.CoutP;
-        pk = align_up(pk, 64);
         cv.tf_off = pk;
         pk += (int64_t)cv.k * cv.k * cv.CinT * cv.CoutP;
         if (cv.Cin != 3) {
             cv.CiP = pack_width(cv.Cin);
-            cv.d_off = pk;
-            pk += (int64_t)cv.k * cv.k * cv.Cout * cv.CiP;
             pk = align_up(pk, 64);
             cv.td_off = pk;
             pk += (int64_t)cv.k * cv.k * cv.Cout * cv.CiP;
         } else {
             cv.CiP = 0;
-            cv.d_off = -1;
             cv.td_off = -1;
         }
         pk = align_up(pk, 64);
@@ -358,7 +351,7 @@ static int get_plans(ocl_net* n, int N, int groups, PlanSet** out) {
         geom_fwd(c, N, groups, &g);
         int rc = plan_conv(g, &ps.fwd[i]);
         if (rc != OCL_OK) return rc;
-        n->pack_need_fwd |= ps.fwd[i].kind == 1 ? PACK_TF : PACK_F;
+        n->pack_need_fwd |= PACK_TF;
         if (c.Cin != 3) {
             // stride-2 3x3: the four parity classes as one launch where conv_t_kernel can take them (OCL_DGRAD_MERGE=0: four launches)
             static const bool merge = [] { const char* e = getenv("OCL_DGRAD_MERGE"); return !(e && e[0] == '0'); }();
@@ -373,7 +366,7 @@ static int get_plans(ocl_net* n, int N, int groups, PlanSet** out) {
                 rc = plan_conv(q, &p);
                 if (rc != OCL_OK) return rc;
                 ps.dgrad[i].push_back(p);
-                n->pack_need_bwd |= p.kind == 1 ? PACK_TD : PACK_D;
+                n->pack_need_bwd |= PACK_TD;
             }
         }
         rc = plan_wgrad(N, c.Hin, c.Win, c.CinT, c.Ho, c.Wo, c.Cout, c.k, c.stride, &ps.wgrad[i]);
@@ -404,8 +397,6 @@ static int upload_descs(ocl_net* n, hipStream_t s) {
     for (size_t i = 0; i < n->convs.size(); ++i) {
         const ConvInfo& c = n->convs[i];
         pd[i].w_off = n->tensors[c.w_t].off;
-        pd[i].f_off = c.f_off;
-        pd[i].d_off = c.d_off;
         pd[i].tf_off = c.tf_off;
         pd[i].td_off = c.td_off;
         pd[i].Cout = c.Cout;
@@ -437,11 +428,10 @@ static const BnFoldDesc* fold_descs(const ocl_net* n) {
     return (const BnFoldDesc*)(n->ws + n->off_descs + align_up((int64_t)(n->convs.size() * sizeof(PackDesc)), 64));
 }
 
-static int run_conv(ocl_net* n, ConvPlan p, const float* in, const float* w, const float* wT, float* out, int flags, double* stats,
+static int run_conv(ocl_net* n, ConvPlan p, const float* in, const float* wT, float* out, int flags, double* stats,
                     const float* scale, const float* shift, const float* res, const float* resmask, hipStream_t s) {
     p.a.stat_rep_stride = n->stats_rep_stride;
     p.a.in = in;
-    p.a.w = w;
     p.a.wT = wT;
     p.a.out = out;
     p.a.flags = flags;
@@ -643,7 +633,7 @@ static int trunk_forward_train(ocl_net* n, PlanSet* ps, const float* P, float* S
     };
     auto conv_stats = [&](int conv_i, const float* in, hipStream_t st) -> int {
         const ConvInfo& c = n->convs[conv_i];
-        return run_conv(n, ps->fwd[conv_i], in, pack + c.f_off, pack + c.tf_off, at(c.y_off, c), EPI_STATS, stats + n->bns[c.bn].arena_off, nullptr,
+        return run_conv(n, ps->fwd[conv_i], in, pack + c.tf_off, at(c.y_off, c), EPI_STATS, stats + n->bns[c.bn].arena_off, nullptr,
                         nullptr, nullptr, nullptr, st);
     };
     const ConvInfo& c0 = n->convs[0];
@@ -735,7 +725,7 @@ int ocl_net_forward(ocl_net* n, const float* x, int N, int groups, uint32_t flag
             const ConvInfo& c = n->convs[conv_i];
             const BnInfo& b = n->bns[c.bn];
             int fl = EPI_AFFINE | (res ? EPI_RES : 0) | (relu ? EPI_RELU : 0);
-            return run_conv(n, ps->fwd[conv_i], in, pack + c.f_off, pack + c.tf_off, o, fl, nullptr, fold + b.stat_off, fold + b.stat_off + b.C, res,
+            return run_conv(n, ps->fwd[conv_i], in, pack + c.tf_off, o, fl, nullptr, fold + b.stat_off, fold + b.stat_off + b.C, res,
                             nullptr, s);
         };
         float* bufs[4] = {n->gbuf(0), n->gbuf(1), n->gbuf(2), n->gbuf(3)};
@@ -885,7 +875,7 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
         const ConvInfo& c = n->convs[conv_i];
         for (auto& p : ps->dgrad[conv_i]) {
             int fl = extra_flags | (res ? (resmask ? EPI_RESMASK : EPI_RES) : 0);
-            int r = run_conv(n, p, dy, pack + c.d_off, pack + c.td_off, dx, fl, nullptr, nullptr, nullptr, res, resmask, s);
+            int r = run_conv(n, p, dy, pack + c.td_off, dx, fl, nullptr, nullptr, nullptr, res, resmask, s);
             if (r) return r;
         }
         return OCL_OK;
