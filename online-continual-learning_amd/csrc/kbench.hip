@@ -265,8 +265,9 @@ static void bench_geom(const char* lname, const char* kind, ConvGeomDesc g, cons
 }
 
 // ---- calibration: what the f32 MFMA pipe delivers on this box ---------------------------------------------------------
+// rnd (KBENCH_PEAK_RANDOM=1): per-lane pseudo-random operands instead of the few constant values (does the rate depend on the data?)
 template <int NACC, bool LDS>
-__global__ void __launch_bounds__(256) mfma_peak_kernel(float* out, int iters) {
+__global__ void __launch_bounds__(256) mfma_peak_kernel(float* out, int iters, int rnd) {
     __shared__ float sm[4096];
     for (int i = threadIdx.x; i < 4096; i += 256) sm[i] = (float)(i & 7) * 0.125f;
     __syncthreads();
@@ -274,6 +275,13 @@ __global__ void __launch_bounds__(256) mfma_peak_kernel(float* out, int iters) {
 #pragma unroll
     for (int j = 0; j < NACC; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float a = (float)(threadIdx.x & 3) * 0.25f, b = 1.0f;
+    if (rnd) {
+        unsigned h = (threadIdx.x + 1u) * 2654435761u + blockIdx.x * 40503u;
+        h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+        a = __uint_as_float(0x3f000000u | (h & 0x007fffffu)) - 0.75f;              // mantissa bits all random, |a| < 0.25
+        h *= 3266489917u; h ^= h >> 16;
+        b = __uint_as_float(0x3f000000u | (h & 0x007fffffu)) - 0.75f;
+    }
     const int lane = threadIdx.x & 63;
     for (int i = 0; i < iters; ++i) {
         if (LDS) {   // the conv main loop's operand traffic: one A and one B ds_read_b32 per pair of MFMAs
@@ -343,7 +351,7 @@ template <int NACC, bool LDS>
 static void peak_case(const char* name, int blocks_per_cu, float* out) {
     const int iters = 4000;
     const int blocks = 256 * blocks_per_cu;
-    const double t = time_us([&] { hipLaunchKernelGGL((mfma_peak_kernel<NACC, LDS>), dim3(blocks), dim3(256), 0, 0, out, iters); }, 5, 1);
+    const double t = time_us([&] { hipLaunchKernelGGL((mfma_peak_kernel<NACC, LDS>), dim3(blocks), dim3(256), 0, 0, out, iters, getenv("KBENCH_PEAK_RANDOM") ? 1 : 0); }, 5, 1);
     const double flops = (double)blocks * 4 * iters * NACC * 2048.0;
     printf("peak %-28s acc=%d blocks/CU=%d  %8.1f us  %6.1f TF/s  (%.1f cycles/MFMA/SIMD at 2.4 GHz)\n", name, NACC, blocks_per_cu, t,
            flops / t * 1e-6, t * 1e-6 * 2.4e9 / ((double)blocks_per_cu * iters * NACC));
