@@ -94,16 +94,34 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 constexpr int kMaxWgTiles = 64;                // tile descriptors a workgroup keeps in LDS
 
-template <int MT, int NT, int PF, bool RES, bool CLS = false>   // CLS: several output classes per tile (merged parity classes of a stride-2 data gradient)
-__global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
+// PIPE variant of the staged-weight path (experimental, off by default: OCL_CONV_PIPE=1 / ConvGeomDesc::force_pipe).  The two-buffer
+// schedule pays, per stage and with one workgroup per CU, a serial section nothing overlaps: the table look-ups and loads of the
+// next stage (4 dependent LDS round trips), the commit, a barrier and the first operand reads (~1900 of ~3800 cycles around 60
+// MFMAs, profiles/r2_kbench_conv_staged_trace.txt).  Here the stages of a (tile, class, chunk) form ONE software-pipelined round
+// sequence: weights go through a ring of three stage buffers, the registers hold the stage after next, and the stage's single
+// barrier sits in the middle of its first round (after the commit of the next stage), so operand reads run across stage boundaries:
+//    first round of stage t:  operand reads of round 1 | commit regs -> buffer (t+1)%3, look up the rows of stage t+2 |
+//                             MFMAs of round 0 | loads of stage t+2 -> regs, barrier | ...
+//  * buffer (t+1)%3 was last read in stage t-2, which every wave left before the barrier of stage t-1;
+//  * stage t+1 is read after the barrier of stage t, which follows every wave's commit.
+// Stage geometry by MT: QS groups with 256 * WPF == QS * 16 * MT units (every thread commits WPF whole units) and an even number
+// of rounds per stage (the two operand register sets then alternate the same way in every stage).
+__host__ __device__ constexpr int pipe_qs(int MT) { return MT == 1 ? 64 : MT == 2 ? 32 : 16; }
+__host__ __device__ constexpr int pipe_wpf(int MT) { return pipe_qs(MT) * 16 * MT / 256; }
+
+template <int MT, int NT, int PF, bool RES, bool CLS = false, bool PIPE = false>   // CLS: several output classes per tile (merged parity classes of a stride-2 data gradient)
+__global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArgs a) {   // PIPE plans run one workgroup per CU (three stage buffers): all 512 registers
+    static_assert(!(PIPE && RES), "the ring is a schedule of the staged-weight path");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     constexpr int COPW = 16 * MT;              // channels per workgroup (one channel split)
+    constexpr int WPF = RES ? 1 : (PIPE ? pipe_wpf(MT) : kWPF);   // float4 weight-prefetch registers per thread
+    constexpr int QSP = pipe_qs(MT);           // PIPE: groups per stage (== a.QS)
     int* tdesc = (int*)lds_raw;                // [kMaxWgTiles][8] per-tile geometry of this workgroup's tile range
     int* ctab = tdesc + kMaxWgTiles * 8;       // [4][4] per output class: first group, groups (padded to rounds), output offset, weight stages
     int* qoff = ctab + 16;                     // [Qpad] patch offset (floats) of group q relative to a pixel's origin
     int* qrow = qoff + a.Qpad;                 // [Qpad] row of the K-grouped pack (tap * C4tot + channel quad), -1: padding group
-    float* wl = (float*)(qrow + a.Qpad);       // resident: [Qpad][COPW][4]; staged: [2][QS][COPW][4]
-    float* patch = wl + (size_t)(RES ? a.Qpad : 2 * a.QS) * COPW * 4;   // [imgs][PR][PC][CP]
+    float* wl = (float*)(qrow + a.Qpad);       // resident: [Qpad][COPW][4]; staged: [2][QS][COPW][4]; PIPE: [3][QS][COPW][4]
+    float* patch = wl + (size_t)(RES ? a.Qpad : (PIPE ? 3 : 2) * a.QS) * COPW * 4;   // [imgs][PR][PC][CP]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, g = lane >> 4;
@@ -137,7 +155,8 @@ __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
         const int t = t0 + mdiv(ql, a.m_kc4, kc4, c4);
         const bool ok = ql < ntc * kc4;
         qoff[q] = ok ? tap_sel(a.tpo, t) + 4 * c4 : 0;
-        qrow[q] = ok ? tap_sel(a.tw, t) * a.C4tot + c4 : -1;
+        // PIPE: the BYTE offset of the pack row (negative = bit 31 = past every buffer descriptor: such a load returns zeros)
+        qrow[q] = ok ? (tap_sel(a.tw, t) * a.C4tot + c4) * (PIPE ? a.WPT * 16 : 1) : (PIPE ? (int)0x80000000 : -1);
     }
     if (CLS && tid < 4) {
         int q0 = 0, nq = 0;
@@ -198,12 +217,12 @@ __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
     }
     stamp();   // P3: weight DMA issued
     // staged: stage s of chunk c0 covers groups [s*QS, s*QS + QS); unit u = tid + i*256 -> (group in stage, channel)
-    float4 wv[RES ? 1 : kWPF];
+    float4 wv[WPF];
     auto w_prefetch = [&](int s_, int c0_, int cls) __attribute__((always_inline)) {
         const int q0 = (CLS ? ctab[cls * 4] : 0) + s_ * a.QS, qend = CLS ? ctab[cls * 4] + ctab[cls * 4 + 1] : a.Qpad;
         const int c4base = c0_ >> 2;
 #pragma unroll
-        for (int i = 0; i < (RES ? 1 : kWPF); ++i) {
+        for (int i = 0; i < WPF; ++i) {
             const int u = tid + i * 256;
             const int qq = u / COPW, c = u - qq * COPW;
             const int q = q0 + qq;
@@ -214,10 +233,51 @@ __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
     auto w_commit = [&](int buf) __attribute__((always_inline)) {
         float* dst = wl + (size_t)buf * a.QS * COPW * 4;
 #pragma unroll
-        for (int i = 0; i < (RES ? 1 : kWPF); ++i) {
+        for (int i = 0; i < WPF; ++i) {
             const int u = tid + i * 256;
             if (u < a.QS * COPW) *(float4*)(dst + (size_t)u * 4) = wv[i];
         }
+    };
+    // ---- PIPE: the prefetch cursor runs two stages ahead of the MFMAs (stage in class-chunk, chunk origin, class, tile; the class's
+    // first group / group count / stage count); the look-up, the loads and the commit are separate steps so that each sits where its
+    // latency is covered (see the schedule above).  Past the workgroup's last stage the cursor simply wraps to the first tile's stages
+    // (two stages of loads nobody reads).
+    int pf_s = 0, pf_c0 = 0, pf_cls = 0, pf_q0 = 0, pf_nq = a.Qpad, pf_nst = a.nstage;
+    int xb = 0;                                // ring buffer of the stage whose MFMAs issue
+    // The look-up only READS the table (its consumers come after a round of MFMAs: no wait in between).  No bounds beyond the table's:
+    // groups past the class's last one (partial last stage) or past the workgroup's last stage fetch rows no MFMA reads.
+    int prow[PIPE ? WPF : 1];
+    auto pf_lookup = [&]() __attribute__((always_inline)) {
+        const int qs0 = pf_q0 + pf_s * QSP;
+#pragma unroll
+        for (int i = 0; i < (PIPE ? WPF : 1); ++i) prow[i] = qrow[min(qs0 + (tid + i * 256) / COPW, a.Qpad - 1)];
+    };
+    auto pf_issue = [&]() __attribute__((always_inline)) {
+        const int cb = (pf_c0 >> 2) * a.WPT * 16;   // chunk origin in the pack, bytes
+#pragma unroll
+        for (int i = 0; i < (PIPE ? WPF : 1); ++i) {
+            const int u = tid + i * 256;
+            const int c = u - (u / COPW) * COPW;
+            wv[i] = buf_load16(rs_w, (prow[i] + cb + (n0 + c) * 16) | (c < wcol_ok ? 0 : (int)0x80000000));
+        }
+        if (++pf_s >= pf_nst) {   // block-uniform
+            pf_s = 0;
+            pf_c0 += a.KC;
+            if (pf_c0 >= a.Cin) {
+                pf_c0 = 0;
+                if (CLS) {   // next class, or the first class of the next tile
+                    if (++pf_cls >= ncls) pf_cls = 0;
+                    pf_q0 = __builtin_amdgcn_readfirstlane(ctab[pf_cls * 4]);
+                    pf_nq = __builtin_amdgcn_readfirstlane(ctab[pf_cls * 4 + 1]);
+                    pf_nst = (pf_nq + QSP - 1) / QSP;
+                }
+            }
+        }
+    };
+    auto pf_commit = [&](int buf) __attribute__((always_inline)) {   // 256 * WPF == QSP * COPW: every unit exists
+        float* dst = wl + (size_t)buf * QSP * COPW * 4;
+#pragma unroll
+        for (int i = 0; i < (PIPE ? WPF : 1); ++i) *(float4*)(dst + (size_t)(tid + i * 256) * 4) = wv[i];
     };
 
     // ---- per-thread patch units (float4 along the channels): tile-invariant pieces ------------------------------------------------
@@ -312,7 +372,20 @@ __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
     }
 
     int st = 0;
-    if (!RES) w_prefetch(0, 0, 0);
+    if (PIPE) {   // stage 0 into buffer 0 (published by the barriers of the first tile), stage 1 into the registers
+        if (CLS) {
+            pf_q0 = __builtin_amdgcn_readfirstlane(ctab[0]);
+            pf_nq = __builtin_amdgcn_readfirstlane(ctab[1]);
+            pf_nst = (pf_nq + QSP - 1) / QSP;
+        }
+        pf_lookup();
+        pf_issue();
+        pf_commit(0);
+        pf_lookup();
+        pf_issue();
+    } else if (!RES) {
+        w_prefetch(0, 0, 0);
+    }
     // the resident weights (LDS-DMA) were in flight during the per-lane set-up above; every wave waits for ITS OWN DMA writes here
     // (a barrier does not wait for vector-memory operations), the barriers of the first tile publish them
     if (RES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -384,6 +457,71 @@ __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
             }
             if (rho < nr) fma4(0);
         };
+        // PIPE: the nrs rounds of one (class, chunk) as ONE pipelined sequence over its weight stages (ring buffers xb, xb+1, ...)
+        auto seq = [&](int q0, int nrs) __attribute__((always_inline)) {
+            constexpr int RPS = QSP / 4;                 // rounds per stage (even)
+            const float* wlane = wl + (size_t)(g * COPW + r16) * 4;
+            float4 bv[2][NT], av[2][MT];
+            int fR = 0, fr = 0, fb = xb;                 // fetch cursor: round of the sequence, round of its stage, ring buffer
+            int po = qoff[q0 + g];                       // patch offset of the round fetched next (looked up one round ahead)
+            auto fetch = [&](int set) __attribute__((always_inline)) {
+                const float* wb = wlane + (size_t)fb * (QSP * COPW * 4) + fr * (16 * COPW);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bv[set][nt] = *(const float4*)(patch + pbase[nt] + po);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) av[set][mt] = *(const float4*)(wb + mt * 64);
+                ++fR;
+                po = qoff[q0 + 4 * min(fR, nrs - 1) + g];
+                if (++fr == RPS) { fr = 0; fb = fb == 2 ? 0 : fb + 1; }
+            };
+            // k component outermost: consecutive MFMAs accumulate into different tiles
+            auto fma4 = [&](int set) __attribute__((always_inline)) {
+#define OCL_KSTEP(E)                                                                                                              \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                           \
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][mt].E, bv[set][nt].E, acc[mt][nt], 0, 0, 0);
+                OCL_KSTEP(x) OCL_KSTEP(y) OCL_KSTEP(z) OCL_KSTEP(w)
+#undef OCL_KSTEP
+            };
+            int xr = 0;                                  // round of its stage of the round whose MFMAs issue next
+            fetch(0);
+            int R = 0;
+            // (the operand reads of round R + 2 are unconditional: past the sequence's last round they fetch registers nobody uses,
+            // from addresses inside the ring and the patch, and the first-round block below stays free of branches)
+            for (; R + 2 <= nrs; R += 2) {
+                fetch(1);
+                if (xr == 0) {                            // block-uniform: first two rounds of a stage, with the stage's bookkeeping
+                    pf_commit(xb == 2 ? 0 : xb + 1);
+                    pf_lookup();
+                    fma4(0);
+                    __builtin_amdgcn_sched_barrier(0);   // the loads (and their table values) stay behind the first round's MFMAs
+                    fetch(0);
+                    pf_issue();
+                    fma4(1);
+                    __builtin_amdgcn_sched_barrier(0);   // (the barrier is not hoisted into the MFMAs: its wait would cover the reads above)
+                    __syncthreads();                     // before the first read of stage t+1 (last round pair of this stage)
+                } else {
+                    fma4(0);
+                    fetch(0);
+                    fma4(1);
+                }
+                xr += 2;
+                if (xr == RPS) { xr = 0; xb = xb == 2 ? 0 : xb + 1; }
+            }
+            if (R < nrs) {   // odd tail: the last round of the class-chunk's last stage
+                if (xr == 0) {
+                    pf_commit(xb == 2 ? 0 : xb + 1);
+                    pf_lookup();
+                    fma4(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    pf_issue();
+                    __syncthreads();
+                } else {
+                    fma4(0);
+                }
+                xr += 1;
+            }
+            if (xr != 0) xb = xb == 2 ? 0 : xb + 1;      // partial last stage
+        };
 
         // output classes (one for an ordinary convolution): with a single channel chunk they share the tile's patch; with several
         // chunks every (class, chunk) stages its own
@@ -413,6 +551,13 @@ __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
                 }
                 rounds(wl + (size_t)ct.x * COPW * 4, ct.x, ct.y);
                 if (fresh) stamp();   // tile + 4: MFMAs issued
+            } else if (PIPE) {
+                if (fresh) {
+                    __syncthreads();   // patch visible (a stage's weights: published by the barrier that follows their commit)
+                    stamp();
+                }
+                seq(ct.x, ct.y >> 2);
+                stamp();   // (ring) MFMAs of the class-chunk issued
             } else {
                 for (int s_ = 0; s_ < ct.w; ++s_, ++st) {
                     w_commit(st & 1);
@@ -502,7 +647,18 @@ __global__ void __launch_bounds__(256, 2) conv_t_kernel(const ConvArgs a) {
 
 #define OCL_CONVT_TILINGS(X) X(1, 1) X(2, 1) X(3, 1) X(4, 1) X(5, 1) X(1, 2) X(2, 2) X(3, 2) X(4, 2) X(5, 2)
 typedef void (*conv_fn_t)(const ConvArgs);
-static conv_fn_t convt_fn(int MT, int NT, int PF, int res, int cls = 0) {
+static conv_fn_t convt_fn(int MT, int NT, int PF, int res, int cls = 0, int pipe = 0) {
+    if (pipe) {   // staged weights through the ring: one pixel tile per wave
+        if (res || NT != 1) return nullptr;
+#define OCL_CASE(M)                                                                                                                  \
+    if (MT == M) {                                                                                                                   \
+        if (PF == 4) return cls ? conv_t_kernel<M, 1, 4, false, true, true> : conv_t_kernel<M, 1, 4, false, false, true>;            \
+        if (PF == 8) return cls ? conv_t_kernel<M, 1, 8, false, true, true> : conv_t_kernel<M, 1, 8, false, false, true>;            \
+    }
+        OCL_CASE(1) OCL_CASE(2) OCL_CASE(3) OCL_CASE(4) OCL_CASE(5)
+#undef OCL_CASE
+        return nullptr;
+    }
     if (cls) {   // output classes: one pixel tile per wave (the class lattices are the small ones)
 #define OCL_CASE(M)                                                                                              \
     if (MT == M && NT == 1) {                                                                                    \
@@ -525,7 +681,7 @@ static conv_fn_t convt_fn(int MT, int NT, int PF, int res, int cls = 0) {
 static int convt_pf_for(int units) { return units <= 1024 ? 4 : 8; }
 
 // ---- conv_t_kernel layout: fills the tile-dependent fields for (MT channel tiles, NT pixel tiles); returns LDS bytes (0: no fit)
-static size_t convt_layout(const ConvGeomDesc& g, ConvArgs& a, int MT, int NT) {
+static size_t convt_layout(const ConvGeomDesc& g, ConvArgs& a, int MT, int NT, bool pipe = false) {
     const int nt16 = cdiv(g.Cout, 16);
     const int splits = cdiv(nt16, MT);
     const int COPW = 16 * MT;
@@ -554,10 +710,11 @@ static size_t convt_layout(const ConvGeomDesc& g, ConvArgs& a, int MT, int NT) {
             for (int c = 0; c < std::max(1, g.ncls); ++c) a.Qpad += (int)round_up((g.ncls > 1 ? g.cls_ntaps[c] : g.ntaps) * (KC / 4), 4);
             const size_t w_all = (size_t)a.Qpad * COPW * 16;
             a.wres = (KC == g.Cin && w_all <= kResidentBytes) ? 1 : 0;
-            a.QS = a.wres ? a.Qpad : std::min(a.Qpad, ((256 * kWPF) / COPW) & ~3);
+            a.pipe = (pipe && !a.wres && NT == 1) ? 1 : 0;   // ring of three stage buffers of pipe_qs(MT) groups (conv_t_kernel<..., PIPE>)
+            a.QS = a.wres ? a.Qpad : a.pipe ? pipe_qs(MT) : std::min(a.Qpad, ((256 * kWPF) / COPW) & ~3);
             a.nstage = cdiv(a.Qpad, a.QS);
             const size_t patch_b = std::max((size_t)a.imgs * a.PR * a.PC * a.CP * 4, (size_t)8 * COPW * 8);
-            bytes = (size_t)kMaxWgTiles * 32 + 64 + (size_t)2 * a.Qpad * 4 + (a.wres ? w_all : (size_t)2 * a.QS * COPW * 16) + patch_b;
+            bytes = (size_t)kMaxWgTiles * 32 + 64 + (size_t)2 * a.Qpad * 4 + (a.wres ? w_all : (size_t)(a.pipe ? 3 : 2) * a.QS * COPW * 16) + patch_b;
             const bool units_ok = a.imgs * a.PR * a.PC * (KC / 4) <= 256 * kConvPatchPF;
             if (units_ok && bytes <= kLdsLimit - 2048 && (bytes <= 100 * 1024 || KC <= 20)) goto found;
         }
@@ -590,8 +747,12 @@ static int plan_conv_t(const ConvGeomDesc& g, ConvPlan* p) {
     if (g.force_MT) MT = g.force_MT;
     if (g.force_NT) NT = g.force_NT;
     if (MT < 1 || MT > 5 || NT < 1 || NT > 2 || MT > nt16) return OCL_ERR_ARG;
-    size_t lds = convt_layout(g, a, MT, NT);
-    if (!lds && NT == 2 && !g.force_NT) { NT = 1; lds = convt_layout(g, a, MT, NT); }
+    // staged-weight schedule: the three-buffer ring is experimental and off unless asked for (plan constant: read once)
+    static const bool env_pipe = [] { const char* e = getenv("OCL_CONV_PIPE"); return e && atoi(e) != 0; }();
+    const bool pipe = g.force_pipe > 0 || (g.force_pipe == 0 && env_pipe);
+    size_t lds = convt_layout(g, a, MT, NT, pipe);
+    if (!lds && NT == 2 && !g.force_NT) { NT = 1; lds = convt_layout(g, a, MT, NT, pipe); }
+    if (!lds && pipe) lds = convt_layout(g, a, MT, NT, false);
     if (!lds) return OCL_ERR_ARG;
     a.cls_pack = std::max(1, g.ncls);
     a.cls_oyx = 0;
@@ -753,7 +914,7 @@ void geom_dgrad(const ConvShape& c, int N, std::vector<ConvGeomDesc>* out, bool 
 }
 
 int launch_conv(const ConvPlan& p, hipStream_t s) {
-    conv_fn_t fn = convt_fn(p.MT, p.NT, convt_pf_for(p.a.imgs * p.a.PR * p.a.PC * (p.a.KC / 4)), p.a.wres, (p.a.cls_pack & 15) > 1);
+    conv_fn_t fn = convt_fn(p.MT, p.NT, convt_pf_for(p.a.imgs * p.a.PR * p.a.PC * (p.a.KC / 4)), p.a.wres, (p.a.cls_pack & 15) > 1, p.a.pipe);
     if (!fn) {
         set_error("launch_conv: no kernel for MT=%d NT=%d", p.MT, p.NT);
         return OCL_ERR_STATE;
@@ -1880,6 +2041,10 @@ int conv_kernels_init() {
         for (int pf = 4; pf <= 8; pf += 4)
             for (int res = 0; res < 2; ++res)
                 OCL_HIP(hipFuncSetAttribute((const void*)convt_fn(m, 1, pf, res, 1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+    for (int m = 1; m <= 5; ++m)
+        for (int pf = 4; pf <= 8; pf += 4)
+            for (int cls = 0; cls < 2; ++cls)
+                OCL_HIP(hipFuncSetAttribute((const void*)convt_fn(m, 1, pf, 0, cls, 1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     done = true;
     return OCL_OK;
 }

@@ -177,11 +177,14 @@ static void bench_geom(const char* lname, const char* kind, ConvGeomDesc g, cons
         double* stats2;
         CK(hipMalloc(&stats2, kStatReps * 8 * 2 * 1024 * 8));
         for (int mt = 0; mt <= (sweep ? 5 : 0); ++mt)
-            for (int nt = (mt ? 1 : 0); nt <= (mt ? 2 : 0); ++nt) {
+            for (int nt = (mt ? 1 : 0); nt <= (mt ? 2 : 0); ++nt)
+            for (int pipe = 0; pipe < 2; ++pipe) {   // staged-weight plans: the two-buffer schedule, then the three-buffer ring
                 ConvGeomDesc gt = g;
                 gt.force_MT = mt; gt.force_NT = nt;
+                gt.force_pipe = pipe ? 1 : -1;
                 ConvPlan pt;
                 if (plan_conv(gt, &pt) != OCL_OK) continue;
+                if (pipe && !pt.a.pipe) continue;
                 CK(hipMemset(out, 0, out_elems * 4));
                 CK(hipMemset(stats2, 0, kStatReps * 8 * 2 * 1024 * 8));
                 double* keep = stats;
@@ -255,8 +258,8 @@ static void bench_geom(const char* lname, const char* kind, ConvGeomDesc g, cons
                     }
                     CK(hipFree(tr));
                 }
-                printf("    conv_t%s MT=%d NT=%d grid=%5dx%d lds=%6zu KC=%3d Q=%3d QS=%3d res=%d  %7.1f us %6.1f TF/s  maxdiff=%.2e statdiff=%.1e%s\n",
-                       mt ? "      " : " (auto)", pt.MT, pt.NT, pt.grid_x, pt.grid_y, pt.lds_bytes, pt.a.KC, pt.a.Qc, pt.a.QS, pt.a.wres, t,
+                printf("    conv_t%s%s MT=%d NT=%d grid=%5dx%d lds=%6zu KC=%3d Q=%3d QS=%3d res=%d  %7.1f us %6.1f TF/s  maxdiff=%.2e statdiff=%.1e%s\n",
+                       mt ? "      " : " (auto)", pipe ? " ring" : "     ", pt.MT, pt.NT, pt.grid_x, pt.grid_y, pt.lds_bytes, pt.a.KC, pt.a.Qc, pt.a.QS, pt.a.wres, t,
                        flops / t * 1e-6, d, ds, (d > 1e-3 || ds > 1e-3) ? "  <-- MISMATCH" : "");
             }
         CK(hipFree(stats2));
@@ -475,6 +478,14 @@ int main(int argc, char** argv) {
                 printf("%-20s %-6s M=%7d N=%3d K=%4d  MT=%d NT=%d grid=%5dx%d lds=%6zu KC=%3d CP=%3d Qpad=%d QS=%d res=%d classes=%d imgs=%d ppi=%d PR=%d PC=%d\n",
                        l.name.c_str(), i == 0 ? "fwd" : "dgrad", all[i].N * all[i].LH * all[i].LW, all[i].Cout, all[i].ntaps * all[i].Cin,
                        p.MT, p.NT, p.grid_x, p.grid_y, p.lds_bytes, p.a.KC, p.a.CP, p.a.Qpad, p.a.QS, p.a.wres, p.a.cls_pack & 15, p.a.imgs, p.a.ppi, p.a.PR, p.a.PC);
+                if (!p.a.wres) {   // staged weights: the plan of the three-buffer ring (OCL_CONV_PIPE=1)
+                    ConvGeomDesc gp = all[i];
+                    gp.force_pipe = 1;
+                    ConvPlan pp;
+                    if (plan_conv(gp, &pp) == OCL_OK && pp.a.pipe)
+                        printf("%-20s %-6s   ring: MT=%d NT=%d grid=%5dx%d lds=%6zu KC=%3d Qpad=%d QS=%d stages=%d\n", "", "", pp.MT, pp.NT, pp.grid_x, pp.grid_y,
+                               pp.lds_bytes, pp.a.KC, pp.a.Qpad, pp.a.QS, pp.a.nstage);
+                }
             }
             WgradPlan wp;
             OK(plan_wgrad(N, c.Hin, c.Win, c.CinT, c.Ho, c.Wo, c.Cout, c.k, c.stride, &wp));
@@ -551,11 +562,14 @@ int main(int argc, char** argv) {
                     float* wT = make_packT(w, dm[0].Cin, dm[0].WPT);
                     std::vector<ConvPlan> p4(4);
                     for (int i = 0; i < 4; ++i) OK(plan_conv(dg[i], &p4[i]));
-                    for (int fmt = 0; fmt <= (sweep ? 5 : 0); ++fmt) {
+                    for (int fmt = 0; fmt <= (sweep ? 5 : 0); ++fmt)
+                    for (int pipe = 0; pipe < 2; ++pipe) {   // merged plan with staged weights: two-buffer schedule, then the ring
                     ConvGeomDesc gm = dm[0];
                     gm.force_MT = fmt;
+                    gm.force_pipe = pipe ? 1 : -1;
                     ConvPlan pm;
                     if (plan_conv(gm, &pm) == OCL_OK) {
+                        if (pipe && !pm.a.pipe) continue;
                         auto run = [&](ConvPlan p, float* o) {
                             p.a.in = bufA; p.a.wT = wT; p.a.out = o; p.a.flags = 0; p.a.stats = stats; p.a.stat_rep_stride = 8 * 2 * 1024;
                             OK(launch_conv(p, 0));
@@ -568,10 +582,10 @@ int main(int argc, char** argv) {
                         const double t4 = time_us([&] { for (auto& p : p4) run(p, bufC); });
                         const double tm = time_us([&] { run(pm, bufB); });
                         const double f = 2.0 * (double)N * c.Ho * c.Wo * c.Cout * c.Cin * 9;
-                        printf("%-20s dgradM%s 4 launches %7.1f us; merged MT=%d NT=%d grid=%5dx%d lds=%6zu KC=%3d Qpad=%3d QS=%3d res=%d  %7.1f us %6.1f TF/s  maxdiff=%.2e%s\n",
-                               l.name.c_str(), fmt ? " " : "*", t4, pm.MT, pm.NT, pm.grid_x, pm.grid_y, pm.lds_bytes, pm.a.KC, pm.a.Qpad, pm.a.QS, pm.a.wres, tm,
+                        printf("%-20s dgradM%s 4 launches %7.1f us; merged%s MT=%d NT=%d grid=%5dx%d lds=%6zu KC=%3d Qpad=%3d QS=%3d res=%d  %7.1f us %6.1f TF/s  maxdiff=%.2e%s\n",
+                               l.name.c_str(), fmt ? " " : "*", t4, pipe ? " (ring)" : "", pm.MT, pm.NT, pm.grid_x, pm.grid_y, pm.lds_bytes, pm.a.KC, pm.a.Qpad, pm.a.QS, pm.a.wres, tm,
                                f / tm * 1e-6, d, d > 1e-3 ? "  <-- MISMATCH" : "");
-                    } else if (!fmt) {
+                    } else if (!fmt && !pipe) {
                         printf("%-20s dgradM  no merged plan: %s\n", l.name.c_str(), ocl_last_error());
                     }
                     }
