@@ -268,9 +268,13 @@ static void bench_geom(const char* lname, const char* kind, ConvGeomDesc g, cons
 }
 
 // ---- calibration: what the f32 MFMA pipe delivers on this box ---------------------------------------------------------
+// __launch_bounds__(256, 2) keeps the accumulators in ArchVGPRs, as in conv_t_kernel.  Without it (round 1 / 2 measurements,
+// profiles/r1_mfma_peak_calibration.txt) the compiler put them in AccVGPRs and, unable to coalesce the tuples across the loop's back
+// edge, added `s_nop 7` + 8 accvgpr copies to EVERY iteration (~70 cycles per 4 or 8 MFMAs): those files UNDERSTATE the 16x16x4
+// rate (32 + 70/4 = 50 and 32 + 70/8 = 41 cycles are exactly what they show); the 32x32x2 loop was clean.
 // rnd (KBENCH_PEAK_RANDOM=1): per-lane pseudo-random operands instead of the few constant values (does the rate depend on the data?)
 template <int NACC, bool LDS>
-__global__ void __launch_bounds__(256) mfma_peak_kernel(float* out, int iters, int rnd) {
+__global__ void __launch_bounds__(256, 2) mfma_peak_kernel(float* out, int iters, int rnd) {
     __shared__ float sm[4096];
     for (int i = threadIdx.x; i < 4096; i += 256) sm[i] = (float)(i & 7) * 0.125f;
     __syncthreads();
@@ -288,7 +292,7 @@ __global__ void __launch_bounds__(256) mfma_peak_kernel(float* out, int iters, i
     const int lane = threadIdx.x & 63;
     for (int i = 0; i < iters; ++i) {
         if (LDS) {   // the conv main loop's operand traffic: one A and one B ds_read_b32 per pair of MFMAs
-            float av[NACC / 2], bv[2];
+            float av[NACC / 2 > 0 ? NACC / 2 : 1], bv[2];
 #pragma unroll
             for (int j = 0; j < NACC / 2; ++j) av[j] = sm[(lane * 22 + j * 64 + i * 4) & 4095];
             bv[0] = sm[(lane + i * 48) & 4095];
@@ -514,6 +518,9 @@ int main(int argc, char** argv) {
     printf("# kbench N=%d groups=%d hw=%d\n", N, groups, hw);
     if (mode == "launch") { launch_probe(); return 0; }
     if (mode == "all" || mode == "peak") {
+        // one / two accumulators: every MFMA (every other one) depends on the one before it -- the price of a dependent issue
+        peak_case<1, false>("regs only", 1, bufB);
+        peak_case<2, false>("regs only", 1, bufB);
         peak_case<4, false>("regs only", 1, bufB);
         peak_case<4, false>("regs only", 2, bufB);
         peak_case<8, false>("regs only", 1, bufB);
