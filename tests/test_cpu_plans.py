@@ -1,0 +1,66 @@
+"""CPU: the convolution / weight-gradient planner (host code of csrc/conv.hip) through `kbench ... plan`, which needs no GPU.
+
+Every layer of Reduced-ResNet18 at the batch sizes the path uses (replay-sized, the SCR step's 220 views, the 410-image eval-mode
+pass, mini-ImageNet's 84x84) must get a tiling that fits the LDS; the experimental three-buffer weight ring (OCL_CONV_PIPE=1,
+DESIGN §4.1 (c)) must only ever replace a staged-weight plan and keep the stage geometry its kernel is compiled for."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+CSRC = os.path.join(ROOT, "online-continual-learning_amd", "csrc")
+KBENCH = os.path.join(CSRC, "kbench")
+LDS_LIMIT = 160 * 1024
+PIPE_QS = {1: 64, 2: 32, 3: 16, 4: 16, 5: 16}      # conv.hip: pipe_qs(MT)
+
+
+def _plan_lines(n, groups, hw):
+    if not os.path.exists(KBENCH):
+        subprocess.run(["make", "-C", CSRC, "kbench"], check=True, stdout=subprocess.DEVNULL)
+    r = subprocess.run([KBENCH, str(n), str(groups), str(hw), "plan"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return r.stdout.splitlines()
+
+
+def _fields(line):
+    return {k: int(v) for k, v in re.findall(r"(\w+)= *(-?\d+)", line)}
+
+
+@pytest.mark.parametrize("n,groups,hw", [(10, 1, 32), (20, 2, 32), (220, 2, 32), (410, 1, 32), (220, 2, 84), (15, 1, 84)])
+def test_every_layer_gets_a_plan_that_fits(n, groups, hw):
+    lines = _plan_lines(n, groups, hw)
+    conv = [l for l in lines if re.search(r"\s(fwd|dgrad)\s", l)]
+    wgrad = [l for l in lines if " wgrad " in l]
+    ring = [l for l in lines if "ring:" in l]
+    assert len(wgrad) == 20 and len(conv) >= 39          # 20 convolutions; forward + at least one data-gradient plan each (not the stem)
+    for l in conv:
+        f = _fields(l)
+        assert 1 <= f["MT"] <= 5 and 1 <= f["NT"] <= 2
+        assert f["lds"] <= LDS_LIMIT - 2048
+        assert f["Qpad"] % 4 == 0 and f["KC"] % 4 == 0
+        if f["res"]:
+            assert f["QS"] == f["Qpad"]                   # resident weights: one "stage" = everything
+        else:
+            assert f["QS"] % 4 == 0 and 0 < f["QS"] <= f["Qpad"]
+        if f["classes"] > 1:
+            assert f["NT"] == 1 and f["classes"] == 4    # merged parity classes: one pixel tile per wave
+    for l in wgrad:
+        f = _fields(l)
+        assert f["lds"] <= LDS_LIMIT - 1024
+        assert f["S"] >= 1 and f["partial"] >= 0
+    # a ring plan follows the staged plan it would replace, keeps its tiling and uses the compiled stage geometry
+    for i, l in enumerate(lines):
+        if "ring:" not in l:
+            continue
+        base, f = _fields(lines[i - 1]), _fields(l)
+        assert base["res"] == 0, "a ring plan for resident weights"
+        assert f["MT"] == base["MT"] and f["NT"] == 1 and f["KC"] == base["KC"] and f["Qpad"] == base["Qpad"]
+        assert f["QS"] == PIPE_QS[f["MT"]]
+        assert f["lds"] <= LDS_LIMIT - 2048
+        # three stage buffers of QS groups x 16*MT channels x 16 bytes instead of two of the two-buffer plan's
+        assert f["lds"] - base["lds"] == 3 * f["QS"] * 16 * f["MT"] * 16 - 2 * base["QS"] * 16 * base["MT"] * 16
+    if hw == 32 and n >= 220:
+        assert ring, "layers 3 - 4 stream their weights at these sizes"
