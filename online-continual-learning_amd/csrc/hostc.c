@@ -91,7 +91,11 @@ static PyObject* py_randperm_check(PyObject* self, PyObject* args) {
     if (!r) { PyBuffer_Release(&sb); return PyErr_NoMemory(); }
     randperm(s, n, r);
     PyObject* out = PyList_New((Py_ssize_t)n);
-    for (long long i = 0; out && i < n; ++i) PyList_SET_ITEM(out, (Py_ssize_t)i, PyLong_FromLongLong(r[i]));
+    for (long long i = 0; out && i < n; ++i) {
+        PyObject* v = PyLong_FromLongLong(r[i]);
+        if (!v) { Py_CLEAR(out); break; }
+        PyList_SET_ITEM(out, (Py_ssize_t)i, v);
+    }
     PyMem_Free(r);
     PyBuffer_Release(&sb);
     return out;
@@ -150,6 +154,7 @@ static PyObject* py_cbrs_sample(PyObject* self, PyObject* args) {
             long long memo_version = 0;
             if (memo_ok && PyLong_Check(key)) {
                 const long long label = PyLong_AsLongLong(key);
+                if (label == -1 && PyErr_Occurred()) PyErr_Clear();   /* a label beyond 64 bits: simply not memoised */
                 if (label >= 0 && label < MEMO_LABELS && label < n_versions) {
                     memo = &g_memo[label];
                     if (memo->members && memo->token == token && memo->version == versions[label] && memo->n == PySet_GET_SIZE(slots)) {
@@ -198,7 +203,7 @@ static PyObject* py_cbrs_sample(PyObject* self, PyObject* args) {
             if (memo) {   /* keep the order for the next draw of this (unchanged) class */
                 int64_t* mm = (int64_t*)PyMem_RawRealloc(memo->members, sizeof(int64_t) * (size_t)(n ? n : 1));
                 if (mm) {   /* (version and token are stamped only with a complete entry) */
-                    memcpy(mm, members, sizeof(int64_t) * (size_t)n);
+                    if (n) memcpy(mm, members, sizeof(int64_t) * (size_t)n);
                     memo->members = mm;
                     memo->n = n;
                     memo->version = memo_version;
