@@ -112,11 +112,16 @@ int upload_small(const void* host, size_t nbytes, void* dev, hipStream_t s) {
     if (!r.base) {
         void* h = nullptr;
         OCL_HIP(hipHostMalloc(&h, kStageSlots * kStageBytes, hipHostMallocDefault));
-        r.base = (char*)h;
         for (int i = 0; i < kStageSlots; ++i) {
-            OCL_HIP(hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming));
+            if (hipEventCreateWithFlags(&r.ev[i], hipEventDisableTiming) != hipSuccess) {   // the ring exists only once it is complete
+                for (int j = 0; j < i; ++j) (void)hipEventDestroy(r.ev[j]);
+                (void)hipHostFree(h);
+                set_error("ocl_upload: cannot create the staging ring's events");
+                return OCL_ERR_HIP;
+            }
             r.used[i] = false;
         }
+        r.base = (char*)h;
     }
     const int k = r.next;
     r.next = (k + 1) % kStageSlots;
