@@ -75,23 +75,19 @@ class ASER_update(object):
         total = ops.col_reduce(values, "sum")
         ranking_dev = ops.argsort_desc(total)
         # the ranking travels to the host asynchronously, behind the scoring kernels and in front of whatever the caller issues next
-        if ranking_dev.is_cuda:
-            if self._pinned is None or self._pinned.numel() < ranking_dev.numel():
-                self._pinned = torch.empty(max(1024, ranking_dev.numel()), dtype=ranking_dev.dtype).pin_memory()
-            ranking_host = self._pinned[:ranking_dev.numel()]
-            ranking_host.copy_(ranking_dev, non_blocking=True)
-            arrived = torch.cuda.Event()
-            arrived.record()
-        else:
-            ranking_host, arrived = ranking_dev, None
+        if self._pinned is None or self._pinned.numel() < ranking_dev.numel():
+            self._pinned = torch.empty(max(1024, ranking_dev.numel()), dtype=ranking_dev.dtype).pin_memory()
+        ranking_host = self._pinned[:ranking_dev.numel()]
+        ranking_host.copy_(ranking_dev, non_blocking=True)
+        arrived = torch.cuda.Event()
+        arrived.record()
         buffer.n_seen_so_far += n_cur
         return (cur_x, cur_y, cur_labels, mem_slots, eval_slots, minor_x, total, (ranking_host, arrived, ranking_dev), knn_order, n_mem, n_cur)
 
     def _replace(self, buffer, cur_x, cur_y, cur_labels, mem_slots, eval_slots, minor_x, total, ranking_dev, knn_order, n_mem, n_cur):
         trace = debug.on()
         ranking_host, arrived, _keep = ranking_dev
-        if arrived is not None:
-            arrived.synchronize()                        # the update's one synchronisation: the ranking has reached the host
+        arrived.synchronize()                            # the update's one synchronisation: the ranking has reached the host
         ranking = ranking_host.clone()
 
         # the n_mem best-valued candidates hold a slot afterwards: batch items among them move in, memory items outside move out
