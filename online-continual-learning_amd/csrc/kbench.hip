@@ -147,6 +147,31 @@ __global__ void conv_ref_kernel(ConvGeomDesc g, const float* __restrict__ in, co
     }
 }
 
+// Reference result for the weight-gradient kernels: one thread per (co, ci, tap), fp64 sum over every output pixel of
+// x[n][oy*stride + dy][ox*stride + dx][ci] * dy[n][oy][ox][co] (independent of the split-K tiling and of the slab reduction).
+__global__ void wgrad_ref_kernel(const float* __restrict__ x, const float* __restrict__ dy, int N, int Hin, int Win, int CinT, int CinReal, int Ho,
+                                 int Wo, int Cout, int k, int stride, float* __restrict__ grad) {
+    const int total = Cout * CinReal * k * k;
+    const int pad = k == 3 ? 1 : 0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int t = i % (k * k);
+        const int ci = (i / (k * k)) % CinReal, co = i / (k * k * CinReal);
+        const int ddy = t / k - pad, ddx = t % k - pad;
+        double acc = 0.0;
+        for (int n = 0; n < N; ++n)
+            for (int oy = 0; oy < Ho; ++oy) {
+                const int iy = oy * stride + ddy;
+                if (iy < 0 || iy >= Hin) continue;
+                for (int ox = 0; ox < Wo; ++ox) {
+                    const int ix = ox * stride + ddx;
+                    if (ix < 0 || ix >= Win) continue;
+                    acc += (double)x[(((int64_t)n * Hin + iy) * Win + ix) * CinT + ci] * (double)dy[(((int64_t)n * Ho + oy) * Wo + ox) * Cout + co];
+                }
+            }
+        grad[i] = (float)acc;   // OIHW: (co * CinReal + ci) * k*k + t
+    }
+}
+
 static void bench_geom(const char* lname, const char* kind, ConvGeomDesc g, const float* in, const float* w, float* out,
                        float* out_ref, double* stats, int flags, double flops, size_t out_elems, bool sweep) {
     float* wT = make_packT(w, g.Cin, g.WPT);
@@ -612,6 +637,7 @@ int main(int argc, char** argv) {
         }
         CK(hipMalloc(&partial, pf * 4 + 4096));
         float* grad = dev_rand(max_w + 4096, 7);
+        float* grad_ref = dev_rand(max_w + 4096, 8);
         for (auto& l : layers) {
             const ConvShape& c = l.s;
             WgradPlan wp;
@@ -620,9 +646,20 @@ int main(int argc, char** argv) {
             const double macs = (double)N * c.Ho * c.Wo * c.Cout * c.Cin * c.k * c.k;
             const double t1 = time_us([&] { OK(launch_wgrad(wp, 0)); });
             const double t2 = time_us([&] { OK(launch_wgrad_reduce(wp, grad, 0, 0)); });
-            printf("%-20s wgrad   M=%4d N=%3d K=%7d  MTW=%d NTW=%d grid=%4dx%3d lds=%6zu KC=%3d S=%4d partial=%6.2f MB  %7.1f us + reduce %6.1f us  %6.1f TF/s\n",
+            // against the reference kernel (relative to the largest gradient entry: the sums run over up to 2e5 products)
+            const int n_w = c.Cout * c.Cin * c.k * c.k;
+            hipLaunchKernelGGL(wgrad_ref_kernel, dim3(cdiv(n_w, 64)), dim3(64), 0, 0, bufA, bufB, N, c.Hin, c.Win, c.CinT, c.Cin, c.Ho, c.Wo, c.Cout, c.k,
+                               c.stride, grad_ref);
+            CK(hipDeviceSynchronize());
+            std::vector<float> hg(n_w), hr(n_w);
+            CK(hipMemcpy(hg.data(), grad, (size_t)n_w * 4, hipMemcpyDeviceToHost));
+            CK(hipMemcpy(hr.data(), grad_ref, (size_t)n_w * 4, hipMemcpyDeviceToHost));
+            double dmax = 0.0, rmax = 0.0;
+            for (int i = 0; i < n_w; ++i) { dmax = fmax(dmax, fabs((double)hg[i] - (double)hr[i])); rmax = fmax(rmax, fabs((double)hr[i])); }
+            const double rel = dmax / (rmax + 1e-30);
+            printf("%-20s wgrad   M=%4d N=%3d K=%7d  MTW=%d NTW=%d grid=%4dx%3d lds=%6zu KC=%3d S=%4d partial=%6.2f MB  %7.1f us + reduce %6.1f us  %6.1f TF/s  reldiff=%.1e%s\n",
                    l.name.c_str(), c.k * c.k * c.CinT, c.Cout, N * c.Ho * c.Wo, wp.MTW, wp.NTW, wp.grid_x, wp.grid_y, wp.lds_bytes, wp.a.KC,
-                   wp.a.S, wp.partial_floats * 4e-6, t1, t2, 2.0 * macs / (t1 + t2) * 1e-6);
+                   wp.a.S, wp.partial_floats * 4e-6, t1, t2, 2.0 * macs / (t1 + t2) * 1e-6, rel, rel > 1e-4 ? "  <-- MISMATCH" : "");
         }
     }
     if (mode == "all" || mode == "bn") {
