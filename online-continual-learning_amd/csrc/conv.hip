@@ -279,6 +279,15 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
 #pragma unroll
         for (int i = 0; i < (PIPE ? WPF : 1); ++i) *(float4*)(dst + (size_t)(tid + i * 256) * 4) = wv[i];
     };
+    if (PIPE) {   // stage 0 is requested here: its latency runs under the per-lane set-up below
+        if (CLS) {
+            pf_q0 = __builtin_amdgcn_readfirstlane(ctab[0]);
+            pf_nq = __builtin_amdgcn_readfirstlane(ctab[1]);
+            pf_nst = (pf_nq + QSP - 1) / QSP;
+        }
+        pf_lookup();
+        pf_issue();
+    }
 
     // ---- per-thread patch units (float4 along the channels): tile-invariant pieces ------------------------------------------------
     int pu_goff[PF], pu_lds[PF], pu_rp[PF];   // global byte offset from the patch origin; LDS float offset; row | pr << 16 (row = il*PR + pr)
@@ -373,13 +382,6 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
 
     int st = 0;
     if (PIPE) {   // stage 0 into buffer 0 (published by the barriers of the first tile), stage 1 into the registers
-        if (CLS) {
-            pf_q0 = __builtin_amdgcn_readfirstlane(ctab[0]);
-            pf_nq = __builtin_amdgcn_readfirstlane(ctab[1]);
-            pf_nst = (pf_nq + QSP - 1) / QSP;
-        }
-        pf_lookup();
-        pf_issue();
         pf_commit(0);
         pf_lookup();
         pf_issue();
