@@ -570,7 +570,9 @@ int main(int argc, char** argv) {
 
     if (mode == "all" || mode == "conv") {
         double tot_auto = 0.0;
+        const char* only = getenv("KBENCH_ONLY");   // substring of the layer names to run (e.g. KBENCH_ONLY=layer3.0)
         for (auto& l : layers) {
+            if (only && l.name.find(only) == std::string::npos) continue;
             const ConvShape& c = l.s;
             const double macs = (double)N * c.Ho * c.Wo * c.Cout * c.Cin * c.k * c.k;
             ConvGeomDesc g;
