@@ -336,6 +336,29 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) s1[mt][e] = s2[mt][e] = 0.f;
+    // PIPE (one workgroup per CU: the AccVGPR half of the register file is free): the statistics partials sit in AccVGPRs while a
+    // tile's MFMA sequence runs -- 8*MT ArchVGPRs fewer live across the loop, which is what lets the register allocator keep the two
+    // operand sets in place instead of squeezing temporaries into them (copies + early waits: profiles/r2_kbench_ring_trace.txt)
+    constexpr bool PARK = PIPE && !CLS;
+    float park[PARK ? 8 * MT : 1];
+    auto park_stats = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(park[PARK ? (mt * 4 + e) * 2 : 0]) : "v"(s1[mt][e]));
+                asm volatile("v_accvgpr_write_b32 %0, %1" : "=a"(park[PARK ? (mt * 4 + e) * 2 + 1 : 0]) : "v"(s2[mt][e]));
+            }
+    };
+    auto unpark_stats = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(s1[mt][e]) : "a"(park[PARK ? (mt * 4 + e) * 2 : 0]));
+                asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(s2[mt][e]) : "a"(park[PARK ? (mt * 4 + e) * 2 + 1 : 0]));
+            }
+    };
     int run_grp = -1;
     auto flush_stats = [&]() __attribute__((always_inline)) {
         // lanes with the same g hold the same channels for 16 different pixels: fp32 butterfly over them (a lane's partial covers at
@@ -465,7 +488,9 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
             const float* wlane = wl + (size_t)(g * COPW + r16) * 4;
             float4 bv[2][NT], av[2][MT];
             int fR = 0, fr = 0, fb = xb;                 // fetch cursor: round of the sequence, round of its stage, ring buffer
-            int po = qoff[q0 + g];                       // patch offset of the round fetched next (looked up one round ahead)
+            // patch offsets of the next two fetches: a table entry is consumed two fetches (one loop iteration, 2 x 4*MT*NT MFMAs) after it
+            // is read, so the wait in front of its address arithmetic never falls on reads that have just been issued
+            int po = qoff[q0 + g], po1 = qoff[q0 + 4 * min(1, nrs - 1) + g];
             auto fetch = [&](int set) __attribute__((always_inline)) {
                 const float* wb = wlane + (size_t)fb * (QSP * COPW * 4) + fr * (16 * COPW);
 #pragma unroll
@@ -473,7 +498,8 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) av[set][mt] = *(const float4*)(wb + mt * 64);
                 ++fR;
-                po = qoff[q0 + 4 * min(fR, nrs - 1) + g];
+                po = po1;
+                po1 = qoff[q0 + 4 * min(fR + 1, nrs - 1) + g];
                 if (++fr == RPS) { fr = 0; fb = fb == 2 ? 0 : fb + 1; }
             };
             // k component outermost: consecutive MFMAs accumulate into different tiles
@@ -484,49 +510,68 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
                 OCL_KSTEP(x) OCL_KSTEP(y) OCL_KSTEP(z) OCL_KSTEP(w)
 #undef OCL_KSTEP
             };
-            int xr = 0;                                  // round of its stage of the round whose MFMAs issue next
-            fetch(0);
-            int R = 0;
-            // (the operand reads of round R + 2 are unconditional: past the sequence's last round they fetch registers nobody uses,
-            // from addresses inside the ring and the patch, and the first-round block below stays free of branches)
-            for (; R + 2 <= nrs; R += 2) {
+            // (operand reads are unconditional: past the sequence's last round they fetch registers nobody uses, from addresses inside the
+            // ring and the patch.  The sched_barriers keep every read where it is written: hoisted into MFMAs that still read the
+            // register set it refills, a read gets other registers and a copy -- with an early wait -- behind it.)
+            auto first_pair = [&]() __attribute__((always_inline)) {   // rounds 0, 1 of a stage, with the stage's bookkeeping
                 fetch(1);
-                if (xr == 0) {                            // block-uniform: first two rounds of a stage, with the stage's bookkeeping
-                    pf_commit(xb == 2 ? 0 : xb + 1);
-                    pf_lookup();
-                    fma4(0);
-                    __builtin_amdgcn_sched_barrier(0);   // the loads (and their table values) stay behind the first round's MFMAs
-                    fetch(0);
-                    pf_issue();
-                    fma4(1);
-                    __builtin_amdgcn_sched_barrier(0);   // (the barrier is not hoisted into the MFMAs: its wait would cover the reads above)
-                    __syncthreads();                     // before the first read of stage t+1 (last round pair of this stage)
-                } else {
-                    fma4(0);
-                    fetch(0);
-                    fma4(1);
-                }
-                xr += 2;
-                if (xr == RPS) { xr = 0; xb = xb == 2 ? 0 : xb + 1; }
+                pf_commit(xb == 2 ? 0 : xb + 1);
+                pf_lookup();
+                fma4(0);
+                __builtin_amdgcn_sched_barrier(0);       // the loads (and their table values) stay behind the first round's MFMAs
+                fetch(0);
+                __builtin_amdgcn_sched_barrier(0);       // operand reads first: they have the whole second round to land
+                pf_issue();
+                fma4(1);
+                __builtin_amdgcn_sched_barrier(0);       // (the barrier is not hoisted into the MFMAs: its wait would cover the reads above)
+                __syncthreads();                         // before the first read of stage t+1 (last round pair of this stage)
+            };
+            auto pair = [&]() __attribute__((always_inline)) {
+                fetch(1);
+                __builtin_amdgcn_sched_barrier(0);
+                fma4(0);
+                __builtin_amdgcn_sched_barrier(0);
+                fetch(0);
+                __builtin_amdgcn_sched_barrier(0);
+                fma4(1);
+                __builtin_amdgcn_sched_barrier(0);
+            };
+            fetch(0);
+            // whole stages: ONE straight-line loop body (RPS rounds), so the two operand sets keep their registers around the back edge
+            const int nfull = nrs / RPS;
+            for (int t = 0; t < nfull; ++t) {
+                first_pair();
+#pragma unroll
+                for (int p = 1; p < RPS / 2; ++p) pair();
+                xb = xb == 2 ? 0 : xb + 1;
             }
-            if (R < nrs) {   // odd tail: the last round of the class-chunk's last stage
-                if (xr == 0) {
-                    pf_commit(xb == 2 ? 0 : xb + 1);
-                    pf_lookup();
-                    fma4(0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    pf_issue();
-                    __syncthreads();
-                } else {
-                    fma4(0);
+            // the class-chunk's last, partial stage (fewer than RPS rounds)
+            const int rem = nrs - nfull * RPS;
+            if (rem > 0) {
+                int R = 0;
+                if (rem >= 2) {
+                    first_pair();
+                    for (R = 2; R + 2 <= rem; R += 2) pair();
                 }
-                xr += 1;
+                if (R < rem) {   // odd last round
+                    if (R == 0) {
+                        pf_commit(xb == 2 ? 0 : xb + 1);
+                        pf_lookup();
+                        fma4(0);
+                        __builtin_amdgcn_sched_barrier(0);
+                        pf_issue();
+                        __syncthreads();
+                    } else {
+                        fma4(0);
+                    }
+                }
+                xb = xb == 2 ? 0 : xb + 1;
             }
-            if (xr != 0) xb = xb == 2 ? 0 : xb + 1;      // partial last stage
         };
 
         // output classes (one for an ordinary convolution): with a single channel chunk they share the tile's patch; with several
         // chunks every (class, chunk) stages its own
+        if (PARK) park_stats();
         for (int cls = 0; cls < ncls; ++cls) {
         const int4 ct = CLS ? *(const int4*)(ctab + cls * 4) : make_int4(0, a.Qpad, 0, a.nstage);   // first group, groups, output offset, weight stages
 #pragma unroll
@@ -584,6 +629,7 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
             }
         }
 
+        if (PARK) unpark_stats();
         // ---- epilogue from registers: lane (r16 = pixel, g) holds channels n0 + mt*16 + 4g .. +3 of its NT pixels -----------------
         // the two flag sets of a training step (forward: statistics only; plain data gradient: nothing) run without per-store branches
         if (flags == EPI_STATS || flags == 0) {
