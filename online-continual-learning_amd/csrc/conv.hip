@@ -829,6 +829,20 @@ static int plan_conv_t(const ConvGeomDesc& g, ConvPlan* p) {
     if (!lds && NT == 2 && !g.force_NT) { NT = 1; lds = convt_layout(g, a, MT, NT, pipe); }
     if (!lds && pipe) lds = convt_layout(g, a, MT, NT, false);
     if (!lds) return OCL_ERR_ARG;
+    if (a.pipe) {
+        // the ring's third buffer can cost the second workgroup per CU; when the launch has more workgroups than CUs that matters more
+        // than the schedule (layer 4's merged data gradient at 220 images: 275 workgroups, 36.7 us with two buffers and two workgroups
+        // per CU, 40.6 us with the ring and one: profiles/r2_kbench_ring_v2.txt) -- keep the two-buffer plan there
+        ConvArgs b = a;
+        const size_t lds2 = convt_layout(g, b, MT, NT, false);
+        const int bpc_ring = (int)std::min<size_t>(2, kLdsLimit / (lds + 512));
+        const int bpc_two = lds2 ? (int)std::min<size_t>(2, kLdsLimit / (lds2 + 512)) : 0;
+        const int64_t wgs = (int64_t)g.groups * (cdiv(a.group_size, a.imgs) * a.tiles_per_img) * a.n_splits;
+        if (bpc_two > bpc_ring && wgs > 256 * bpc_ring) {
+            a = b;
+            lds = lds2;
+        }
+    }
     a.cls_pack = std::max(1, g.ncls);
     a.cls_oyx = 0;
     for (int c = 0; c < std::max(1, g.ncls); ++c) {
