@@ -491,75 +491,52 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
             // patch offsets of the next two fetches: a table entry is consumed two fetches (one loop iteration, 2 x 4*MT*NT MFMAs) after it
             // is read, so the wait in front of its address arithmetic never falls on reads that have just been issued
             int po = qoff[q0 + g], po1 = qoff[q0 + 4 * min(1, nrs - 1) + g];
-            // A round's operand reads come in three pieces, placed in the gaps between the four k-steps (MT*NT MFMAs each) of the round
-            // before: a piece is at most three LDS instructions, issued while the MFMA pipe still works on the k-step in front of it.
-            // piece 0: the NT patch reads + the first weight read; piece 1: weight reads [1, AH); piece 2: the rest, the table
-            // look-up of the fetch after next, and the cursor.
-            constexpr int AH = (MT + 2) / 2;
-            auto fetch_piece = [&](int set, int piece) __attribute__((always_inline)) {
-                const float* wb = wlane + (size_t)fb * (QSP * COPW * 4) + fr * (16 * COPW);
-                if (piece == 0) {
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) bv[set][nt] = *(const float4*)(patch + pbase[nt] + po);
-                    av[set][0] = *(const float4*)wb;
-                } else if (piece == 1) {
-#pragma unroll
-                    for (int mt = 1; mt < AH; ++mt) av[set][mt] = *(const float4*)(wb + mt * 64);
-                } else {
-#pragma unroll
-                    for (int mt = AH; mt < MT; ++mt) av[set][mt] = *(const float4*)(wb + mt * 64);
-                    ++fR;
-                    po = po1;
-                    po1 = qoff[q0 + 4 * min(fR + 1, nrs - 1) + g];
-                    if (++fr == RPS) { fr = 0; fb = fb == 2 ? 0 : fb + 1; }
-                }
-            };
             auto fetch = [&](int set) __attribute__((always_inline)) {
-                fetch_piece(set, 0);
-                fetch_piece(set, 1);
-                fetch_piece(set, 2);
+                const float* wb = wlane + (size_t)fb * (QSP * COPW * 4) + fr * (16 * COPW);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bv[set][nt] = *(const float4*)(patch + pbase[nt] + po);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) av[set][mt] = *(const float4*)(wb + mt * 64);
+                ++fR;
+                po = po1;
+                po1 = qoff[q0 + 4 * min(fR + 1, nrs - 1) + g];
+                if (++fr == RPS) { fr = 0; fb = fb == 2 ? 0 : fb + 1; }
             };
             // k component outermost: consecutive MFMAs accumulate into different tiles
-#define OCL_KSTEP(S, E)                                                                                                           \
-    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                           \
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[S][mt].E, bv[S][nt].E, acc[mt][nt], 0, 0, 0);
-#define OCL_SB __builtin_amdgcn_sched_barrier(0);
             auto fma4 = [&](int set) __attribute__((always_inline)) {
-                OCL_KSTEP(set, x) OCL_KSTEP(set, y) OCL_KSTEP(set, z) OCL_KSTEP(set, w)
+#define OCL_KSTEP(E)                                                                                                              \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                           \
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][mt].E, bv[set][nt].E, acc[mt][nt], 0, 0, 0);
+                OCL_KSTEP(x) OCL_KSTEP(y) OCL_KSTEP(z) OCL_KSTEP(w)
+#undef OCL_KSTEP
             };
-            // one round's MFMAs (set sm) with the reads of the round after next (into set sf) in its gaps.  Every piece is pinned by
-            // scheduling barriers: a read hoisted into MFMAs that still use the register set it refills would get other registers and a
-            // copy -- with an early wait -- behind it (profiles/r2_kbench_ring_trace.txt), a read pushed back loses its cover.
-            auto round_ = [&](int sm, int sf) __attribute__((always_inline)) {
-                OCL_SB fetch_piece(sf, 0); OCL_SB OCL_KSTEP(sm, x)
-                OCL_SB fetch_piece(sf, 1); OCL_SB OCL_KSTEP(sm, y)
-                OCL_SB fetch_piece(sf, 2); OCL_SB OCL_KSTEP(sm, z)
-                OCL_SB OCL_KSTEP(sm, w) OCL_SB
-            };
-            auto pair = [&]() __attribute__((always_inline)) {
-                round_(0, 1);
-                round_(1, 0);
-            };
-            // rounds 0, 1 of a stage with the stage's bookkeeping in the gaps: the commit of stage t+1 (one to two 16-byte writes per
-            // gap), the table reads of stage t+2 before the last k-step of round 0, its loads around the last k-step of round 1 (one
-            // whole round after the table reads), then the stage's barrier
-            constexpr int CH = (WPF + 2) / 2;
-            auto commit_piece = [&](int i0, int i1) __attribute__((always_inline)) {
-                float* dst = wl + (size_t)(xb == 2 ? 0 : xb + 1) * QSP * COPW * 4;
-#pragma unroll
-                for (int i = i0; i < i1; ++i) *(float4*)(dst + (size_t)(tid + i * 256) * 4) = wv[i];
-            };
-            auto first_pair = [&]() __attribute__((always_inline)) {
-                OCL_SB fetch_piece(1, 0); commit_piece(0, 1); OCL_SB OCL_KSTEP(0, x)
-                OCL_SB fetch_piece(1, 1); commit_piece(1, CH); OCL_SB OCL_KSTEP(0, y)
-                OCL_SB fetch_piece(1, 2); commit_piece(CH, WPF); OCL_SB OCL_KSTEP(0, z)
-                OCL_SB pf_lookup(); OCL_SB OCL_KSTEP(0, w)
-                OCL_SB fetch_piece(0, 0); OCL_SB OCL_KSTEP(1, x)
-                OCL_SB fetch_piece(0, 1); OCL_SB OCL_KSTEP(1, y)
-                OCL_SB fetch_piece(0, 2); OCL_SB OCL_KSTEP(1, z)
-                OCL_SB pf_issue(); OCL_KSTEP(1, w)
-                OCL_SB                                   // (the barrier is not hoisted into the MFMAs)
+            // (operand reads are unconditional: past the sequence's last round they fetch registers nobody uses, from addresses inside the
+            // ring and the patch.  The sched_barriers keep every read where it is written: hoisted into MFMAs that still read the
+            // register set it refills, a read gets other registers and a copy -- with an early wait -- behind it.)
+            auto first_pair = [&]() __attribute__((always_inline)) {   // rounds 0, 1 of a stage, with the stage's bookkeeping
+                fetch(1);
+                pf_commit(xb == 2 ? 0 : xb + 1);
+                pf_lookup();
+                fma4(0);
+                __builtin_amdgcn_sched_barrier(0);       // the loads (and their table values) stay behind the first round's MFMAs
+                fetch(0);
+                __builtin_amdgcn_sched_barrier(0);       // operand reads first: they have the whole second round to land
+                pf_issue();
+                fma4(1);
+                __builtin_amdgcn_sched_barrier(0);       // (the barrier is not hoisted into the MFMAs: its wait would cover the reads above)
                 __syncthreads();                         // before the first read of stage t+1 (last round pair of this stage)
+            };
+            // (a variant with each round's reads split into three pieces between the k-steps of the round before -- at most three LDS
+            // instructions per gap -- measured the same: profiles/r2_kbench_ring_v3.txt; the simpler form is kept)
+            auto pair = [&]() __attribute__((always_inline)) {
+                fetch(1);
+                __builtin_amdgcn_sched_barrier(0);
+                fma4(0);
+                __builtin_amdgcn_sched_barrier(0);
+                fetch(0);
+                __builtin_amdgcn_sched_barrier(0);
+                fma4(1);
+                __builtin_amdgcn_sched_barrier(0);
             };
             fetch(0);
             // whole stages: ONE straight-line loop body (RPS rounds), so the two operand sets keep their registers around the back edge
@@ -593,8 +570,6 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
                 xb = xb == 2 ? 0 : xb + 1;
             }
         };
-#undef OCL_KSTEP
-#undef OCL_SB
 
         // output classes (one for an ordinary convolution): with a single channel chunk they share the tile's patch; with several
         // chunks every (class, chunk) stages its own
