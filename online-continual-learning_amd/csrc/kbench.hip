@@ -335,6 +335,38 @@ __global__ void __launch_bounds__(256, 2) mfma_peak_kernel(float* out, int iters
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 
+// VGPR banks of the two source operands.  A and B come from two 16-byte LDS reads (register tuples); SAME pairs component k with
+// component k (the same register index mod 4 when the tuples are 4-aligned -- every conv kernel here does that), otherwise k with
+// (k + 2) % 4.  The ISA decides what is really measured: check `v_mfma ... vA, vB` register numbers.
+template <int NACC, bool SAME>
+__global__ void __launch_bounds__(256, 2) mfma_bank_kernel(float* out, int iters) {
+    __shared__ __attribute__((aligned(16))) float sm[4096];
+    for (int i = threadIdx.x; i < 4096; i += 256) sm[i] = (float)(i & 7) * 0.125f;
+    __syncthreads();
+    f32x4 acc[NACC];
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float4 a = *(const float4*)&sm[(threadIdx.x & 63) * 4], b = *(const float4*)&sm[1024 + (threadIdx.x & 63) * 4];
+    for (int i = 0; i < iters; ++i) {
+#define KB_STEP(E, F) _Pragma("unroll") for (int j = 0; j < NACC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.E, b.F, acc[j], 0, 0, 0);
+        if (SAME) { KB_STEP(x, x) KB_STEP(y, y) KB_STEP(z, z) KB_STEP(w, w) }
+        else      { KB_STEP(x, z) KB_STEP(y, w) KB_STEP(z, x) KB_STEP(w, y) }
+#undef KB_STEP
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) s += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+template <int NACC, bool SAME>
+static void bank_case(int blocks_per_cu, float* out) {
+    const int blocks = 256 * blocks_per_cu, iters = 1000;
+    const double t = time_us([&] { hipLaunchKernelGGL((mfma_bank_kernel<NACC, SAME>), dim3(blocks), dim3(256), 0, 0, out, iters); }, 5, 1);
+    const double flops = (double)blocks * 4 * iters * 4 * NACC * 2.0 * 16 * 16 * 4;
+    printf("peak 16x16x4, A / B in %-20s acc=%d blocks/CU=%d  %7.1f us  %6.1f TF/s  (%.1f cycles/MFMA/SIMD at 2.4 GHz)\n", SAME ? "the same VGPR bank" : "different VGPR banks",
+           NACC, blocks_per_cu, t, flops / t * 1e-6, t * 2400.0 / ((double)iters * 4 * NACC * blocks_per_cu));
+}
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 // 32x32x2 variant: lane l holds A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]
 template <int NACC, bool LDS>
@@ -543,6 +575,11 @@ int main(int argc, char** argv) {
     printf("# kbench N=%d groups=%d hw=%d\n", N, groups, hw);
     if (mode == "launch") { launch_probe(); return 0; }
     if (mode == "all" || mode == "peak") {
+        // the two source operands in the same / in different VGPR banks
+        bank_case<4, true>(1, bufB);
+        bank_case<4, false>(1, bufB);
+        bank_case<5, true>(1, bufB);
+        bank_case<5, false>(1, bufB);
         // one / two accumulators: every MFMA (every other one) depends on the one before it -- the price of a dependent issue
         peak_case<1, false>("regs only", 1, bufB);
         peak_case<2, false>("regs only", 1, bufB);
