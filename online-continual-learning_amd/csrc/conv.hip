@@ -94,13 +94,13 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 constexpr int kMaxWgTiles = 64;                // tile descriptors a workgroup keeps in LDS
 
-// Probe for the next measurement (build with -DOCL_PIPE_BROT=1; PIPE kernels only).  In every conv kernel here both source operands of
+// Probe for the next measurement (build with -DOCL_BROT=1: every conv_t_kernel, results unchanged).  In every conv kernel here both source operands of
 // an MFMA are the SAME component of two 16-byte LDS reads, i.e. registers (4-aligned base + k) of two tuples: the same VGPR bank
 // (register index mod 4).  The register-only calibration, which reaches 33.8 cycles per MFMA where the ring's loop needs 44.9 with
 // nothing else left in its ISA to blame, reads A and B from different banks.  With the probe the patch is stored with every channel quad
 // rotated by two, so its 16-byte read returns [k2, k3, k0, k1] and MFMA k pairs A's register k with B's register (k + 2) % 4.
-#ifndef OCL_PIPE_BROT
-#define OCL_PIPE_BROT 0
+#ifndef OCL_BROT
+#define OCL_BROT 0
 #endif
 
 // PIPE variant of the staged-weight path (experimental, off by default: OCL_CONV_PIPE=1 / ConvGeomDesc::force_pipe).  The two-buffer
@@ -335,11 +335,11 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
 #pragma unroll
         for (int i = 0; i < PF; ++i)
             if ((pu_rp[i] & 0xffff) < nrows) {   // CP % 4 == 0: 16-byte aligned
-#if OCL_PIPE_BROT
-                if (PIPE) *(float4*)(patch + pu_lds[i]) = make_float4(pv[i].z, pv[i].w, pv[i].x, pv[i].y);   // probe: channel quads rotated by two
-                else
-#endif
+#if OCL_BROT
+                *(float4*)(patch + pu_lds[i]) = make_float4(pv[i].z, pv[i].w, pv[i].x, pv[i].y);   // probe: channel quads rotated by two
+#else
                 *(float4*)(patch + pu_lds[i]) = pv[i];
+#endif
             }
     };
     load_patch(0, 0);
@@ -481,10 +481,17 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
+#if OCL_BROT   // probe: the patch holds [k2, k3, k0, k1] per channel quad
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][mt].x, bv[set][nt].z, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][mt].y, bv[set][nt].w, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][mt].z, bv[set][nt].x, acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][mt].w, bv[set][nt].y, acc[mt][nt], 0, 0, 0);
+#else
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][mt].x, bv[set][nt].x, acc[mt][nt], 0, 0, 0);
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][mt].y, bv[set][nt].y, acc[mt][nt], 0, 0, 0);
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][mt].z, bv[set][nt].z, acc[mt][nt], 0, 0, 0);
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][mt].w, bv[set][nt].w, acc[mt][nt], 0, 0, 0);
+#endif
                     }
             };
             fetch(0, 0);
@@ -509,7 +516,7 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
             auto fetch = [&](int set) __attribute__((always_inline)) {
                 const float* wb = wlane + (size_t)fb * (QSP * COPW * 4) + fr * (16 * COPW);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bv[set][nt] = *(const float4*)(patch + pbase[nt] + po);   // (OCL_PIPE_BROT: [k2, k3, k0, k1])
+                for (int nt = 0; nt < NT; ++nt) bv[set][nt] = *(const float4*)(patch + pbase[nt] + po);   // (OCL_BROT: [k2, k3, k0, k1])
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) av[set][mt] = *(const float4*)(wb + mt * 64);
                 ++fR;
@@ -522,7 +529,7 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
 #define OCL_KSTEP(E, F)                                                                                                           \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                           \
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][mt].E, bv[set][nt].F, acc[mt][nt], 0, 0, 0);
-#if OCL_PIPE_BROT   // A.k in register (tuple base + k), B.k in (tuple base + (k + 2) % 4): the two source operands of an MFMA in different VGPR banks
+#if OCL_BROT   // A.k in register (tuple base + k), B.k in (tuple base + (k + 2) % 4): the two source operands of an MFMA in different VGPR banks
                 OCL_KSTEP(x, z) OCL_KSTEP(y, w) OCL_KSTEP(z, x) OCL_KSTEP(w, y)
 #else
                 OCL_KSTEP(x, x) OCL_KSTEP(y, y) OCL_KSTEP(z, z) OCL_KSTEP(w, w)
