@@ -18,6 +18,8 @@ timeout 120 $K 410 1 32 conv 0 > gpurun_out/${T}_kbench_conv_410.txt 2>&1; echo 
 timeout 120 $K 15 1 84 conv 0 > gpurun_out/${T}_kbench_conv_84.txt 2>&1; echo "kbench conv 15x84 rc=$?" >> $L
 #    the weight-gradient kernels against kbench's reference (reldiff / MISMATCH): the baseline for work on their k loop
 timeout 300 $K 220 2 32 wgrad 0 > gpurun_out/${T}_kbench_wgrad_220.txt 2>&1; echo "kbench wgrad 220 rc=$?" >> $L
+#    the VGPR-bank probe (make -C online-continual-learning_amd/csrc kbench_brot beforehand): every layer, both schedules, operands of each MFMA in different banks
+[ -x ${K}_brot ] && { timeout 180 ${K}_brot 220 2 32 conv 0 > gpurun_out/${T}_kbench_conv_220_brot.txt 2>&1; echo "kbench_brot conv 220 rc=$?" >> $L; }
 # 2. the MFMA calibration with a clean loop (1 / 2 / 4 / 8 accumulators: the price of a dependent issue)
 timeout 120 $K 220 2 32 peak > gpurun_out/${T}_kbench_peak.txt 2>&1; echo "kbench peak rc=$?" >> $L
 # 3. phase trace of the ring on the staged layers
