@@ -26,6 +26,8 @@ timeout 120 $K 220 2 32 peak > gpurun_out/${T}_kbench_peak.txt 2>&1; echo "kbenc
 KBENCH_TRACE=1 timeout 120 $K 220 2 32 conv 0 > gpurun_out/${T}_kbench_trace.txt 2>&1; echo "kbench trace rc=$?" >> $L
 # 4. parity with the ring on: network forward / backward and whole steps against the oracle
 OCL_CONV_PIPE=1 timeout 900 python -m pytest tests/ -m gpu -q --tb=short -p no:cacheprovider -x > gpurun_out/${T}_tests_ring.log 2>&1; echo "tests (ring) rc=$?" >> $L
+#    forward outputs and gradients bit-identical with the ring on / off (whole network, five batch shapes)
+OCL_TEST_RING=1 timeout 900 python -m pytest tests/test_gpu_ring.py -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/${T}_tests_ring_equal.log 2>&1; echo "ring == two-buffer rc=$?" >> $L
 # 5. the step, ring off / on
 Q="--no-cpu-baseline --no-also --no-accuracy"
 for w in scr aser er mir; do

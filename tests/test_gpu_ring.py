@@ -1,0 +1,63 @@
+"""GPU (opt-in: OCL_TEST_RING=1): the experimental three-buffer weight ring of the staged convolutions (OCL_CONV_PIPE=1)
+against the default two-buffer schedule on the whole network.  The ring issues the same MFMAs per accumulator in the same order, so
+forward outputs and every gradient must be BIT-IDENTICAL.  The schedule is chosen once per process (when the first plan is made), so
+each side runs in its own interpreter and reports a digest.
+
+Opt-in because the ring has only run in `kbench` so far (per layer, against the reference kernel); the first GPU call of the next
+round runs this file with OCL_TEST_RING=1 before the default is flipped."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(os.environ.get("OCL_TEST_RING") != "1", reason="opt-in: OCL_TEST_RING=1 (experimental schedule)")]
+
+_SCRIPT = r"""
+import hashlib, json, sys
+from types import SimpleNamespace
+import torch
+sys.path.insert(0, %(root)r)
+import ocl_amd
+from ocl_amd.setup_elements import setup_architecture
+out = {}
+for agent, data, head, n, groups in [("SCR", "cifar100", "mlp", 220, 2), ("ER", "cifar100", None, 20, 1), ("ER", "cifar100", None, 7, 1),
+                                     ("ER", "mini_imagenet", None, 6, 1), ("SCR", "cifar100", "mlp", 410, 1)]:
+    torch.manual_seed(5)
+    m = setup_architecture(SimpleNamespace(agent=agent, data=data, head=head))
+    m.max_batch = max(64, n)
+    m = m.cuda()
+    hw = 84 if data == "mini_imagenet" else 32
+    x = torch.randn(n, 3, hw, hw, generator=torch.Generator().manual_seed(n)).cuda()
+    m.train()
+    y = m.forward(x) if groups == 1 else m.forward_views([x[: n // 2], x[n // 2:]])   # two views = two BatchNorm groups in one pass
+    loss = (y * y).mean()
+    m.zero_grad()
+    loss.backward()
+    h = hashlib.sha256()
+    h.update(y.detach().cpu().numpy().tobytes())
+    for p in m.parameters():
+        if p.grad is not None:
+            h.update(p.grad.detach().cpu().numpy().tobytes())
+    out["%%s-%%s-%%d" %% (agent, data, n)] = h.hexdigest()
+print("DIGEST " + json.dumps(out))
+"""
+
+
+def _run(pipe):
+    env = dict(os.environ, OCL_CONV_PIPE=pipe, PYTHONDONTWRITEBYTECODE="1")
+    r = subprocess.run([sys.executable, "-c", _SCRIPT % {"root": ROOT}], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("DIGEST ")][-1]
+    return json.loads(line[len("DIGEST "):])
+
+
+def test_ring_schedule_is_bit_identical_to_the_two_buffer_schedule():
+    off, on = _run("0"), _run("1")
+    assert off.keys() == on.keys() and len(off) == 5
+    for k in off:
+        assert off[k] == on[k], "forward output / gradients differ with OCL_CONV_PIPE=1 for %s" % k
