@@ -64,3 +64,13 @@ def test_every_layer_gets_a_plan_that_fits(n, groups, hw):
         assert f["lds"] - base["lds"] == 3 * f["QS"] * 16 * f["MT"] * 16 - 2 * base["QS"] * 16 * base["MT"] * 16
     if hw == 32 and n >= 220:
         assert ring, "layers 3 - 4 stream their weights at these sizes"
+
+
+def test_ring_schedule_index_model():
+    """The index arithmetic of the ring (prefetch cursor, buffer rotation, operand fetches across stage boundaries) replayed for random
+    plans: scripts/ring_schedule_model.py mirrors the control flow of conv_t_kernel's `seq`."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ring_schedule_model", os.path.join(ROOT, "scripts", "ring_schedule_model.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert m.main(400, seed=7) == 400
