@@ -363,9 +363,10 @@ def main():
     also, acc_res, acc_stream = None, None, None
     with contextlib.redirect_stdout(sys.stderr):   # the agents print like the reference ("buffer has N slots"): stdout carries the JSON only
         res = gpu_leg(args, rank, world, local)
-        if args.workload == "scr" and not args.no_also:
+        # the second headline and the accuracy leg belong to the single-GPU record (the scaling runs time the headline step only)
+        if args.workload == "scr" and not args.no_also and world == 1:
             also = gpu_leg(args, rank, world, local, workload="aser", steps=args.also_steps, warmup=10)
-        if not args.no_accuracy:
+        if not args.no_accuracy and world == 1:
             acc_res, acc_stream = accuracy_leg(args, rank, world, local)
     if rank != 0:
         return
