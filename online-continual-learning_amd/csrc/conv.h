@@ -48,7 +48,7 @@ struct ConvArgs {
     int C4tot, WPT;             // Cin/4 of the whole convolution; row stride (channels) of the pack
     int Qc, Qpad;               // (tap, channel-quad) groups of one channel chunk; rounded up to whole rounds of 4
     int QS, nstage, wres;       // groups per weight stage, stages per chunk; 1: all weights stay in LDS for the workgroup's lifetime
-    int pipe;                   // staged weights through the three-buffer ring (conv_t_kernel<..., PIPE>; experimental, OCL_CONV_PIPE=1)
+    int pipe;                   // staged weights through the three-buffer ring (conv_t_kernel<..., PIPE>; default, OCL_CONV_PIPE=0: two buffers)
     int aligned;                // 1: every tile starts at a lattice row and holds whole rows / whole images: a lane's pixel geometry is tile-invariant
     // output classes sharing one launch (the four parity classes of a stride-2 data gradient: same input window, disjoint taps and
     // output lattices).  cls_pack = ncls | ntaps(class 0) << 4 | ntaps(class 1) << 8 | ...: the taps are listed class by class;
@@ -74,7 +74,7 @@ struct ConvGeomDesc {
     int ntaps;
     int tdy[9], tdx[9], tw[9];
     int force_MT, force_NT, force_bpc;   // 0 = planner's choice (benchmarks / tests)
-    int force_pipe;                      // staged-weight schedule: 0 = environment (OCL_CONV_PIPE, default off), 1 = ring, -1 = two-buffer
+    int force_pipe;                      // staged-weight schedule: 0 = environment (OCL_CONV_PIPE, default on), 1 = ring, -1 = two-buffer
     int WPT;                    // row stride of the K-grouped weight pack (0: the plan's own CoutP)
     int ncls;                   // > 1: output classes of one launch, taps listed class by class
     int cls_ntaps[4], cls_oy[4], cls_ox[4];

@@ -94,16 +94,8 @@ __device__ __forceinline__ float row16_sum(float v) {
 }
 constexpr int kMaxWgTiles = 64;                // tile descriptors a workgroup keeps in LDS
 
-// Probe for the next measurement (build with -DOCL_BROT=1: every conv_t_kernel, results unchanged).  In every conv kernel here both source operands of
-// an MFMA are the SAME component of two 16-byte LDS reads, i.e. registers (4-aligned base + k) of two tuples: the same VGPR bank
-// (register index mod 4).  The register-only calibration, which reaches 33.8 cycles per MFMA where the ring's loop needs 44.9 with
-// nothing else left in its ISA to blame, reads A and B from different banks.  With the probe the patch is stored with every channel quad
-// rotated by two, so its 16-byte read returns [k2, k3, k0, k1] and MFMA k pairs A's register k with B's register (k + 2) % 4.
-#ifndef OCL_BROT
-#define OCL_BROT 0
-#endif
-
-// PIPE variant of the staged-weight path (experimental, off by default: OCL_CONV_PIPE=1 / ConvGeomDesc::force_pipe).  The two-buffer
+// PIPE variant of the staged-weight path (the default since round 3; OCL_CONV_PIPE=0 / ConvGeomDesc::force_pipe = -1 select the
+// two-buffer schedule).  Bit-identical to it on the whole network (tests/test_gpu_ring.py), 18 - 21 % faster per staged launch.  The two-buffer
 // schedule pays, per stage and with one workgroup per CU, a serial section nothing overlaps: the table look-ups and loads of the
 // next stage (4 dependent LDS round trips), the commit, a barrier and the first operand reads (~1900 of ~3800 cycles around 60
 // MFMAs, profiles/r2_kbench_conv_staged_trace.txt).  Here the stages of a (tile, class, chunk) form ONE software-pipelined round
@@ -335,11 +327,7 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
 #pragma unroll
         for (int i = 0; i < PF; ++i)
             if ((pu_rp[i] & 0xffff) < nrows) {   // CP % 4 == 0: 16-byte aligned
-#if OCL_BROT
-                *(float4*)(patch + pu_lds[i]) = make_float4(pv[i].z, pv[i].w, pv[i].x, pv[i].y);   // probe: channel quads rotated by two
-#else
                 *(float4*)(patch + pu_lds[i]) = pv[i];
-#endif
             }
     };
     load_patch(0, 0);
@@ -481,17 +469,10 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) {
-#if OCL_BROT   // probe: the patch holds [k2, k3, k0, k1] per channel quad
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][mt].x, bv[set][nt].z, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][mt].y, bv[set][nt].w, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][mt].z, bv[set][nt].x, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][mt].w, bv[set][nt].y, acc[mt][nt], 0, 0, 0);
-#else
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][mt].x, bv[set][nt].x, acc[mt][nt], 0, 0, 0);
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][mt].y, bv[set][nt].y, acc[mt][nt], 0, 0, 0);
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][mt].z, bv[set][nt].z, acc[mt][nt], 0, 0, 0);
                         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][mt].w, bv[set][nt].w, acc[mt][nt], 0, 0, 0);
-#endif
                     }
             };
             fetch(0, 0);
@@ -516,7 +497,7 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
             auto fetch = [&](int set) __attribute__((always_inline)) {
                 const float* wb = wlane + (size_t)fb * (QSP * COPW * 4) + fr * (16 * COPW);
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bv[set][nt] = *(const float4*)(patch + pbase[nt] + po);   // (OCL_BROT: [k2, k3, k0, k1])
+                for (int nt = 0; nt < NT; ++nt) bv[set][nt] = *(const float4*)(patch + pbase[nt] + po);
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) av[set][mt] = *(const float4*)(wb + mt * 64);
                 ++fR;
@@ -529,11 +510,7 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
 #define OCL_KSTEP(E, F)                                                                                                           \
     _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                           \
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][mt].E, bv[set][nt].F, acc[mt][nt], 0, 0, 0);
-#if OCL_BROT   // A.k in register (tuple base + k), B.k in (tuple base + (k + 2) % 4): the two source operands of an MFMA in different VGPR banks
-                OCL_KSTEP(x, z) OCL_KSTEP(y, w) OCL_KSTEP(z, x) OCL_KSTEP(w, y)
-#else
                 OCL_KSTEP(x, x) OCL_KSTEP(y, y) OCL_KSTEP(z, z) OCL_KSTEP(w, w)
-#endif
 #undef OCL_KSTEP
             };
             // (operand reads are unconditional: past the sequence's last round they fetch registers nobody uses, from addresses inside the
@@ -823,8 +800,8 @@ static int plan_conv_t(const ConvGeomDesc& g, ConvPlan* p) {
     if (g.force_MT) MT = g.force_MT;
     if (g.force_NT) NT = g.force_NT;
     if (MT < 1 || MT > 5 || NT < 1 || NT > 2 || MT > nt16) return OCL_ERR_ARG;
-    // staged-weight schedule: the three-buffer ring is experimental and off unless asked for (plan constant: read once)
-    static const bool env_pipe = [] { const char* e = getenv("OCL_CONV_PIPE"); return e && atoi(e) != 0; }();
+    // staged-weight schedule: the three-buffer ring unless OCL_CONV_PIPE=0 asks for the two-buffer one (plan constant: read once)
+    static const bool env_pipe = [] { const char* e = getenv("OCL_CONV_PIPE"); return !(e && atoi(e) == 0); }();
     const bool pipe = g.force_pipe > 0 || (g.force_pipe == 0 && env_pipe);
     size_t lds = convt_layout(g, a, MT, NT, pipe);
     if (!lds && NT == 2 && !g.force_NT) { NT = 1; lds = convt_layout(g, a, MT, NT, pipe); }

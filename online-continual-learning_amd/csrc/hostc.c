@@ -109,9 +109,26 @@ static PyObject* py_randperm_check(PyObject* self, PyObject* args) {
 typedef struct {
     long long token, version;
     Py_ssize_t n;
+    uint64_t content;   /* order-independent checksum of the set's elements (set_checksum) when the order was recorded */
     int64_t* members;
 } ClassMemo;
 static ClassMemo g_memo[MEMO_LABELS];
+
+/* The memo is keyed on (dict token, per-label version, set size); versions are bumped only by update_cache.  Any other in-place
+ * mutation of a class set (a test, a future plugin, a remove + add of equal size) is caught by comparing an order-independent
+ * checksum of the live set's element hashes (one pass over the hash table: no set copy, no PyLong conversion). */
+static uint64_t set_checksum(PyObject* set) {
+    Py_ssize_t pos = 0;
+    PyObject* item;
+    Py_hash_t h;
+    uint64_t acc = 0;
+    while (_PySet_NextEntry(set, &pos, &item, &h)) {
+        uint64_t x = (uint64_t)h * 0x9E3779B97F4A7C15ull;
+        x ^= x >> 29;
+        acc += x * 0xBF58476D1CE4E5B9ull;
+    }
+    return acc;
+}
 
 /* cbrs_sample(class_index_cache: dict[label -> set[int]], excluded: set | None, n_smp_cls: int, state, out[, versions, token])
  * -> number of picks.  out: writable buffer of int64; raises if it is too small.  versions: int64 buffer indexed by label. */
@@ -157,7 +174,8 @@ static PyObject* py_cbrs_sample(PyObject* self, PyObject* args) {
                 if (label == -1 && PyErr_Occurred()) PyErr_Clear();   /* a label beyond 64 bits: simply not memoised */
                 if (label >= 0 && label < MEMO_LABELS && label < n_versions) {
                     memo = &g_memo[label];
-                    if (memo->members && memo->token == token && memo->version == versions[label] && memo->n == PySet_GET_SIZE(slots)) {
+                    if (memo->members && memo->token == token && memo->version == versions[label] && memo->n == PySet_GET_SIZE(slots) &&
+                        memo->content == set_checksum(slots)) {
                         const Py_ssize_t n = memo->n;
                         if (n > cap) {
                             cap = n * 2 + 64;
@@ -206,6 +224,7 @@ static PyObject* py_cbrs_sample(PyObject* self, PyObject* args) {
                     if (n) memcpy(mm, members, sizeof(int64_t) * (size_t)n);
                     memo->members = mm;
                     memo->n = n;
+                    memo->content = set_checksum(slots);   /* (memo_ok: nothing is excluded, `eligible` has the elements of `slots`) */
                     memo->version = memo_version;
                     memo->token = token;
                 } else {

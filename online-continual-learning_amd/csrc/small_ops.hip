@@ -93,7 +93,9 @@ __global__ void __launch_bounds__(256) sgd_flat(float* __restrict__ p, const flo
 // GSS: max_i cos(mem_i, g) over k stored gradient vectors (utils/buffer/buffer_utils.py:51-56, gss_greedy_update.py:79,121)
 // =====================================================================================================
 // Pass 1: every workgroup owns a contiguous range of the vector; g's chunk stays in registers while the k rows stream past
-// it; fp32 lane partials, fp64 from the wave reduction on, one fp64 atomic per (row, workgroup).  Pass 2: one wave finishes.
+// it; fp32 lane partials, fp64 from the wave reduction on, one fp64 partial per (workgroup, row) in the workspace
+// [blocks][2k + 1] -- no atomics: pass 2 (one wave) sums the workgroups' partials in a fixed order, so the scores (which feed hard
+// decisions: `batch_sim < 0`, multinomial weights, the stored buffer_score) are bit-reproducible run to run.
 constexpr int kCosChunk = 4;   // float4 per thread and pass
 // VEC: rows are 16-byte aligned (n % 4 == 0) -> float4 loads; otherwise scalar loads (any n)
 template <bool VEC>
@@ -109,8 +111,9 @@ __global__ void __launch_bounds__(256) cosine_partial_kernel(const float* __rest
         __syncthreads();
         if (lane == 0) red[wid] = v;
         __syncthreads();
-        if (threadIdx.x == 0) atomicAdd(dst, (red[0] + red[1]) + (red[2] + red[3]));
+        if (threadIdx.x == 0) *dst = (red[0] + red[1]) + (red[2] + red[3]);
     };
+    acc += (int64_t)blockIdx.x * (2 * k + 1);   // this workgroup's row of partials
     for (int r = -1; r < k; ++r) {   // r = -1: |g|^2
         const float* row = r < 0 ? g : mem + (int64_t)r * n;
         float sd = 0.f, sm = 0.f;
@@ -137,13 +140,19 @@ __global__ void __launch_bounds__(256) cosine_partial_kernel(const float* __rest
         }
     }
 }
-__global__ void __launch_bounds__(64) cosine_finish_kernel(const double* __restrict__ acc, int k, float eps, float* __restrict__ out) {
+__global__ void __launch_bounds__(64) cosine_finish_kernel(const double* __restrict__ acc, int nblocks, int k, float eps, float* __restrict__ out) {
     const int lane = threadIdx.x;
     float best = -INFINITY;
-    const float ng = sqrtf((float)acc[2 * k]);
+    const int W = 2 * k + 1;
+    auto total = [&](int col) {   // workgroups in ascending order
+        double t = 0.0;
+        for (int b = 0; b < nblocks; ++b) t += acc[(int64_t)b * W + col];
+        return t;
+    };
+    const float ng = sqrtf((float)total(2 * k));
     for (int r = lane; r < k; r += 64) {
-        const float w = fmaxf(sqrtf((float)acc[2 * r + 1]) * ng, eps);
-        best = fmaxf(best, (float)acc[2 * r] / w);
+        const float w = fmaxf(sqrtf((float)total(2 * r + 1)) * ng, eps);
+        best = fmaxf(best, (float)total(2 * r) / w);
     }
     best = wave_max(best);
     if (lane == 0) out[0] = best;
@@ -885,6 +894,9 @@ int ocl_gather_u8_hwc_to_f32_chw(const uint8_t* src, const int64_t* idx, int64_t
 int ocl_sgd_step(float* params, const float* grads, int64_t n, float lr, float weight_decay, float grad_scale, float* out,
                  void* stream) {
     OCL_REQUIRE(params && grads && n > 0, "sgd: null pointer or n<=0");
+    // a backward whose one-pass BatchNorm timed out has poisoned `grads` with NaN: refuse the step instead of applying it (the word
+    // is read without synchronising; a time-out that lands after this check is caught by the next forward, before its step)
+    if (int arc = ocl::check_async_error("sgd_step")) return arc;
     OCL_REQUIRE((((uintptr_t)params | (uintptr_t)grads | (uintptr_t)out) % 16) == 0, "sgd: pointers must be 16-B aligned");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(PROF_BN, s);
@@ -894,20 +906,20 @@ int ocl_sgd_step(float* params, const float* grads, int64_t n, float lr, float w
     return OCL_OK;
 }
 
-int64_t ocl_cosine_max_workspace_bytes(int k) { return (int64_t)(2 * (int64_t)k + 1) * 8; }
+constexpr int kCosMaxBlocks = 512;
+int64_t ocl_cosine_max_workspace_bytes(int k) { return (int64_t)kCosMaxBlocks * (2 * (int64_t)k + 1) * 8; }
 
 int ocl_cosine_max(const float* mem, int k, int64_t n, const float* g, float eps, float* out, void* workspace, void* stream) {
     OCL_REQUIRE(mem && g && out && workspace && k > 0 && n > 0, "cosine_max: bad arguments");
     hipStream_t s = (hipStream_t)stream;
     ProfScope ps(PROF_KNN, s);
-    OCL_HIP(hipMemsetAsync(workspace, 0, (size_t)ocl_cosine_max_workspace_bytes(k), s));
-    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(512, (n / 4 + 256 * kCosChunk - 1) / (256 * kCosChunk)));
+    const int blocks = (int)std::max<int64_t>(1, std::min<int64_t>(kCosMaxBlocks, (n / 4 + 256 * kCosChunk - 1) / (256 * kCosChunk)));
     if (n % 4 == 0 && ((uintptr_t)mem % 16) == 0 && ((uintptr_t)g % 16) == 0)
         hipLaunchKernelGGL(cosine_partial_kernel<true>, dim3(blocks), dim3(256), 0, s, mem, k, n, g, (double*)workspace);
     else
         hipLaunchKernelGGL(cosine_partial_kernel<false>, dim3(blocks), dim3(256), 0, s, mem, k, n, g, (double*)workspace);
     OCL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(cosine_finish_kernel, dim3(1), dim3(64), 0, s, (const double*)workspace, k, eps, out);
+    hipLaunchKernelGGL(cosine_finish_kernel, dim3(1), dim3(64), 0, s, (const double*)workspace, blocks, k, eps, out);
     OCL_LAUNCH_CHECK();
     return OCL_OK;
 }

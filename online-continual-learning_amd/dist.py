@@ -13,17 +13,22 @@ import torch.distributed as dist
 
 
 def init_from_env(backend=None):
-    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torch.distributed.run). Returns (rank, world, local_rank)."""
+    """Reads RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torch.distributed.run). Returns (rank, world, device index).
+    One rank per GPU over RCCL (backend "nccl"); when the node shows fewer GPUs than local ranks (a 1-GPU test box running
+    `--gpus 2`), the ranks share the devices round-robin and the scalars travel over gloo -- RCCL refuses two ranks on one device."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    shared = n_dev > 0 and local_world > n_dev
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("OCL_DIST_BACKEND") or ("nccl" if n_dev > 0 and not shared else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world)
-    return rank, world, local
+    return rank, world, (local % n_dev if shared else local)
 
 
 def run_seed(base_seed, rank):
@@ -51,6 +56,18 @@ def gather_runs(acc_array, extra=None, device=None):
     stacked = torch.stack(outs).cpu().numpy()
     n = acc.size
     return stacked[:, :n].reshape((-1,) + acc.shape), stacked[:, n:]
+
+
+def gather_scalars(values, device=None):
+    """all_gather of a few float64 scalars per rank -> array [world, len(values)] on every rank (bench: per-rank timings)."""
+    v = torch.from_numpy(np.asarray(values, dtype=np.float64).reshape(-1))
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return v.numpy()[None]
+    if dist.get_backend() == "nccl":
+        v = v.to(device or torch.device("cuda", torch.cuda.current_device()))
+    outs = [torch.empty_like(v) for _ in range(dist.get_world_size())]
+    dist.all_gather(outs, v)
+    return torch.stack(outs).cpu().numpy()
 
 
 def max_over_ranks(value, device=None):

@@ -160,9 +160,23 @@ class ClassBalancedRandomSampling:
         room = max(1, len(cache) * max(0, int(n_smp_cls)))
         if cls._scratch is None or cls._scratch.shape[0] < room:
             cls._scratch = np.empty(room, dtype=np.int64)
-        n = _hostc.cbrs_sample(cache, excl_indices, int(n_smp_cls), state.numpy(), cls._scratch, cls._versions, cls._token)
+        entry_state = state.clone()       # (the C call advances `state` in place)
+        try:
+            n = _hostc.cbrs_sample(cache, excl_indices, int(n_smp_cls), state.numpy(), cls._scratch, cls._versions, cls._token)
+        except Exception:
+            # the C helper gave up midway (a class set holding a non-integer, out of memory): the generator has not been touched yet
+            # -- it is set only below -- so the Python loop replays the draw from the state this call started with
+            torch.set_rng_state(entry_state)
+            cls.invalidate()
+            return cls.draw(n_smp_cls, excl_indices)
         torch.set_rng_state(state)
         return torch.from_numpy(cls._scratch[:n].copy())
+
+    @classmethod
+    def invalidate(cls):
+        """Forget the C helper's memoised iteration orders (call after mutating a class set other than through update_cache; the
+        helper also compares a checksum of every set's elements, so this is belt and braces)."""
+        cls._tracked = None
 
     @classmethod
     def sample(cls, buffer_x, buffer_y, n_smp_cls, excl_indices=None, device="cpu", label_host=None):

@@ -26,6 +26,16 @@ def slow_update(*a, **k):
 
 
 agent.buffer.update = slow_update
+um = agent.buffer.update_method
+if hasattr(um, "update_begin"):   # the pipelined ASER loop bypasses buffer.update (agents/exp_replay.py): slow its entry point as well
+    orig_begin = um.update_begin
+
+    def slow_begin(*a, **k):
+        t = time.perf_counter() + spin_us[0] * 1e-6
+        while time.perf_counter() < t:
+            pass
+        return orig_begin(*a, **k)
+    um.update_begin = slow_begin
 for us in (0, 200, 400, 800, 0):
     spin_us[0] = us
     x, y = bench.synth_u8(n * 10, hw, ncls, 2)

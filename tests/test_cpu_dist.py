@@ -22,10 +22,11 @@ acc = np.tril(rng.random((3, 3)))
 accs, extras = odist.gather_runs(acc, extra=[1.5 + rank, 100 * (rank + 1)])
 tmax = odist.max_over_ranks(0.25 * (rank + 1))
 tsum = odist.sum_over_ranks(10 * (rank + 1))
+per_rank = odist.gather_scalars([2.0 + rank, -1.0 * rank])
 odist.barrier()
 if rank == 0:
     perf = compute_performance(accs)
-    print(json.dumps(dict(shape=list(accs.shape), accs=accs.tolist(), extras=extras.tolist(), tmax=tmax, tsum=tsum, end=perf[0][0])))
+    print(json.dumps(dict(shape=list(accs.shape), accs=accs.tolist(), extras=extras.tolist(), tmax=tmax, tsum=tsum, end=perf[0][0], per_rank=per_rank.tolist())))
 '''
 
 
@@ -50,5 +51,6 @@ def test_two_rank_metric_allgather_gloo(tmp_path):
         assert np.allclose(np.array(res["accs"][r]), exp)
         assert res["extras"][r] == [1.5 + r, 100.0 * (r + 1)]
     assert res["tmax"] == 0.5 and res["tsum"] == 30.0
+    assert res["per_rank"] == [[2.0, -0.0], [3.0, -1.0]]
     exp_end = np.mean([np.mean(np.tril(np.random.default_rng(7 + r).random((3, 3)))[-1]) for r in range(2)])
     assert abs(res["end"] - exp_end) < 1e-12

@@ -302,3 +302,40 @@ def test_class_balanced_draw_memo_follows_the_class_table():
             assert torch.equal(a, b) and torch.equal(sa, sb), step
     finally:
         C.class_index_cache, C.class_num_cache = saved
+
+
+def test_class_balanced_draw_memo_survives_mutations_outside_update_cache():
+    """A class set changed behind update_cache's back (equal size: one slot removed, another added -- versions and sizes unchanged)
+    must not be served from the memoised order: the helper compares a checksum of the live set.  And when the C call raises
+    midway (a non-integer slot), the Python loop replays the draw from the generator state the call started with."""
+    from ocl_amd.plugins import buffer_utils as B
+    assert B._hostc_usable()
+    C = B.ClassBalancedRandomSampling
+    saved = (C.class_index_cache, C.class_num_cache)
+    try:
+        labels = np.random.default_rng(5).integers(0, 12, 400).astype(np.int64)
+        C.class_index_cache = None
+        C.update_cache(labels, 12)
+        torch.manual_seed(3)
+        C.draw_fast(4)                                   # records every class's order
+        for step in range(10):
+            lab = step % 12
+            s = C.class_index_cache[lab]
+            s.remove(next(iter(s)))
+            s.add(1000 + step)                           # same size, same version, other content
+            state = torch.get_rng_state()
+            a, sa = C.draw(4), torch.get_rng_state()
+            torch.set_rng_state(state)
+            b, sb = C.draw_fast(4), torch.get_rng_state()
+            assert torch.equal(a, b) and torch.equal(sa, sb), step
+        C.class_index_cache[20] = {"not a slot"}         # the C helper raises on it, after having drawn for the classes before
+        state = torch.get_rng_state()
+        with pytest.raises(Exception):
+            C.draw(4)
+        s_py = torch.get_rng_state()
+        torch.set_rng_state(state)
+        with pytest.raises(Exception):
+            C.draw_fast(4)                               # falls back to draw(), which fails the same way ...
+        assert torch.equal(torch.get_rng_state(), s_py)  # ... from the same generator state
+    finally:
+        C.class_index_cache, C.class_num_cache = saved

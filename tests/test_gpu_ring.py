@@ -1,10 +1,10 @@
-"""GPU (opt-in: OCL_TEST_RING=1): the experimental three-buffer weight ring of the staged convolutions (OCL_CONV_PIPE=1)
-against the default two-buffer schedule on the whole network.  The ring issues the same MFMAs per accumulator in the same order, so
+"""GPU: the three-buffer weight ring of the staged convolutions (the default schedule) against the two-buffer
+schedule (OCL_CONV_PIPE=0) on the whole network.  The ring issues the same MFMAs per accumulator in the same order, so
 forward outputs and every gradient must be BIT-IDENTICAL.  The schedule is chosen once per process (when the first plan is made), so
 each side runs in its own interpreter and reports a digest.
 
-Opt-in because the ring has only run in `kbench` so far (per layer, against the reference kernel); the first GPU call of the next
-round runs this file with OCL_TEST_RING=1 before the default is flipped."""
+First run of round 3 (gpurun_out r3a): digests equal for all five shapes, the whole `-m gpu` suite green with the ring on; the
+default was flipped after that."""
 import json
 import os
 import subprocess
@@ -14,8 +14,7 @@ import pytest
 
 from conftest import ROOT
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("OCL_TEST_RING") != "1", reason="opt-in: OCL_TEST_RING=1 (experimental schedule)")]
+pytestmark = pytest.mark.gpu
 
 _SCRIPT = r"""
 import hashlib, json, sys
