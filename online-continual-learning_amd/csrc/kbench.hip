@@ -535,13 +535,15 @@ int main(int argc, char** argv) {
             all.insert(all.end(), dg.begin(), dg.end());
             for (size_t i = 0; i < all.size(); ++i) {
                 ConvPlan p;
-                OK(plan_conv(all[i], &p));
+                ConvGeomDesc g2 = all[i];
+                g2.force_pipe = -1;   // this line: resident weights or the two-buffer schedule; the default (ring) plan follows as "ring:"
+                OK(plan_conv(g2, &p));
                 printf("%-20s %-6s M=%7d N=%3d K=%4d  MT=%d NT=%d grid=%5dx%d lds=%6zu KC=%3d CP=%3d Qpad=%d QS=%d res=%d classes=%d imgs=%d ppi=%d PR=%d PC=%d\n",
                        l.name.c_str(), i == 0 ? "fwd" : "dgrad", all[i].N * all[i].LH * all[i].LW, all[i].Cout, all[i].ntaps * all[i].Cin,
                        p.MT, p.NT, p.grid_x, p.grid_y, p.lds_bytes, p.a.KC, p.a.CP, p.a.Qpad, p.a.QS, p.a.wres, p.a.cls_pack & 15, p.a.imgs, p.a.ppi, p.a.PR, p.a.PC);
-                if (!p.a.wres) {   // staged weights: the plan of the three-buffer ring (OCL_CONV_PIPE=1)
+                if (!p.a.wres) {   // staged weights: the default plan, when it is the three-buffer ring
                     ConvGeomDesc gp = all[i];
-                    gp.force_pipe = 1;
+                    gp.force_pipe = 0;
                     ConvPlan pp;
                     if (plan_conv(gp, &pp) == OCL_OK && pp.a.pipe)
                         printf("%-20s %-6s   ring: MT=%d NT=%d grid=%5dx%d lds=%6zu KC=%3d Qpad=%d QS=%d stages=%d\n", "", "", pp.MT, pp.NT, pp.grid_x, pp.grid_y,
