@@ -55,6 +55,10 @@ struct ConvArgs {
     // cls_oyx bit 2c = oy0 of class c, bit 2c+1 = ox0.  One class (ncls = 1): an ordinary convolution.
     int cls_pack, cls_oyx;
     unsigned m_tpg, m_tpi, m_lw, m_ppi, m_kc4, m_pc, m_pr;   // ceil(2^32 / d) of the plan's divisors (exact quotients by one v_mul_hi)
+    // plan-constant tables in device memory (conv_plan_finalize): [ctab 16 | qoff Qpad | qrow Qpad | pad] [tile descriptors ntiles x 8]
+    // [patch units 3 * PF x 256] [output pixels 3 * NT x 256], offsets in ints
+    const int* blob;
+    int off_tdesc, off_pu, off_loc, blob_ints;
     unsigned long long* trace;  // measurement only (kbench): per workgroup 64 s_memtime stamps of wave 0 at the phase boundaries
 };
 
@@ -81,6 +85,12 @@ struct ConvGeomDesc {
 };
 
 int plan_conv(const ConvGeomDesc& g, ConvPlan* p);
+// the plan's tables as the kernel reads them (host arithmetic only); conv_plan_finalize puts them into device memory (one hipMalloc +
+// one blocking copy per plan: plans are made once per batch shape) and sets p->a.blob -- a plan must be finalized before launch_conv;
+// conv_plan_release frees them
+void conv_plan_tables(const ConvPlan& p, std::vector<int>* out);
+int conv_plan_finalize(ConvPlan* p);
+void conv_plan_release(ConvPlan* p);
 
 // One convolution layer of the network (models/resnet.py:10-12,25-30): shapes and weight-pack row strides.
 struct ConvShape {

@@ -107,6 +107,9 @@ constexpr int kMaxWgTiles = 64;                // tile descriptors a workgroup k
 //  * stage t+1 is read after the barrier of stage t, which follows every wave's commit.
 // Stage geometry by MT: QS groups with 256 * WPF == QS * 16 * MT units (every thread commits WPF whole units) and an even number
 // of rounds per stage (the two operand register sets then alternate the same way in every stage).
+#ifndef OCL_RING_SPREAD
+#define OCL_RING_SPREAD 1
+#endif
 __host__ __device__ constexpr int pipe_qs(int MT) { return MT == 1 ? 64 : MT == 2 ? 32 : 16; }
 __host__ __device__ constexpr int pipe_wpf(int MT) { return pipe_qs(MT) * 16 * MT / 256; }
 
@@ -133,71 +136,75 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
     const int t_begin = (int)(((int64_t)blockIdx.x * ntiles_all) / gridDim.x), t_end = (int)(((int64_t)(blockIdx.x + 1) * ntiles_all) / gridDim.x);
     const int nwt = t_end - t_begin;
     if (nwt <= 0) return;
-    const int kc4 = a.KC >> 2;
     const int flags = a.flags;
     int tr_n = 0;
     auto stamp = [&]() __attribute__((always_inline)) {
         if (a.trace && tid == 0 && tr_n < 64) a.trace[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 64 + tr_n++] = __builtin_amdgcn_s_memtime();
     };
     stamp();   // 0: start
-    // ---- tables: K groups, and the geometry of every tile of this workgroup (computed in parallel, read back as plain data) ------
+    // ---- tables ------------------------------------------------------------------------------------------------------------------
+    // Everything that depends only on the plan -- the K-group tables, the geometry of every tile, every thread's patch units and
+    // output pixels -- is computed ONCE on the host when the plan is made (conv_plan_tables) and sits in device memory next to the
+    // plan: the prologue is a handful of independent loads instead of ~8 k cycles of integer arithmetic, dependent LDS round trips
+    // and kernel-argument fetches per launch (profiles/r3_kbench_conv_220_trace.txt; rounds 1 - 2 built them here, per workgroup).
     const int ncls = CLS ? (a.cls_pack & 15) : 1;
-    for (int q = tid; q < a.Qpad; q += 256) {
-        // the class of group q: classes follow each other, each padded to whole rounds of 4 groups
-        int c = 0, q0 = 0, t0 = 0;
-        int ntc = (a.cls_pack >> 4) & 15, nq = (ntc * kc4 + 3) & ~3;
-        while (c + 1 < ncls && q >= q0 + nq) {
-            q0 += nq; t0 += ntc; ++c;
-            ntc = (a.cls_pack >> (4 + 4 * c)) & 15;
-            nq = (ntc * kc4 + 3) & ~3;
+    const int* __restrict__ blob = a.blob;
+    int pu_goff[PF], pu_lds[PF], pu_rp[PF];   // per-thread patch units (float4 along the channels): global byte offset from the patch origin; LDS float offset; row | pr << 16
+    {
+        const int* pu = blob + a.off_pu + tid;
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            pu_goff[i] = pu[(3 * i + 0) * 256];
+            pu_lds[i] = pu[(3 * i + 1) * 256];
+            pu_rp[i] = pu[(3 * i + 2) * 256];
         }
-        const int ql = q - q0;
-        int c4;
-        const int t = t0 + mdiv(ql, a.m_kc4, kc4, c4);
-        const bool ok = ql < ntc * kc4;
-        qoff[q] = ok ? tap_sel(a.tpo, t) + 4 * c4 : 0;
-        // PIPE: the BYTE offset of the pack row (negative = bit 31 = past every buffer descriptor: such a load returns zeros)
-        qrow[q] = ok ? (tap_sel(a.tw, t) * a.C4tot + c4) * (PIPE ? a.WPT * 16 : 1) : (PIPE ? (int)0x80000000 : -1);
     }
-    if (CLS && tid < 4) {
-        int q0 = 0, nq = 0;
-        for (int c = 0; c <= tid && c < ncls; ++c) {
-            q0 += nq;
-            nq = ((((a.cls_pack >> (4 + 4 * c)) & 15) * kc4) + 3) & ~3;
+    // the lane's NT pixels relative to the tile origin (aligned plans: tile-invariant)
+    int loc_p[NT], loc_o[NT], loc_il[NT];
+    {
+        const int* lc = blob + a.off_loc + tid;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            loc_p[nt] = lc[(3 * nt + 0) * 256];
+            loc_o[nt] = lc[(3 * nt + 1) * 256];
+            loc_il[nt] = lc[(3 * nt + 2) * 256];
         }
-        const int oy = (a.cls_oyx >> (2 * tid)) & 1, ox = (a.cls_oyx >> (2 * tid + 1)) & 1;
-        ctab[tid * 4 + 0] = q0;
-        ctab[tid * 4 + 1] = tid < ncls ? nq : 0;
-        ctab[tid * 4 + 2] = (oy * a.Wout + ox) * a.Cout;
-        ctab[tid * 4 + 3] = RES ? 1 : (nq + a.QS - 1) / a.QS;
     }
-    if (tid < nwt) {
-        const int tile = t_begin + tid;
-        int tg_, tp, rem;
-        const int grp = mdiv(tile, a.m_tpg, a.tiles_per_group, tg_);
-        const int ti = mdiv(tg_, a.m_tpi, a.tiles_per_img, tp);
-        const int img0 = grp * a.group_size + ti * a.imgs;
-        const int p0 = tp * a.ppi;
-        const int grp_end = min(a.N, (grp + 1) * a.group_size);
-        const int ly0 = mdiv(p0, a.m_lw, a.LW, rem);
-        const int pend = min(p0 + a.ppi, LP);
-        const int ly1 = mdiv(pend - 1, a.m_lw, a.LW, rem);
-        const int nimg = min(a.imgs, grp_end - img0);
-        const int nrows = a.imgs > 1 ? nimg * a.PR : (ly1 - ly0) * a.is + (a.max_dy - a.min_dy) + 1;
-        const int iy0 = ly0 * a.is + a.min_dy;
-        int* d = tdesc + tid * 8;
-        d[0] = (((img0 * a.Hin + iy0) * a.Win + a.min_dx) * a.Cin) * 4;                         // input byte offset of the patch origin
-        d[1] = iy0;
-        d[2] = nrows;
-        d[3] = ((img0 * a.Hout + ly0 * a.os + a.oy0) * a.Wout + a.ox0) * a.Cout;                  // output element offset of the tile origin
-        d[4] = nimg;
-        d[5] = grp;
-        d[6] = p0;
-        d[7] = img0 | (ly0 << 20);
-    }
-
+    const int4 tile0 = *(const int4*)(blob + a.off_tdesc + (size_t)t_begin * 8);   // first tile: in_base, iy0, nrows, obase (block-uniform)
+    // class table + group tables (contiguous in the blob and in LDS: 16 + 2 * Qpad <= 768 ints, checked by the planner) and this
+    // workgroup's tile descriptors (<= kMaxWgTiles * 8 = 512 ints): predicated loads, requested BEFORE the first patch (loads return in order: the stores
+    // below then wait for the tables only, not for the patch)
+    const int ntab = 16 + 2 * a.Qpad, ntd = nwt * 8;
+    const int* td = blob + a.off_tdesc + (size_t)t_begin * 8;
+    const int tab0 = tid < ntab ? blob[tid] : 0, tab1 = tid + 256 < ntab ? blob[tid + 256] : 0, tab2 = tid + 512 < ntab ? blob[tid + 512] : 0;
+    const int td0 = tid < ntd ? td[tid] : 0, td1 = tid + 256 < ntd ? td[tid + 256] : 0;
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in), rs_w = make_rsrc(a.wT);
-    stamp();   // P1: tables written
+    float4 pv[PF];
+    auto load_patch_d = [&](const int4 d, int c0) __attribute__((always_inline)) {   // d: in_base, iy0, nrows, obase
+        const int base = d.x + c0 * 4;
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int row = pu_rp[i] & 0xffff, pr = pu_rp[i] >> 16;
+            const bool ok = (row < d.z) & ((unsigned)(d.y + pr) < (unsigned)a.Hin) & (pu_goff[i] >= 0);
+            pv[i] = buf_load16(rs_in, ok ? base + pu_goff[i] : kOob);
+        }
+    };
+    auto store_patch = [&](int nrows) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PF; ++i)
+            if ((pu_rp[i] & 0xffff) < nrows) {   // CP % 4 == 0: 16-byte aligned
+                *(float4*)(patch + pu_lds[i]) = pv[i];
+            }
+    };
+    auto load_patch = [&](int k, int c0) __attribute__((always_inline)) { load_patch_d(*(const int4*)(tdesc + k * 8), c0); };
+    load_patch_d(tile0, 0);
+    if (tid < ntab) ctab[tid] = tab0;
+    if (tid + 256 < ntab) ctab[tid + 256] = tab1;
+    if (tid + 512 < ntab) ctab[tid + 512] = tab2;
+    if (tid < ntd) tdesc[tid] = td0;
+    if (tid + 256 < ntd) tdesc[tid + 256] = td1;
+
+    stamp();   // P1: tables written, first patch requested
     __syncthreads();   // tables visible
     stamp();   // P2: barrier
     // ---- weights ----------------------------------------------------------------------------------------------------------
@@ -290,49 +297,6 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
         pf_issue();
     }
 
-    // ---- per-thread patch units (float4 along the channels): tile-invariant pieces ------------------------------------------------
-    int pu_goff[PF], pu_lds[PF], pu_rp[PF];   // global byte offset from the patch origin; LDS float offset; row | pr << 16 (row = il*PR + pr)
-    {
-        int c4, pc;
-        const int pix = mdiv(tid, a.m_kc4, kc4, c4);
-        int row = mdiv(pix, a.m_pc, a.PC, pc);
-#pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            int il = 0, pr = row;
-            if (a.imgs > 1) il = mdiv(row, a.m_pr, a.PR, pr);
-            const int ix = a.min_dx + pc;
-            const bool xok = (ix >= 0) & (ix < a.Win);            // columns of the halo outside the image: zeros (never loaded, still stored)
-            pu_goff[i] = xok ? (((il * a.Hin + pr) * a.Win + pc) * a.Cin + c4 * 4) * 4 : -1;
-            pu_lds[i] = (row * a.PC + pc) * a.CP + c4 * 4;
-            pu_rp[i] = ((il < 128) & (pr < 256)) ? (row | (pr << 16)) : 0x7fff;   // row 0x7fff: past every tile's last row
-            c4 += a.d_c4;
-            pc += a.d_pc;
-            if (c4 >= kc4) { c4 -= kc4; pc += 1; }
-            row += a.d_row;
-            if (pc >= a.PC) { pc -= a.PC; row += 1; }
-        }
-    }
-    float4 pv[PF];
-    auto load_patch = [&](int k, int c0) __attribute__((always_inline)) {
-        const int4 d = *(const int4*)(tdesc + k * 8);   // in_base, iy0, nrows, obase
-        const int base = d.x + c0 * 4;
-#pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            const int row = pu_rp[i] & 0xffff, pr = pu_rp[i] >> 16;
-            const bool ok = (row < d.z) & ((unsigned)(d.y + pr) < (unsigned)a.Hin) & (pu_goff[i] >= 0);
-            pv[i] = buf_load16(rs_in, ok ? base + pu_goff[i] : kOob);
-        }
-    };
-    auto store_patch = [&](int nrows) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < PF; ++i)
-            if ((pu_rp[i] & 0xffff) < nrows) {   // CP % 4 == 0: 16-byte aligned
-                *(float4*)(patch + pu_lds[i]) = pv[i];
-            }
-    };
-    load_patch(0, 0);
-    stamp();   // P4: first patch requested
-
     const int nchunks = a.Cin / a.KC;
     float s1[MT][4], s2[MT][4];   // BatchNorm partial sums of this lane's channels over this workgroup's tiles
 #pragma unroll
@@ -393,19 +357,6 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
         __syncthreads();
     };
 
-    // the lane's NT pixels relative to the tile origin (aligned plans: tile-invariant)
-    int loc_p[NT], loc_o[NT], loc_il[NT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const int r = wave * 16 * NT + nt * 16 + r16;
-        int pl, lx;
-        const int il = mdiv(r, a.m_ppi, a.ppi, pl);
-        const int ly = mdiv(pl, a.m_lw, a.LW, lx);
-        loc_il[nt] = il;
-        loc_p[nt] = ((il * a.PR + ly * a.is) * a.PC + lx * a.is) * a.CP;
-        loc_o[nt] = ((il * a.Hout + ly * a.os) * a.Wout + lx * a.os) * a.Cout;
-    }
-
     int st = 0;
     if (PIPE) {   // stage 0 into buffer 0 (published by the barriers of the first tile), stage 1 into the registers
         pf_commit(0);
@@ -452,36 +403,45 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
         }
         f32x4 acc[MT][NT];
 
-        // operands of round rho+1 are read from LDS while the MFMAs of round rho issue (two register sets)
+        // operands of round rho+1 are read from LDS while the MFMAs of round rho issue (two register sets).  What the ring's loop taught
+        //  applies here too: the patch-offset table entry of a fetch is read TWO fetches ahead (its wait never falls on
+        // reads that have just been issued -- the round-2 loop waited for the entry right behind its ds_read, an exposed LDS round trip
+        // per round pair), the operand reads are unconditional (past the last round they fetch registers nobody uses, from addresses
+        // inside the weight / patch area) so that a round pair is ONE straight-line body, and sched_barriers keep every read in front
+        // of the MFMAs whose register set it does not touch.
         auto rounds = [&](const float* wbase, int q0, int nq) __attribute__((always_inline)) {
             const float* wb = wbase + (size_t)(g * COPW + r16) * 4;
             const int nr = nq >> 2;
             float4 bv[2][NT], av[2][MT];
-            auto fetch = [&](int rho, int set) __attribute__((always_inline)) {
-                const int po = qoff[q0 + 4 * rho + g];
+            int fR = 0;
+            int po = qoff[q0 + g], po1 = qoff[q0 + 4 * min(1, nr - 1) + g];
+            auto fetch = [&](int set) __attribute__((always_inline)) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) bv[set][nt] = *(const float4*)(patch + pbase[nt] + po);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) av[set][mt] = *(const float4*)(wb + (size_t)rho * 4 * COPW * 4 + mt * 64);
+                for (int mt = 0; mt < MT; ++mt) av[set][mt] = *(const float4*)(wb + (size_t)fR * 4 * COPW * 4 + mt * 64);
+                ++fR;
+                po = po1;
+                po1 = qoff[q0 + 4 * min(fR + 1, nr - 1) + g];
             };
-            auto fma4 = [&](int set) __attribute__((always_inline)) {
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) {
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][mt].x, bv[set][nt].x, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][mt].y, bv[set][nt].y, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][mt].z, bv[set][nt].z, acc[mt][nt], 0, 0, 0);
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][mt].w, bv[set][nt].w, acc[mt][nt], 0, 0, 0);
-                    }
+            auto fma4 = [&](int set) __attribute__((always_inline)) {   // k component outermost: consecutive MFMAs accumulate into different tiles
+#define OCL_KSTEP(E)                                                                                                              \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) _Pragma("unroll") for (int nt = 0; nt < NT; ++nt)                           \
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][mt].E, bv[set][nt].E, acc[mt][nt], 0, 0, 0);
+                OCL_KSTEP(x) OCL_KSTEP(y) OCL_KSTEP(z) OCL_KSTEP(w)
+#undef OCL_KSTEP
             };
-            fetch(0, 0);
+            fetch(0);
             int rho = 0;
             for (; rho + 2 <= nr; rho += 2) {
-                fetch(rho + 1, 1);
+                fetch(1);
+                __builtin_amdgcn_sched_barrier(0);
                 fma4(0);
-                if (rho + 2 < nr) fetch(rho + 2, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                fetch(0);
+                __builtin_amdgcn_sched_barrier(0);
                 fma4(1);
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (rho < nr) fma4(0);
         };
@@ -516,16 +476,33 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
             // (operand reads are unconditional: past the sequence's last round they fetch registers nobody uses, from addresses inside the
             // ring and the patch.  The sched_barriers keep every read where it is written: hoisted into MFMAs that still read the
             // register set it refills, a read gets other registers and a copy -- with an early wait -- behind it.)
+            // One wave per SIMD: every instruction that is not an MFMA costs the MFMA stream an issue slot unless it falls into the
+            // 32-cycle shadow of an MFMA (about four per gap, cdna guide: issue slots).  The stage's bookkeeping is ~45 instructions
+            // (commit, table look-ups) plus ~40 (addresses, loads, cursor): left to the scheduler they form two bursts in front of the
+            // first MFMAs of each round (ISA of round 2's build: 45 instructions inside the first k-step of round 0) and the MFMA pipe
+            // starves for ~900 cycles per stage (profiles/r3_kbench_conv_220_trace.txt: 44.9 cycles per MFMA against 33.8).  The
+            // group barriers below spread them: after every MFMA of the round at most kFill other instructions.
+            constexpr int kFillMask = 0x002 | 0x004 | 0x010 | 0x080;   // VALU | SALU | VMEM | DS
+            auto spread = [&](int fill) __attribute__((always_inline)) {
+#pragma unroll
+                for (int i = 0; i < 4 * MT * NT; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    if (fill == 2) __builtin_amdgcn_sched_group_barrier(kFillMask, 2, 0);
+                    else __builtin_amdgcn_sched_group_barrier(kFillMask, 3, 0);
+                }
+            };
             auto first_pair = [&]() __attribute__((always_inline)) {   // rounds 0, 1 of a stage, with the stage's bookkeeping
                 fetch(1);
                 pf_commit(xb == 2 ? 0 : xb + 1);
                 pf_lookup();
                 fma4(0);
+                if (OCL_RING_SPREAD) spread(3);
                 __builtin_amdgcn_sched_barrier(0);       // the loads (and their table values) stay behind the first round's MFMAs
                 fetch(0);
                 __builtin_amdgcn_sched_barrier(0);       // operand reads first: they have the whole second round to land
                 pf_issue();
                 fma4(1);
+                if (OCL_RING_SPREAD) spread(2);
                 __builtin_amdgcn_sched_barrier(0);       // (the barrier is not hoisted into the MFMAs: its wait would cover the reads above)
                 __syncthreads();                         // before the first read of stage t+1 (last round pair of this stage)
             };
@@ -858,7 +835,130 @@ static int plan_conv_t(const ConvGeomDesc& g, ConvPlan* p) {
     p->grid_x = std::max(1, std::min(ntiles, (256 * std::max(1, bpc)) / a.n_splits));
     p->grid_x = std::max(p->grid_x, cdiv(ntiles, kMaxWgTiles));   // a workgroup keeps at most kMaxWgTiles tile descriptors
     p->grid_y = a.n_splits;
+    // layout of the plan's device tables (conv_plan_tables)
+    if (16 + 2 * a.Qpad > 768) return OCL_ERR_ARG;   // the prologue copies the group tables with three predicated loads per thread
+    const int PF = convt_pf_for(a.imgs * a.PR * a.PC * (a.KC / 4));
+    a.off_tdesc = (int)round_up(16 + 2 * a.Qpad, 4);
+    a.off_pu = a.off_tdesc + ntiles * 8;
+    a.off_loc = a.off_pu + 3 * PF * 256;
+    a.blob_ints = a.off_loc + 3 * NT * 256;
+    a.blob = nullptr;
     return OCL_OK;
+}
+
+// ---- the plan's tables: every value the kernel's prologue used to compute per workgroup and per launch -------------------------
+void conv_plan_tables(const ConvPlan& p, std::vector<int>* out) {
+    const ConvArgs& a = p.a;
+    const int NT = p.NT, MT = p.MT;
+    (void)MT;
+    const int kc4 = a.KC / 4;
+    const int ncls = a.cls_pack & 15;
+    const bool pipe = a.pipe != 0, res = a.wres != 0;
+    std::vector<int>& b = *out;
+    b.assign((size_t)a.blob_ints, 0);
+    int* ctab = b.data();
+    int* qoff = ctab + 16;
+    int* qrow = qoff + a.Qpad;
+    // K groups: class by class, each class padded to whole rounds of 4 groups
+    {
+        int q0 = 0, t0 = 0;
+        for (int c = 0; c < ncls; ++c) {
+            const int ntc = (a.cls_pack >> (4 + 4 * c)) & 15, nq = (ntc * kc4 + 3) & ~3;
+            for (int ql = 0; ql < nq; ++ql) {
+                const int q = q0 + ql;
+                const bool ok = ql < ntc * kc4;
+                const int t = t0 + ql / kc4, c4 = ql % kc4;
+                qoff[q] = ok ? a.tpo[t] + 4 * c4 : 0;
+                // ring: the BYTE offset of the pack row (bit 31 = past every buffer descriptor: such a load returns zeros)
+                qrow[q] = ok ? (a.tw[t] * a.C4tot + c4) * (pipe ? a.WPT * 16 : 1) : (pipe ? (int)0x80000000 : -1);
+            }
+            if (ncls > 1) {
+                const int oy = (a.cls_oyx >> (2 * c)) & 1, ox = (a.cls_oyx >> (2 * c + 1)) & 1;
+                ctab[c * 4 + 0] = q0;
+                ctab[c * 4 + 1] = nq;
+                ctab[c * 4 + 2] = (oy * a.Wout + ox) * a.Cout;
+                ctab[c * 4 + 3] = res ? 1 : (nq + a.QS - 1) / a.QS;
+            }
+            q0 += nq; t0 += ntc;
+        }
+        if (ncls > 1)
+            for (int c = ncls; c < 4; ++c) ctab[c * 4 + 0] = q0;   // (classes past the last: first group = end, no groups)
+    }
+    // tile descriptors
+    const int LP = a.LH * a.LW;
+    const int ntiles = a.groups * a.tiles_per_group;
+    int* td = b.data() + a.off_tdesc;
+    for (int tile = 0; tile < ntiles; ++tile) {
+        const int grp = tile / a.tiles_per_group, tg_ = tile % a.tiles_per_group;
+        const int ti = tg_ / a.tiles_per_img, tp = tg_ % a.tiles_per_img;
+        const int img0 = grp * a.group_size + ti * a.imgs;
+        const int p0 = tp * a.ppi;
+        const int grp_end = std::min(a.N, (grp + 1) * a.group_size);
+        const int ly0 = p0 / a.LW;
+        const int pend = std::min(p0 + a.ppi, LP);
+        const int ly1 = (pend - 1) / a.LW;
+        const int nimg = std::min(a.imgs, grp_end - img0);
+        const int nrows = a.imgs > 1 ? nimg * a.PR : (ly1 - ly0) * a.is + (a.max_dy - a.min_dy) + 1;
+        const int iy0 = ly0 * a.is + a.min_dy;
+        int* d = td + (size_t)tile * 8;
+        d[0] = (((img0 * a.Hin + iy0) * a.Win + a.min_dx) * a.Cin) * 4;                // input byte offset of the patch origin
+        d[1] = iy0;
+        d[2] = nrows;
+        d[3] = ((img0 * a.Hout + ly0 * a.os + a.oy0) * a.Wout + a.ox0) * a.Cout;         // output element offset of the tile origin
+        d[4] = nimg;
+        d[5] = grp;
+        d[6] = p0;
+        d[7] = img0 | (ly0 << 20);
+    }
+    // per-thread patch units: unit u = tid + i * 256 of the flat [row][pc][c4] patch
+    const int PF = (a.off_loc - a.off_pu) / (3 * 256);
+    int* pu = b.data() + a.off_pu;
+    for (int tid = 0; tid < 256; ++tid) {
+        const int pix = tid / kc4;
+        int c4 = tid % kc4, row = pix / a.PC, pc = pix % a.PC;
+        for (int i = 0; i < PF; ++i) {
+            int il = 0, pr = row;
+            if (a.imgs > 1) { il = row / a.PR; pr = row % a.PR; }
+            const int ix = a.min_dx + pc;
+            const bool xok = ix >= 0 && ix < a.Win;               // columns of the halo outside the image: zeros (never loaded, still stored)
+            pu[(3 * i + 0) * 256 + tid] = xok ? (((il * a.Hin + pr) * a.Win + pc) * a.Cin + c4 * 4) * 4 : -1;
+            pu[(3 * i + 1) * 256 + tid] = (row * a.PC + pc) * a.CP + c4 * 4;
+            pu[(3 * i + 2) * 256 + tid] = (il < 128 && pr < 256) ? (row | (pr << 16)) : 0x7fff;   // row 0x7fff: past every tile's last row
+            c4 += a.d_c4;
+            pc += a.d_pc;
+            if (c4 >= kc4) { c4 -= kc4; pc += 1; }
+            row += a.d_row;
+            if (pc >= a.PC) { pc -= a.PC; row += 1; }
+        }
+    }
+    // per-lane output pixels relative to the tile origin
+    int* lc = b.data() + a.off_loc;
+    for (int tid = 0; tid < 256; ++tid) {
+        const int wave = tid >> 6, r16 = tid & 15;
+        for (int nt = 0; nt < NT; ++nt) {
+            const int r = wave * 16 * NT + nt * 16 + r16;
+            const int il = r / a.ppi, pl = r % a.ppi;
+            const int ly = pl / a.LW, lx = pl % a.LW;
+            lc[(3 * nt + 0) * 256 + tid] = ((il * a.PR + ly * a.is) * a.PC + lx * a.is) * a.CP;
+            lc[(3 * nt + 1) * 256 + tid] = ((il * a.Hout + ly * a.os) * a.Wout + lx * a.os) * a.Cout;
+            lc[(3 * nt + 2) * 256 + tid] = il;
+        }
+    }
+}
+
+int conv_plan_finalize(ConvPlan* p) {
+    if (p->a.blob) return OCL_OK;
+    std::vector<int> t;
+    conv_plan_tables(*p, &t);
+    int* d = nullptr;
+    OCL_HIP(hipMalloc((void**)&d, t.size() * sizeof(int)));
+    OCL_HIP(hipMemcpy(d, t.data(), t.size() * sizeof(int), hipMemcpyHostToDevice));
+    p->a.blob = d;
+    return OCL_OK;
+}
+void conv_plan_release(ConvPlan* p) {
+    if (p->a.blob) (void)hipFree((void*)p->a.blob);
+    p->a.blob = nullptr;
 }
 
 int plan_conv(const ConvGeomDesc& g, ConvPlan* p) {
@@ -984,6 +1084,10 @@ int launch_conv(const ConvPlan& p, hipStream_t s) {
     conv_fn_t fn = convt_fn(p.MT, p.NT, convt_pf_for(p.a.imgs * p.a.PR * p.a.PC * (p.a.KC / 4)), p.a.wres, (p.a.cls_pack & 15) > 1, p.a.pipe);
     if (!fn) {
         set_error("launch_conv: no kernel for MT=%d NT=%d", p.MT, p.NT);
+        return OCL_ERR_STATE;
+    }
+    if (!p.a.blob) {
+        set_error("launch_conv: plan without device tables (conv_plan_finalize)");
         return OCL_ERR_STATE;
     }
     ProfScope ps(PROF_CONV, s);

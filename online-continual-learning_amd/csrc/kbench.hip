@@ -210,6 +210,7 @@ static void bench_geom(const char* lname, const char* kind, ConvGeomDesc g, cons
                 ConvPlan pt;
                 if (plan_conv(gt, &pt) != OCL_OK) continue;
                 if (pipe && !pt.a.pipe) continue;
+                OK(conv_plan_finalize(&pt));   // (kbench leaks the plans' device tables: a measurement tool that exits right after)
                 CK(hipMemset(out, 0, out_elems * 4));
                 CK(hipMemset(stats2, 0, kStatReps * 8 * 2 * 1024 * 8));
                 double* keep = stats;
@@ -365,6 +366,84 @@ static void bank_case(int blocks_per_cu, float* out) {
     const double flops = (double)blocks * 4 * iters * 4 * NACC * 2.0 * 16 * 16 * 4;
     printf("peak 16x16x4, A / B in %-20s acc=%d blocks/CU=%d  %7.1f us  %6.1f TF/s  (%.1f cycles/MFMA/SIMD at 2.4 GHz)\n", SAME ? "the same VGPR bank" : "different VGPR banks",
            NACC, blocks_per_cu, t, flops / t * 1e-6, t * 2400.0 / ((double)iters * 4 * NACC * blocks_per_cu));
+}
+
+// ---- v_mfma_f32_4x4x1_16b_f32 (sixteen independent 4x4 outer products per instruction): the shape that would carry the 20-channel
+// layers without padding the channels to 32 (blocks = 16 groups of 4 pixels, A = 4 output channels broadcast to every block, B = one
+// input value per pixel lane).  Rate with NACC independent accumulators, registers only; and with the operand traffic such a
+// convolution would have (per (tap, channel-quad) group: 5 A reads + NT B reads of 16 bytes for 20 * NT MFMAs).
+template <int NACC>
+__global__ void __launch_bounds__(256, 2) mfma_peak4_kernel(float* out, int iters) {
+    f32x4 acc[NACC];
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float a = (float)(threadIdx.x & 3) * 0.25f, b = 1.0f + (float)(threadIdx.x & 7);
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int j = 0; j < NACC; ++j) acc[j] = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, acc[j], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NACC; ++j) s += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+template <int NT>
+__global__ void __launch_bounds__(256, 2) mfma_peak4_lds_kernel(float* out, int iters) {
+    __shared__ __attribute__((aligned(16))) float sm[8192];
+    for (int i = threadIdx.x; i < 8192; i += 256) sm[i] = (float)(i & 7) * 0.125f;
+    __syncthreads();
+    f32x4 acc[5][NT];
+#pragma unroll
+    for (int m = 0; m < 5; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int lane = threadIdx.x & 63;
+    float4 av[2][5], bv[2][NT];
+    auto fetch = [&](int set, int i) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < 5; ++m) av[set][m] = *(const float4*)&sm[((i * 20 + m * 4 + (lane & 3)) * 4) & 4095];          // 4 distinct addresses per read (broadcast)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) bv[set][n] = *(const float4*)&sm[4096 + ((lane * 5 + n * 320 + i * 4) * 4 & 4095)];    // one pixel per lane, odd 16-byte stride
+    };
+    auto fma = [&](int set) __attribute__((always_inline)) {
+#define KB_STEP(E) _Pragma("unroll") for (int m = 0; m < 5; ++m) _Pragma("unroll") for (int n = 0; n < NT; ++n) \
+        acc[m][n] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[set][m].E, bv[set][n].E, acc[m][n], 0, 0, 0);
+        KB_STEP(x) KB_STEP(y) KB_STEP(z) KB_STEP(w)
+#undef KB_STEP
+    };
+    fetch(0, 0);
+    for (int i = 0; i < iters; i += 2) {
+        fetch(1, i + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        fma(0);
+        __builtin_amdgcn_sched_barrier(0);
+        fetch(0, i + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        fma(1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int m = 0; m < 5; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) s += acc[m][n][0] + acc[m][n][1] + acc[m][n][2] + acc[m][n][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+template <int NACC>
+static void peak4_case(int blocks_per_cu, float* out) {
+    const int blocks = 256 * blocks_per_cu, iters = 2000;
+    const double t = time_us([&] { hipLaunchKernelGGL((mfma_peak4_kernel<NACC>), dim3(blocks), dim3(256), 0, 0, out, iters); }, 5, 1);
+    const double flops = (double)blocks * 4 * iters * NACC * 2.0 * 4 * 4 * 16;
+    printf("peak 4x4x1_16b regs only              acc=%2d blocks/CU=%d  %7.1f us  %6.1f TF/s  (%.1f cycles/MFMA/SIMD at 2.4 GHz)\n", NACC, blocks_per_cu, t,
+           flops / t * 1e-6, t * 2400.0 / ((double)iters * NACC * blocks_per_cu));
+}
+template <int NT>
+static void peak4_lds_case(int blocks_per_cu, float* out) {
+    const int blocks = 256 * blocks_per_cu, iters = 400;
+    const double t = time_us([&] { hipLaunchKernelGGL((mfma_peak4_lds_kernel<NT>), dim3(blocks), dim3(256), 0, 0, out, iters); }, 5, 1);
+    const double flops = (double)blocks * 4 * iters * 20 * NT * 2.0 * 4 * 4 * 16;
+    printf("peak 4x4x1_16b 5 A + %d B reads / %3d MFMAs    blocks/CU=%d  %7.1f us  %6.1f TF/s  (%.1f cycles/MFMA/SIMD at 2.4 GHz)\n", NT, 20 * NT, blocks_per_cu, t,
+           flops / t * 1e-6, t * 2400.0 / ((double)iters * 20 * NT * blocks_per_cu));
 }
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -576,6 +655,11 @@ int main(int argc, char** argv) {
     CK(hipMemset(stats, 0, kStatReps * 8 * 2 * 1024 * 8));
     printf("# kbench N=%d groups=%d hw=%d\n", N, groups, hw);
     if (mode == "launch") { launch_probe(); return 0; }
+    if (mode == "peak4") {
+        peak4_case<4>(1, bufB); peak4_case<10>(1, bufB); peak4_case<20>(1, bufB); peak4_case<20>(2, bufB);
+        peak4_lds_case<2>(1, bufB); peak4_lds_case<2>(2, bufB); peak4_lds_case<4>(1, bufB); peak4_lds_case<4>(2, bufB);
+        return 0;
+    }
     if (mode == "all" || mode == "peak") {
         // the two source operands in the same / in different VGPR banks
         bank_case<4, true>(1, bufB);
@@ -634,7 +718,7 @@ int main(int argc, char** argv) {
                     const size_t out_elems = (size_t)N * c.Hin * c.Win * c.Cin;
                     float* wT = make_packT(w, dm[0].Cin, dm[0].WPT);
                     std::vector<ConvPlan> p4(4);
-                    for (int i = 0; i < 4; ++i) OK(plan_conv(dg[i], &p4[i]));
+                    for (int i = 0; i < 4; ++i) { OK(plan_conv(dg[i], &p4[i])); OK(conv_plan_finalize(&p4[i])); }
                     for (int fmt = 0; fmt <= (sweep ? 5 : 0); ++fmt)
                     for (int pipe = 0; pipe < 2; ++pipe) {   // merged plan with staged weights: two-buffer schedule, then the ring
                     ConvGeomDesc gm = dm[0];
@@ -643,6 +727,7 @@ int main(int argc, char** argv) {
                     ConvPlan pm;
                     if (plan_conv(gm, &pm) == OCL_OK) {
                         if (pipe && !pm.a.pipe) continue;
+                        OK(conv_plan_finalize(&pm));
                         auto run = [&](ConvPlan p, float* o) {
                             p.a.in = bufA; p.a.wT = wT; p.a.out = o; p.a.flags = 0; p.a.stats = stats; p.a.stat_rep_stride = 8 * 2 * 1024;
                             OK(launch_conv(p, 0));

@@ -351,6 +351,7 @@ static int get_plans(ocl_net* n, int N, int groups, PlanSet** out) {
         geom_fwd(c, N, groups, &g);
         int rc = plan_conv(g, &ps.fwd[i]);
         if (rc != OCL_OK) return rc;
+        if ((rc = conv_plan_finalize(&ps.fwd[i])) != OCL_OK) return rc;
         n->pack_need_fwd |= PACK_TF;
         if (c.Cin != 3) {
             // stride-2 3x3: the four parity classes as one launch where conv_t_kernel can take them (OCL_DGRAD_MERGE=0: four launches)
@@ -365,6 +366,7 @@ static int get_plans(ocl_net* n, int N, int groups, PlanSet** out) {
                 ConvPlan p;
                 rc = plan_conv(q, &p);
                 if (rc != OCL_OK) return rc;
+                if ((rc = conv_plan_finalize(&p)) != OCL_OK) return rc;
                 ps.dgrad[i].push_back(p);
                 n->pack_need_bwd |= PACK_TD;
             }
@@ -536,6 +538,11 @@ void ocl_net_destroy(ocl_net* net) {
     if (net->ev_join) (void)hipEventDestroy(net->ev_join);
     if (net->ev_fork) (void)hipEventDestroy(net->ev_fork);
     if (net->s2) (void)hipStreamDestroy(net->s2);
+    for (auto& kv : net->plans) {   // the plans' device tables
+        for (auto& p : kv.second.fwd) conv_plan_release(&p);
+        for (auto& v : kv.second.dgrad)
+            for (auto& p : v) conv_plan_release(&p);
+    }
     delete net;
 }
 
