@@ -55,6 +55,24 @@ struct ConvArgs {
     // cls_oyx bit 2c = oy0 of class c, bit 2c+1 = ox0.  One class (ncls = 1): an ordinary convolution.
     int cls_pack, cls_oyx;
     unsigned m_tpg, m_tpi, m_lw, m_ppi, m_kc4, m_pc, m_pr;   // ceil(2^32 / d) of the plan's divisors (exact quotients by one v_mul_hi)
+    // ---- input transform (xf = 1): the train-mode BatchNorm + ReLU of the PRODUCING convolution applied while this convolution stages
+    // its input patch (models/resnet.py:33: out = relu(bn1(conv1(x))) feeding conv2): `in` is the producer's raw output, the batch
+    // statistics are final when this launch starts, every workgroup folds them into a per-(group, channel) scale / shift table in
+    // LDS, and workgroup (0, 0) does what the BatchNorm kernel's first block did (saved mean / invstd for the backward, running
+    // statistics).  Halo positions outside the image stay zero (the convolution pads the ACTIVATION, not the raw output).
+    int xf;
+    int patch_floats;           // LDS floats of the patch area (the transform table follows it)
+    const double* xf_stats;     // producer's statistics [kStatReps][groups][2][Cin], replica stride xf_rep_stride doubles
+    int64_t xf_rep_stride;
+    int64_t xf_m_per_group;     // pixels per BatchNorm group of the producer's output
+    const float* xf_gamma;
+    const float* xf_beta;
+    float* xf_save_mean;        // [groups][Cin]
+    float* xf_save_invstd;
+    float* xf_running_mean;     // null: no running-statistics update
+    float* xf_running_var;
+    int64_t* xf_nbt;
+    float xf_momentum, xf_eps;
     // plan-constant tables in device memory (conv_plan_finalize): [ctab 16 | qoff Qpad | qrow Qpad | pad] [tile descriptors ntiles x 8]
     // [patch units 3 * PF x 256] [output pixels 3 * NT x 256], offsets in ints
     const int* blob;
@@ -80,6 +98,7 @@ struct ConvGeomDesc {
     int force_MT, force_NT, force_bpc;   // 0 = planner's choice (benchmarks / tests)
     int force_pipe;                      // staged-weight schedule: 0 = environment (OCL_CONV_PIPE, default on), 1 = ring, -1 = two-buffer
     int WPT;                    // row stride of the K-grouped weight pack (0: the plan's own CoutP)
+    int xf;                     // reserve LDS for the input-transform table (ConvArgs::xf may then be set at launch)
     int ncls;                   // > 1: output classes of one launch, taps listed class by class
     int cls_ntaps[4], cls_oy[4], cls_ox[4];
 };
@@ -125,6 +144,13 @@ struct WgradArgs {
     int nblocks;                // blocks along Cout
     int Mchunk;                 // ntaps*KC
     int Mrows_total;            // nchunks * mblocks_per_chunk * (64*MTW)
+    // input transform (as ConvArgs::xf): x is the raw output of the convolution in front of a BatchNorm + ReLU; the patch staging
+    // applies max(fma(x, scale, shift), 0) with scale / shift from the saved mean / invstd, gamma, beta of that BatchNorm
+    int xf, xf_groups, xf_group_size;   // BatchNorm groups of the pass, images per group
+    const float* xf_mean;       // [groups][Cin]
+    const float* xf_invstd;
+    const float* xf_gamma;
+    const float* xf_beta;
 };
 struct WgradPlan {
     WgradArgs a;
@@ -133,7 +159,8 @@ struct WgradPlan {
     size_t lds_bytes;
     size_t partial_floats;
 };
-int plan_wgrad(int N, int Hin, int Win, int Cin, int Ho, int Wo, int Cout, int ksize, int stride, WgradPlan* p);
+// xf_groups > 0: reserve LDS for the input-transform table of that many BatchNorm groups
+int plan_wgrad(int N, int Hin, int Win, int Cin, int Ho, int Wo, int Cout, int ksize, int stride, WgradPlan* p, int xf_groups = 0);
 int launch_wgrad(const WgradPlan& p, hipStream_t s);
 // sums the S partials and writes/accumulates the OIHW gradient
 int launch_wgrad_reduce(const WgradPlan& p, float* grad_oihw, int accumulate, hipStream_t s);
@@ -191,6 +218,9 @@ struct BnFwdArgs {
     const float* frozen_var;    // tape: the forward of model.eval() under autograd, utils/buffer/gss_greedy_update.py:16,77-79)
 };
 int launch_bn_fwd(const BnFwdArgs& a, hipStream_t s);
+// z = relu(fma(y, scale, shift)) from saved statistics (the activation a fused pass never wrote: debug copies, tests)
+int launch_bn_apply_saved(const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta, float* z,
+                          int64_t m_per_group, int G, int C, hipStream_t s);
 
 // eval-mode fold: scale = gamma/sqrt(rv+eps), shift = beta - rm*scale for every BN at once
 struct BnFoldDesc {
@@ -220,6 +250,10 @@ struct BnBwdArgs {
     int accumulate;       // dgamma/dbeta += (1) or = (0)
     unsigned* err;        // host-mapped asynchronous error word (one-pass kernel: arrival time-out), may be null
     int frozen;           // 1: the forward normalised with constant (running) statistics: dy = gamma*invstd*dpre, no mean terms
+    // mask_from_y: the post-ReLU activation was never written (its BatchNorm + ReLU ran inside the consuming convolution's patch
+    // staging): the ReLU mask is recomputed as fma(y, scale, shift) > 0 with exactly the arithmetic of that staging (nsets == 1, z null)
+    int mask_from_y;
+    const float* beta[2];
 };
 int launch_bn_bwd(const BnBwdArgs& a, hipStream_t s);
 void bn_bwd_tune(int block_cap, int unroll, int phase);

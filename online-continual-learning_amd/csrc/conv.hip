@@ -59,6 +59,48 @@ __device__ __forceinline__ int tap_sel(const int (&tab)[9], int t) {
 constexpr int kPatchPF = 8;      // max float4 patch-prefetch registers per thread of the wgrad kernels
 constexpr int kConvPatchPF = 8;  // ... of the conv kernel (planner: patch units <= 256*kConvPatchPF)
 
+
+// =====================================================================================================
+// BatchNorm arithmetic shared by every kernel that applies or differentiates a train-mode BatchNorm: one statement of the
+// scale / shift (so that an activation recomputed from the raw convolution output -- consuming convolution, weight gradient,
+// ReLU mask of the backward -- has the bits the BatchNorm kernel would have written)
+// =====================================================================================================
+__device__ __forceinline__ void bn_scale_shift(float gamma, float beta, float mean, float invstd, float& sc, float& sh) {
+    sc = gamma * invstd;
+    sh = __fmaf_rn(-mean, sc, beta);
+}
+// mean / invstd of (group g, channel c) from the replicated fp64 sums (biased variance, nn.BatchNorm2d's normalisation)
+__device__ __forceinline__ void bn_batch_moments(const double* __restrict__ stats, int64_t rep_stride, int g, int c, int C, double M, float eps,
+                                                 double& mean, double& var) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < kStatReps; ++r) {   // fixed order: the replica sums are combined deterministically
+        s1 += stats[r * rep_stride + ((int64_t)g * 2 + 0) * C + c];
+        s2 += stats[r * rep_stride + ((int64_t)g * 2 + 1) * C + c];
+    }
+    mean = s1 / M;
+    var = s2 / M - mean * mean;
+    if (var < 0.0) var = 0.0;
+    (void)eps;
+}
+// running statistics: one update per group, in order (= the reference's separate forward calls), unbiased variance, momentum
+__device__ __forceinline__ void bn_running_update(const double* __restrict__ stats, int64_t rep_stride, int G, int C, double M, float momentum,
+                                                  float eps, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                  int64_t* __restrict__ nbt, int tid, int nthreads) {
+    for (int c = tid; c < C; c += nthreads) {
+        float rm = running_mean[c], rv = running_var[c];
+        for (int gg = 0; gg < G; ++gg) {
+            double mean, var;
+            bn_batch_moments(stats, rep_stride, gg, c, C, M, eps, mean, var);
+            const double unb = M > 1.0 ? var * M / (M - 1.0) : var;
+            rm = momentum * (float)mean + (1.f - momentum) * rm;
+            rv = momentum * (float)unb + (1.f - momentum) * rv;
+        }
+        running_mean[c] = rm;
+        running_var[c] = rv;
+    }
+    if (tid == 0 && nbt) *nbt += G;
+}
+
 // =====================================================================================================
 // conv_t_kernel: channels x pixels orientation with K-grouped operands
 // =====================================================================================================
@@ -126,6 +168,7 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
     int* qrow = qoff + a.Qpad;                 // [Qpad] row of the K-grouped pack (tap * C4tot + channel quad), -1: padding group
     float* wl = (float*)(qrow + a.Qpad);       // resident: [Qpad][COPW][4]; staged: [2][QS][COPW][4]; PIPE: [3][QS][COPW][4]
     float* patch = wl + (size_t)(RES ? a.Qpad : (PIPE ? 3 : 2) * a.QS) * COPW * 4;   // [imgs][PR][PC][CP]
+    float* xft = patch + a.patch_floats;       // input transform: [groups][Cin/4][2][4] scale quads / shift quads
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, g = lane >> 4;
@@ -180,16 +223,35 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
     const int td0 = tid < ntd ? td[tid] : 0, td1 = tid + 256 < ntd ? td[tid + 256] : 0;
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in), rs_w = make_rsrc(a.wT);
     float4 pv[PF];
+    unsigned okm = 0;   // bit i: unit i of the patch in flight lies inside the image (input transform: the others stay zero)
     auto load_patch_d = [&](const int4 d, int c0) __attribute__((always_inline)) {   // d: in_base, iy0, nrows, obase
         const int base = d.x + c0 * 4;
+        okm = 0;
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
-            const int row = pu_rp[i] & 0xffff, pr = pu_rp[i] >> 16;
+            const int row = pu_rp[i] & 0xffff, pr = (pu_rp[i] >> 16) & 0xff;
             const bool ok = (row < d.z) & ((unsigned)(d.y + pr) < (unsigned)a.Hin) & (pu_goff[i] >= 0);
             pv[i] = buf_load16(rs_in, ok ? base + pu_goff[i] : kOob);
+            okm |= ok ? (1u << i) : 0u;
         }
     };
-    auto store_patch = [&](int nrows) __attribute__((always_inline)) {
+    // grp / c0: BatchNorm group of the tile and channel origin of the chunk being stored (input transform only)
+    auto store_patch = [&](int nrows, int grp, int c0) __attribute__((always_inline)) {
+        if (a.xf) {   // block-uniform
+            const float* tb = xft + (size_t)(grp * a.C4tot + (c0 >> 2)) * 8;
+#pragma unroll
+            for (int i = 0; i < PF; ++i)
+                if ((pu_rp[i] & 0xffff) < nrows) {
+                    const float* t = tb + (pu_rp[i] >> 24) * 8;
+                    const float4 sc = *(const float4*)t, sh = *(const float4*)(t + 4);
+                    float4 v = pv[i];
+                    v.x = fmaxf(__fmaf_rn(v.x, sc.x, sh.x), 0.f); v.y = fmaxf(__fmaf_rn(v.y, sc.y, sh.y), 0.f);
+                    v.z = fmaxf(__fmaf_rn(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(__fmaf_rn(v.w, sc.w, sh.w), 0.f);
+                    if (!((okm >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                    *(float4*)(patch + pu_lds[i]) = v;
+                }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < PF; ++i)
             if ((pu_rp[i] & 0xffff) < nrows) {   // CP % 4 == 0: 16-byte aligned
@@ -198,6 +260,33 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
     };
     auto load_patch = [&](int k, int c0) __attribute__((always_inline)) { load_patch_d(*(const int4*)(tdesc + k * 8), c0); };
     load_patch_d(tile0, 0);
+    if (a.xf) {   // the producer's BatchNorm folded into scale / shift per (group, channel); see ConvArgs::xf
+        const int C = a.Cin;
+        const double M = (double)a.xf_m_per_group;
+        const bool lead = blockIdx.x == 0 && blockIdx.y == 0;
+        for (int j = tid; j < a.groups * C; j += 256) {
+            const int gq = j / C, c = j - gq * C;
+            double mean, var;
+            bn_batch_moments(a.xf_stats, a.xf_rep_stride, gq, c, C, M, a.xf_eps, mean, var);
+            // 1 / sqrt(var + eps) without the fp64 divide / square-root sequences (every workgroup of the launch runs this prologue):
+            // fp32 rsqrt seed + two Newton steps in fp64 (relative error < 1e-15: the float it is rounded to is the exact one)
+            const double xv = var + (double)a.xf_eps;
+            double invstd = (double)rsqrtf((float)xv);
+            invstd = invstd * (1.5 - 0.5 * xv * invstd * invstd);
+            invstd = invstd * (1.5 - 0.5 * xv * invstd * invstd);
+            float sc, sh;
+            bn_scale_shift(a.xf_gamma[c], a.xf_beta[c], (float)mean, (float)invstd, sc, sh);
+            float* t = xft + (size_t)(gq * (C >> 2) + (c >> 2)) * 8 + (c & 3);
+            t[0] = sc;
+            t[4] = sh;
+            if (lead) {
+                a.xf_save_mean[j] = (float)mean;
+                a.xf_save_invstd[j] = (float)invstd;
+            }
+        }
+        if (lead && a.xf_running_mean)
+            bn_running_update(a.xf_stats, a.xf_rep_stride, a.groups, C, M, a.xf_momentum, a.xf_eps, a.xf_running_mean, a.xf_running_var, a.xf_nbt, tid, 256);
+    }
     if (tid < ntab) ctab[tid] = tab0;
     if (tid + 256 < ntab) ctab[tid + 256] = tab1;
     if (tid + 512 < ntab) ctab[tid + 512] = tab2;
@@ -567,7 +656,7 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
                 stamp();   // tile + 0: tile set-up done
                 __syncthreads();   // consumers of the previous patch are done
                 stamp();   // tile + 1: barrier passed
-                store_patch(d0.z);
+                store_patch(d0.z, d1.y, c0);
                 stamp();   // tile + 2: patch arrived and written to LDS
                 if (chunk + 1 < nchunks) load_patch(k, c0 + a.KC);
                 else if (nchunks > 1 && cls + 1 < ncls) load_patch(k, 0);
@@ -743,8 +832,10 @@ static size_t convt_layout(const ConvGeomDesc& g, ConvArgs& a, int MT, int NT, b
             a.pipe = (pipe && !a.wres && NT == 1) ? 1 : 0;   // ring of three stage buffers of pipe_qs(MT) groups (conv_t_kernel<..., PIPE>)
             a.QS = a.wres ? a.Qpad : a.pipe ? pipe_qs(MT) : std::min(a.Qpad, ((256 * kWPF) / COPW) & ~3);
             a.nstage = cdiv(a.Qpad, a.QS);
-            const size_t patch_b = std::max((size_t)a.imgs * a.PR * a.PC * a.CP * 4, (size_t)8 * COPW * 8);
-            bytes = (size_t)kMaxWgTiles * 32 + 64 + (size_t)2 * a.Qpad * 4 + (a.wres ? w_all : (size_t)(a.pipe ? 3 : 2) * a.QS * COPW * 16) + patch_b;
+            const size_t patch_b = (size_t)round_up(std::max((size_t)a.imgs * a.PR * a.PC * a.CP * 4, (size_t)8 * COPW * 8), 16);
+            a.patch_floats = (int)(patch_b / 4);
+            const size_t xf_b = g.xf ? (size_t)g.groups * g.Cin * 8 : 0;   // input transform: scale / shift per (group, channel)
+            bytes = (size_t)kMaxWgTiles * 32 + 64 + (size_t)2 * a.Qpad * 4 + (a.wres ? w_all : (size_t)(a.pipe ? 3 : 2) * a.QS * COPW * 16) + patch_b + xf_b;
             const bool units_ok = a.imgs * a.PR * a.PC * (KC / 4) <= 256 * kConvPatchPF;
             if (units_ok && bytes <= kLdsLimit - 2048 && (bytes <= 100 * 1024 || KC <= 20)) goto found;
         }
@@ -923,7 +1014,7 @@ void conv_plan_tables(const ConvPlan& p, std::vector<int>* out) {
             const bool xok = ix >= 0 && ix < a.Win;               // columns of the halo outside the image: zeros (never loaded, still stored)
             pu[(3 * i + 0) * 256 + tid] = xok ? (((il * a.Hin + pr) * a.Win + pc) * a.Cin + c4 * 4) * 4 : -1;
             pu[(3 * i + 1) * 256 + tid] = (row * a.PC + pc) * a.CP + c4 * 4;
-            pu[(3 * i + 2) * 256 + tid] = (il < 128 && pr < 256) ? (row | (pr << 16)) : 0x7fff;   // row 0x7fff: past every tile's last row
+            pu[(3 * i + 2) * 256 + tid] = (il < 128 && pr < 256) ? (row | (pr << 16) | (c4 << 24)) : 0x7fff;   // row 0x7fff: past every tile's last row; bits 24+: channel quad
             c4 += a.d_c4;
             pc += a.d_pc;
             if (c4 >= kc4) { c4 -= kc4; pc += 1; }
@@ -1112,6 +1203,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
     int* pixoff = (int*)lds_raw;                    // [KP]
     float* dyt = (float*)(pixoff + a.KP);           // [KP][DP]
     float* patch = dyt + (size_t)a.KP * a.DP;       // [imgs][PR][PC][CP]
+    float* xft = patch + (((size_t)a.imgs * a.PR * a.PC * a.CP + 3) & ~(size_t)3);   // input transform (WgradArgs::xf): [groups][Cin/4][2][4] scale / shift quads
     constexpr int BNW = 16 * NTW;
     constexpr int Q = BNW / 4;
     constexpr int DPF = (128 * Q + 255) / 256;      // dy prefetch registers (KP <= 128)
@@ -1187,6 +1279,19 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
         }
     }
     float4 dv[DPF], pv[PF];
+    unsigned okm = 0;   // bit i: patch unit i of the tile in flight lies inside the image (input transform: the others stay zero)
+    if (a.xf) {   // x is a raw convolution output: its BatchNorm + ReLU is applied while the patch is staged (first barrier of the tile loop publishes the table)
+        const int C = a.Cin;
+        for (int j = threadIdx.x; j < a.xf_groups * C; j += 256) {
+            const int gq = j / C, c = j - gq * C;
+            float sc, sh;
+            bn_scale_shift(a.xf_gamma[c], a.xf_beta[c], a.xf_mean[j], a.xf_invstd[j], sc, sh);
+            float* t = xft + (size_t)(gq * (C >> 2) + (c >> 2)) * 8 + (c & 3);
+            t[0] = sc;
+            t[4] = sh;
+        }
+    }
+    const float inv_gs = a.xf ? 1.0f / (float)a.xf_group_size : 0.f;
     int dpo[DPF];   // LDS patch offset of the pixel (units with c4 == 0 publish it), -1: unit not in this tile
     const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(a.x), rs_dy = make_rsrc(a.dy);
     auto load_tile = [&](const WTile& t) __attribute__((always_inline)) {
@@ -1206,12 +1311,14 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
         }
         const int iy0 = t.oy0 * a.stride + a.min_dy;
         const int base = (((t.img0 * a.Hin + iy0) * a.Win + a.min_dx) * a.Cin + c0) * 4;   // bytes; may be negative (halo)
+        okm = 0;
 #pragma unroll
         for (int i = 0; i < PF; ++i) {
             const int il = pu_pos[i] >> 24, pr = (pu_pos[i] >> 16) & 255, pc = (pu_pos[i] >> 8) & 255, c4 = pu_pos[i] & 255;
             const int iy = iy0 + pr, ix = a.min_dx + pc;
             const bool ok = (il * a.PR + pr < t.nrows) & (iy >= 0) & (iy < a.Hin) & (ix >= 0) & (ix < a.Win);
             pv[i] = buf_load16(rs_x, ok ? base + (((il * a.Hin + pr) * a.Win + pc) * a.Cin + c4 * 4) * 4 : kOob);
+            okm |= ok ? (1u << i) : 0u;
         }
     };
     auto store_tile = [&](const WTile& t) __attribute__((always_inline)) {
@@ -1227,9 +1334,19 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
             const int il = pu_pos[i] >> 24, pr = (pu_pos[i] >> 16) & 255, pc = (pu_pos[i] >> 8) & 255, c4 = pu_pos[i] & 255;
             const int row = il * a.PR + pr;
             if (row < t.nrows) {
+                float4 v = pv[i];
+                if (a.xf) {   // block-uniform
+                    int rem;
+                    const int gq = min(fdiv(t.img0 + il, a.xf_group_size, inv_gs, rem), a.xf_groups - 1);
+                    const float* tb = xft + (size_t)(gq * (a.Cin >> 2) + (c0 >> 2) + c4) * 8;
+                    const float4 sc = *(const float4*)tb, sh = *(const float4*)(tb + 4);
+                    v.x = fmaxf(__fmaf_rn(v.x, sc.x, sh.x), 0.f); v.y = fmaxf(__fmaf_rn(v.y, sc.y, sh.y), 0.f);
+                    v.z = fmaxf(__fmaf_rn(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(__fmaf_rn(v.w, sc.w, sh.w), 0.f);
+                    if (!((okm >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
                 float* d = patch + (row * a.PC + pc) * a.CP + c4 * 4;
-                *(float2*)d = make_float2(pv[i].x, pv[i].y);
-                *(float2*)(d + 2) = make_float2(pv[i].z, pv[i].w);
+                *(float2*)d = make_float2(v.x, v.y);
+                *(float2*)(d + 2) = make_float2(v.z, v.w);
             }
         }
     };
@@ -1247,30 +1364,69 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
             load_tile(cur);
         }
         const float* pb = dyt + (size_t)g * a.DP + r16;
-        auto ksteps = [&](int s, auto UC) __attribute__((always_inline)) {
-            constexpr int U = decltype(UC)::value;
-            int po[U];
-            float av[U][MTW], bv[U][NTW];
+        // One iteration = 16 pixels of the tile = four MFMA k-blocks (lane quarter g supplies pixel 4u + g of block u): per block
+        // MTW A values (patch, through the pixel-offset table) and NTW B values (dy tile).  Rounds 1 - 2 ran an iteration as table
+        // look-up -> wait -> 4 * (MTW + NTW) operand reads -> wait -> MFMAs, i.e. two exposed dependent LDS round trips in front of
+        // every 4 * MTW * NTW MFMAs and nothing in flight across iterations.  Now (the conv kernel's recipe): two operand register
+        // sets, the reads of iteration i + 1 issued before the MFMAs of iteration i, and the table entries of iteration i + 2 read
+        // one iteration ahead of their use, so no wait falls on a read that has just been issued.
+        const int nfull = a.KP >> 4;
+        float av[2][4][MTW], bv[2][4][NTW];
+        int poN[4];
+        auto lookup = [&](int it) __attribute__((always_inline)) {   // table entries of iteration `it` (clamped: past the end they are never used)
+            const int s_ = min(it, nfull - 1) << 4;
 #pragma unroll
-            for (int u = 0; u < U; ++u) po[u] = pixoff[s + 4 * u + g];
+            for (int u = 0; u < 4; ++u) poN[u] = pixoff[s_ + 4 * u + g];
+        };
+        auto fetch = [&](int set, int it) __attribute__((always_inline)) {
+            const int s_ = min(it, nfull - 1) << 4;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
+            for (int u = 0; u < 4; ++u) {
 #pragma unroll
-                for (int mt = 0; mt < MTW; ++mt) av[u][mt] = patch[po[u] + aoff[mt]];
+                for (int mt = 0; mt < MTW; ++mt) av[set][u][mt] = patch[poN[u] + aoff[mt]];
 #pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) bv[u][nt] = pb[(size_t)(s + 4 * u) * a.DP + nt * 16];
+                for (int nt = 0; nt < NTW; ++nt) bv[set][u][nt] = pb[(size_t)(s_ + 4 * u) * a.DP + nt * 16];
             }
+            lookup(it + 1);
+        };
+        auto fma = [&](int set) __attribute__((always_inline)) {
 #pragma unroll
-            for (int u = 0; u < U; ++u)
+            for (int u = 0; u < 4; ++u)
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NTW; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][mt], bv[u][nt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][u][mt], bv[set][u][nt], acc[mt][nt], 0, 0, 0);
         };
-        int s = 0;
-        for (; s + 16 <= a.KP; s += 16) ksteps(s, std::integral_constant<int, 4>());
-        for (; s < a.KP; s += 4) ksteps(s, std::integral_constant<int, 1>());
+        if (nfull > 0) {
+            lookup(0);
+            fetch(0, 0);
+            int it = 0;
+            for (; it + 2 <= nfull; it += 2) {
+                fetch(1, it + 1);
+                __builtin_amdgcn_sched_barrier(0);
+                fma(0);
+                __builtin_amdgcn_sched_barrier(0);
+                fetch(0, it + 2);
+                __builtin_amdgcn_sched_barrier(0);
+                fma(1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (it < nfull) fma(0);
+        }
+        // pixels past the last whole iteration (tiles whose pixel count is not a multiple of 16: 11 x 11 maps), four at a time
+        for (int s = nfull << 4; s < a.KP; s += 4) {
+            const int po = pixoff[s + g];
+            float a1[MTW], b1[NTW];
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt) a1[mt] = patch[po + aoff[mt]];
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) b1[nt] = pb[(size_t)s * a.DP + nt * 16];
+#pragma unroll
+            for (int mt = 0; mt < MTW; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[mt], b1[nt], acc[mt][nt], 0, 0, 0);
+        }
     }
     // partial tile out: rows (chunk, mblock, m), cols co
     const int mrows_chunk = a.mblocks_per_chunk * 64 * MTW;
@@ -1279,9 +1435,12 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
     for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
-            const int row = chunk * mrows_chunk + m0 + wave * 16 * MTW + mt * 16 + g * 4 + reg;
+            const int ml = m0 + wave * 16 * MTW + mt * 16 + g * 4 + reg;   // row inside the chunk: (tap, channel)
+            const int row = chunk * mrows_chunk + ml;
+            if (ml >= a.Mchunk) continue;   // padding rows / columns are never read by the reduction: not written either
 #pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) dst[(int64_t)row * a.CoutP + n0 + nt * 16 + r16] = acc[mt][nt][reg];
+            for (int nt = 0; nt < NTW; ++nt)
+                if (n0 + nt * 16 + r16 < a.Cout) dst[(int64_t)row * a.CoutP + n0 + nt * 16 + r16] = acc[mt][nt][reg];
         }
 }
 
@@ -1368,7 +1527,7 @@ static int wg_cp(int kc, int stride) {
     }
 }
 
-int plan_wgrad(int N, int Hin, int Win, int Cin, int Ho, int Wo, int Cout, int ksize, int stride, WgradPlan* p) {
+int plan_wgrad(int N, int Hin, int Win, int Cin, int Ho, int Wo, int Cout, int ksize, int stride, WgradPlan* p, int xf_groups) {
     memset(p, 0, sizeof(*p));
     WgradArgs& a = p->a;
     OCL_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0 && (ksize == 1 || ksize == 3), "plan_wgrad: Cin=%d Cout=%d k=%d", Cin, Cout, ksize);
@@ -1409,7 +1568,8 @@ int plan_wgrad(int N, int Hin, int Win, int Cin, int Ho, int Wo, int Cout, int k
                 if (Cin % KC) continue;
                 if (pass == 0 && KC < std::min(20, Cin)) break;
                 a.KC = KC; a.CP = wg_cp(KC, stride);
-                const size_t bytes = (size_t)a.KP * 4 + (size_t)a.KP * a.DP * 4 + (size_t)a.imgs * a.PR * a.PC * a.CP * 4;
+                const size_t bytes = (size_t)a.KP * 4 + (size_t)a.KP * a.DP * 4 + (size_t)a.imgs * a.PR * a.PC * a.CP * 4 +
+                                     (size_t)xf_groups * Cin * 8 + (xf_groups ? 16 : 0);   // (+ the input-transform table)
                 const bool fits = (pass == 0 ? bytes <= kLdsTarget : bytes <= kLdsLimit - 1024) &&
                                   a.imgs * a.PR * a.PC * (KC / 4) <= 256 * kPatchPF;
                 if (fits) { p->lds_bytes = bytes; found = true; break; }
@@ -1578,48 +1738,21 @@ __global__ void __launch_bounds__(256) bn_fwd_kernel(const BnFwdArgs a) {
     const int g = blockIdx.y, tid = threadIdx.x;
     const double M = (double)a.m_per_group;
     for (int c = tid; c < a.C; c += 256) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int r = 0; r < kStatReps; ++r) {   // fixed order: the replica sums are combined deterministically
-            s1 += a.stats[r * a.stat_rep_stride + ((int64_t)g * 2 + 0) * a.C + c];
-            s2 += a.stats[r * a.stat_rep_stride + ((int64_t)g * 2 + 1) * a.C + c];
-        }
-        double mean = s1 / M;
-        double var = s2 / M - mean * mean;
-        if (var < 0.0) var = 0.0;
+        double mean, var;
+        bn_batch_moments(a.stats, a.stat_rep_stride, g, c, a.C, M, a.eps, mean, var);
         if (a.frozen_mean) {   // eval-mode BatchNorm on the tape: the running statistics, folded exactly as bn_fold_kernel does
             mean = (double)a.frozen_mean[c];
             var = (double)a.frozen_var[c];
         }
         const double invstd = 1.0 / sqrt(var + (double)a.eps);
-        const float scale = a.gamma[c] * (float)invstd;
-        sc[c] = scale;
-        sh[c] = a.beta[c] - (float)mean * scale;
+        bn_scale_shift(a.gamma[c], a.beta[c], (float)mean, (float)invstd, sc[c], sh[c]);
         if (blockIdx.x == 0) {
             a.save_mean[(int64_t)g * a.C + c] = (float)mean;
             a.save_invstd[(int64_t)g * a.C + c] = (float)invstd;
         }
     }
-    if (blockIdx.x == 0 && g == 0 && a.running_mean) {
-        for (int c = tid; c < a.C; c += 256) {
-            float rm = a.running_mean[c], rv = a.running_var[c];
-            for (int gg = 0; gg < a.G; ++gg) {  // one update per group, in order (= separate forward calls)
-                double s1 = 0.0, s2 = 0.0;
-                for (int r = 0; r < kStatReps; ++r) {
-                    s1 += a.stats[r * a.stat_rep_stride + ((int64_t)gg * 2 + 0) * a.C + c];
-                    s2 += a.stats[r * a.stat_rep_stride + ((int64_t)gg * 2 + 1) * a.C + c];
-                }
-                const double mean = s1 / M;
-                double var = s2 / M - mean * mean;
-                if (var < 0.0) var = 0.0;
-                const double unb = M > 1.0 ? var * M / (M - 1.0) : var;
-                rm = a.momentum * (float)mean + (1.f - a.momentum) * rm;
-                rv = a.momentum * (float)unb + (1.f - a.momentum) * rv;
-            }
-            a.running_mean[c] = rm;
-            a.running_var[c] = rv;
-        }
-        if (tid == 0 && a.nbt) *a.nbt += a.G;
-    }
+    if (blockIdx.x == 0 && g == 0 && a.running_mean)
+        bn_running_update(a.stats, a.stat_rep_stride, a.G, a.C, M, a.momentum, a.eps, a.running_mean, a.running_var, a.nbt, tid, 256);
     __syncthreads();
     const int C4 = a.C >> 2;
     const int64_t units = a.m_per_group * C4;
@@ -1629,10 +1762,10 @@ __global__ void __launch_bounds__(256) bn_fwd_kernel(const BnFwdArgs a) {
     for (int64_t u = (int64_t)blockIdx.x * 256 + tid; u < units; u += (int64_t)gridDim.x * 256) {
         const int c = (int)(u % C4) * 4;
         float4 v = y4[u];
-        v.x = fmaf(v.x, sc[c], sh[c]);
-        v.y = fmaf(v.y, sc[c + 1], sh[c + 1]);
-        v.z = fmaf(v.z, sc[c + 2], sh[c + 2]);
-        v.w = fmaf(v.w, sc[c + 3], sh[c + 3]);
+        v.x = __fmaf_rn(v.x, sc[c], sh[c]);
+        v.y = __fmaf_rn(v.y, sc[c + 1], sh[c + 1]);
+        v.z = __fmaf_rn(v.z, sc[c + 2], sh[c + 2]);
+        v.w = __fmaf_rn(v.w, sc[c + 3], sh[c + 3]);
         if (r4) {
             const float4 r = r4[u];
             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
@@ -1649,6 +1782,34 @@ int launch_bn_fwd(const BnFwdArgs& a, hipStream_t s) {
     const int bx = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (units + 1023) / 1024));
     ProfScope ps(PROF_BN, s);
     hipLaunchKernelGGL(bn_fwd_kernel, dim3(bx, a.G), dim3(256), (size_t)a.C * 8, s, a);
+    OCL_LAUNCH_CHECK();
+    return OCL_OK;
+}
+
+// z = relu(fma(y, scale, shift)) with scale / shift from SAVED statistics: materialises the activation a fused pass never wrote
+__global__ void __launch_bounds__(256) bn_apply_saved_kernel(const float* __restrict__ y, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ z,
+                                                             int64_t m_per_group, int C) {
+    const int g = blockIdx.y, C4 = C >> 2;
+    const int64_t units = m_per_group * C4;
+    for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < units; u += (int64_t)gridDim.x * 256) {
+        const int c = (int)(u % C4) * 4;
+        float4 v = ((const float4*)y)[(int64_t)g * units + u];
+        float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float sc, sh;
+            bn_scale_shift(gamma[c + e], beta[c + e], mean[(int64_t)g * C + c + e], invstd[(int64_t)g * C + c + e], sc, sh);
+            o[e] = fmaxf(__fmaf_rn(o[e], sc, sh), 0.f);
+        }
+        ((float4*)z)[(int64_t)g * units + u] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+int launch_bn_apply_saved(const float* y, const float* mean, const float* invstd, const float* gamma, const float* beta, float* z,
+                          int64_t m_per_group, int G, int C, hipStream_t s) {
+    const int64_t units = m_per_group * (C / 4);
+    const int bx = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (units + 1023) / 1024));
+    hipLaunchKernelGGL(bn_apply_saved_kernel, dim3(bx, G), dim3(256), 0, s, y, mean, invstd, gamma, beta, z, m_per_group, C);
     OCL_LAUNCH_CHECK();
     return OCL_OK;
 }
@@ -1709,8 +1870,16 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const BnBwdArgs a) {
         const int64_t step = (int64_t)PT * C4;
         const int64_t eend = pend * C4;
         int64_t e = (pbeg + pl) * C4 + c4;
-        auto consume = [&](float4 d, const float4& zz, const float4& ya, const float4& yb) __attribute__((always_inline)) {
-            if (z4) {
+        float4 msc = make_float4(0.f, 0.f, 0.f, 0.f), msh = msc;   // mask_from_y: scale / shift of this thread's channel quad
+        if (a.mask_from_y) {
+            const float4 gm = *(const float4*)(a.gamma[0] + c4 * 4), bt = *(const float4*)(a.beta[0] + c4 * 4);
+            bn_scale_shift(gm.x, bt.x, mean[0].x, istd[0].x, msc.x, msh.x); bn_scale_shift(gm.y, bt.y, mean[0].y, istd[0].y, msc.y, msh.y);
+            bn_scale_shift(gm.z, bt.z, mean[0].z, istd[0].z, msc.z, msh.z); bn_scale_shift(gm.w, bt.w, mean[0].w, istd[0].w, msc.w, msh.w);
+        }
+        auto consume = [&](float4 d, float4 zz, const float4& ya, const float4& yb) __attribute__((always_inline)) {
+            if (a.mask_from_y)
+                zz = make_float4(__fmaf_rn(ya.x, msc.x, msh.x), __fmaf_rn(ya.y, msc.y, msh.y), __fmaf_rn(ya.z, msc.z, msh.z), __fmaf_rn(ya.w, msc.w, msh.w));
+            if (z4 || a.mask_from_y) {
                 d.x = zz.x > 0.f ? d.x : 0.f; d.y = zz.y > 0.f ? d.y : 0.f;
                 d.z = zz.z > 0.f ? d.z : 0.f; d.w = zz.w > 0.f ? d.w : 0.f;
             }
@@ -1770,13 +1939,18 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const BnBwdArgs a) {
         const int c = j % a.C, k = j / a.C;
         const double sdy = a.sums[(((int64_t)k * a.G + g) * 2 + 0) * a.C + c];
         const double sdx = a.sums[(((int64_t)k * a.G + g) * 2 + 1) * a.C + c];
-        float* s = sm + (size_t)k * 5 * a.C;
+        float* s = sm + (size_t)k * 6 * a.C;
         const float istd = a.invstd[k][(int64_t)g * a.C + c];
         s[c] = a.frozen ? 0.f : (float)(sdy / Md);
         s[a.C + c] = a.frozen ? 0.f : (float)(sdx / Md);
         s[2 * a.C + c] = a.gamma[k][c] * istd;
         s[3 * a.C + c] = a.mean[k][(int64_t)g * a.C + c];
         s[4 * a.C + c] = istd;
+        if (a.mask_from_y) {
+            float sc_, sh_;
+            bn_scale_shift(a.gamma[k][c], a.beta[k][c], a.mean[k][(int64_t)g * a.C + c], istd, sc_, sh_);
+            s[5 * a.C + c] = sh_;   // (scale: s[2C + c] = gamma * invstd, the same product)
+        }
         if (blockIdx.x == 0 && g == 0) {
             double dg = 0.0, db = 0.0;
             for (int gg = 0; gg < a.G; ++gg) {
@@ -1803,11 +1977,17 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const BnBwdArgs a) {
             const float4 zz = ((const float4*)a.z)[e];
             d.x = zz.x > 0.f ? d.x : 0.f; d.y = zz.y > 0.f ? d.y : 0.f;
             d.z = zz.z > 0.f ? d.z : 0.f; d.w = zz.w > 0.f ? d.w : 0.f;
+        } else if (a.mask_from_y) {
+            const float4 y = ((const float4*)a.y[0])[e];
+            d.x = __fmaf_rn(y.x, sm[2 * a.C + c], sm[5 * a.C + c]) > 0.f ? d.x : 0.f;
+            d.y = __fmaf_rn(y.y, sm[2 * a.C + c + 1], sm[5 * a.C + c + 1]) > 0.f ? d.y : 0.f;
+            d.z = __fmaf_rn(y.z, sm[2 * a.C + c + 2], sm[5 * a.C + c + 2]) > 0.f ? d.z : 0.f;
+            d.w = __fmaf_rn(y.w, sm[2 * a.C + c + 3], sm[5 * a.C + c + 3]) > 0.f ? d.w : 0.f;
         }
 #pragma unroll
         for (int k = 0; k < 2; ++k)
             if (k < a.nsets) {
-                const float* s = sm + (size_t)k * 5 * a.C;
+                const float* s = sm + (size_t)k * 6 * a.C;
                 const float4 y = ((const float4*)a.y[k])[e];
                 float4 o;
                 o.x = s[2 * a.C + c] * (d.x - s[c] - (y.x - s[3 * a.C + c]) * s[4 * a.C + c] * s[a.C + c]);
@@ -1865,6 +2045,17 @@ __global__ void __launch_bounds__(kBnFusedThreads) bn_bwd_fused_kernel(const BnB
             for (int k = 0; k < NS; ++k) xh[k][e] = ((const float4*)a.y[k] + (int64_t)g * units)[uu];
             zz[e] = z4 ? z4[uu] : make_float4(1.f, 1.f, 1.f, 1.f);
             if (!in) d[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (a.mask_from_y) {   // the activation was never written: its sign from the raw output, with the staging kernels' arithmetic
+            const float4 gm = *(const float4*)(a.gamma[0] + c4 * 4), bt = *(const float4*)(a.beta[0] + c4 * 4);
+            const float4 mn = *(const float4*)(a.mean[0] + (int64_t)g * a.C + c4 * 4), is = *(const float4*)(a.invstd[0] + (int64_t)g * a.C + c4 * 4);
+            float4 sc, sh;
+            bn_scale_shift(gm.x, bt.x, mn.x, is.x, sc.x, sh.x); bn_scale_shift(gm.y, bt.y, mn.y, is.y, sc.y, sh.y);
+            bn_scale_shift(gm.z, bt.z, mn.z, is.z, sc.z, sh.z); bn_scale_shift(gm.w, bt.w, mn.w, is.w, sc.w, sh.w);
+#pragma unroll
+            for (int e = 0; e < E; ++e)
+                zz[e] = make_float4(__fmaf_rn(xh[0][e].x, sc.x, sh.x), __fmaf_rn(xh[0][e].y, sc.y, sh.y), __fmaf_rn(xh[0][e].z, sc.z, sh.z),
+                                    __fmaf_rn(xh[0][e].w, sc.w, sh.w));
         }
 #pragma unroll
         for (int e = 0; e < E; ++e) {
@@ -2062,7 +2253,7 @@ int launch_bn_bwd(const BnBwdArgs& a, hipStream_t s) {
     if (g_bn_bwd_phase == 1) return OCL_OK;
     const int64_t units = a.m_per_group * C4;
     const int bx2 = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (units + 1023) / 1024));
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bx2, a.G), dim3(256), (size_t)a.nsets * 5 * a.C * 4, s, a);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(bx2, a.G), dim3(256), (size_t)a.nsets * 6 * a.C * 4, s, a);
     OCL_LAUNCH_CHECK();
     return OCL_OK;
 }

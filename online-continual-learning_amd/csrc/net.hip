@@ -37,6 +37,7 @@ struct ConvInfo : ConvShape {
     int bn;           // following BatchNorm
     int64_t tf_off, td_off;  // K-grouped weight packs in the arena (floats): forward, data gradient
     int64_t y_off;    // raw output inside a slot (floats)
+    int xf_src;       // conv2 of a block: its block's conv1, whose BatchNorm + ReLU this convolution can apply itself (-1: none)
 };
 struct BlockInfo {
     int conv1, conv2, convs;  // convs = -1: identity shortcut
@@ -97,7 +98,7 @@ struct ocl_net {
     int dbg_stop = -1;            // debug: return from backward right after stage (block*10 + step)
     float* dbg_role[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     std::vector<int> slot_n, slot_groups;
-    std::vector<bool> slot_valid, slot_frozen;
+    std::vector<bool> slot_valid, slot_frozen, slot_fused;   // fused: bn1 + ReLU of every block ran inside conv2 (no a1 on the tape)
     std::map<std::pair<int, int>, PlanSet> plans;
 
     float* slotf(int slot) const { return (float*)(ws + slot_base + (int64_t)slot * slot_bytes); }
@@ -161,6 +162,7 @@ static int add_conv(ocl_net* n, const std::string& name, int Cin, int Cout, int 
     c.Wo = (Win + 2 * pad - k) / stride + 1;
     c.w_t = add_tensor(n, name + ".weight", {Cout, Cin, k, k});
     c.bn = -1;
+    c.xf_src = -1;
     n->convs.push_back(c);
     return (int)n->convs.size() - 1;
 }
@@ -187,6 +189,7 @@ static int build_layout(ocl_net* n) {
             const int Ho = n->convs[bi.conv1].Ho, Wo = n->convs[bi.conv1].Wo;
             bi.conv2 = add_conv(n, bp + ".conv2", planes, planes, 3, 1, Ho, Wo);
             n->convs[bi.conv2].bn = add_bn(n, bp + ".bn2", planes);
+            n->convs[bi.conv2].xf_src = bi.conv1;
             bi.convs = -1;
             if (stride != 1 || in_planes != planes) {
                 bi.convs = add_conv(n, bp + ".shortcut.0", in_planes, planes, 1, stride, H, W);
@@ -331,6 +334,7 @@ static int build_layout(ocl_net* n) {
     n->slot_groups.assign(d.n_slots, 1);
     n->slot_valid.assign(d.n_slots, false);
     n->slot_frozen.assign(d.n_slots, false);
+    n->slot_fused.assign(d.n_slots, false);
     return OCL_OK;
 }
 
@@ -349,6 +353,7 @@ static int get_plans(ocl_net* n, int N, int groups, PlanSet** out) {
         const ConvInfo& c = n->convs[i];
         ConvGeomDesc g;
         geom_fwd(c, N, groups, &g);
+        g.xf = c.xf_src >= 0 ? 1 : 0;   // room for the input-transform table (used by train-mode passes only)
         int rc = plan_conv(g, &ps.fwd[i]);
         if (rc != OCL_OK) return rc;
         if ((rc = conv_plan_finalize(&ps.fwd[i])) != OCL_OK) return rc;
@@ -371,7 +376,7 @@ static int get_plans(ocl_net* n, int N, int groups, PlanSet** out) {
                 n->pack_need_bwd |= PACK_TD;
             }
         }
-        rc = plan_wgrad(N, c.Hin, c.Win, c.CinT, c.Ho, c.Wo, c.Cout, c.k, c.stride, &ps.wgrad[i]);
+        rc = plan_wgrad(N, c.Hin, c.Win, c.CinT, c.Ho, c.Wo, c.Cout, c.k, c.stride, &ps.wgrad[i], c.xf_src >= 0 ? groups : 0);
         if (rc != OCL_OK) return rc;
         if ((int64_t)ps.wgrad[i].partial_floats > n->partial_floats) {
             set_error("net: wgrad partial workspace too small (%zu > %lld floats)", ps.wgrad[i].partial_floats,
@@ -430,8 +435,27 @@ static const BnFoldDesc* fold_descs(const ocl_net* n) {
     return (const BnFoldDesc*)(n->ws + n->off_descs + align_up((int64_t)(n->convs.size() * sizeof(PackDesc)), 64));
 }
 
+// the producer-side BatchNorm a convolution applies to its own input (ConvArgs::xf)
+struct XfBn {
+    const double* stats;
+    const float *gamma, *beta;
+    float *save_mean, *save_invstd, *running_mean, *running_var;
+    int64_t* nbt;
+    int64_t m_per_group;
+};
+
 static int run_conv(ocl_net* n, ConvPlan p, const float* in, const float* wT, float* out, int flags, double* stats,
-                    const float* scale, const float* shift, const float* res, const float* resmask, hipStream_t s) {
+                    const float* scale, const float* shift, const float* res, const float* resmask, hipStream_t s, const XfBn* xf = nullptr) {
+    if (xf) {
+        p.a.xf = 1;
+        p.a.xf_stats = xf->stats;
+        p.a.xf_rep_stride = n->stats_rep_stride;
+        p.a.xf_m_per_group = xf->m_per_group;
+        p.a.xf_gamma = xf->gamma; p.a.xf_beta = xf->beta;
+        p.a.xf_save_mean = xf->save_mean; p.a.xf_save_invstd = xf->save_invstd;
+        p.a.xf_running_mean = xf->running_mean; p.a.xf_running_var = xf->running_var; p.a.xf_nbt = xf->nbt;
+        p.a.xf_momentum = 0.1f; p.a.xf_eps = 1e-5f;
+    }
     p.a.stat_rep_stride = n->stats_rep_stride;
     p.a.in = in;
     p.a.wT = wT;
@@ -605,7 +629,7 @@ int ocl_net_bind(ocl_net* net, float* params, float* grads, float* running, int6
 // shortcuts run on the engine's second stream.  frozen: BatchNorm normalises with the running statistics (eval-mode tape).
 // -----------------------------------------------------------------------------------------------------
 static int trunk_forward_train(ocl_net* n, PlanSet* ps, const float* P, float* S, int Nc, int G, bool upd, float* feat, hipStream_t st,
-                               bool side = false, bool frozen = false) {
+                               bool side = false, bool frozen = false, bool fuse = false) {
     const int img0 = 0, g0 = 0;
     float* pack = (float*)(n->ws + n->off_pack);
     double* stats = n->statsbuf();
@@ -664,8 +688,27 @@ static int trunk_forward_train(ocl_net* n, PlanSet* ps, const float* P, float* S
             res = sc;
         }
         if ((rc = conv_stats(b.conv1, cur, st))) return rc;
-        if ((rc = bn_fwd(b.conv1, at(c1.y_off, c1), a1, nullptr, 1, st))) return rc;
-        if ((rc = conv_stats(b.conv2, a1, st))) return rc;
+        if (fuse) {
+            // relu(bn1(.)) is applied by conv2 while it stages its patches: no BatchNorm launch, a1 is never written (the backward
+            // recomputes it where it needs it: weight gradient of conv2, ReLU mask of bn1's backward)
+            const BnInfo& b1 = n->bns[c1.bn];
+            XfBn xf;
+            xf.stats = stats + b1.arena_off;
+            xf.gamma = P + n->tensors[b1.gamma_t].off;
+            xf.beta = P + n->tensors[b1.beta_t].off;
+            xf.save_mean = S + b1.save_off;
+            xf.save_invstd = S + b1.save_off + (int64_t)kGmax * b1.C;
+            xf.running_mean = upd ? n->running + b1.stat_off : nullptr;
+            xf.running_var = upd ? n->running + b1.stat_off + b1.C : nullptr;
+            xf.nbt = upd ? n->nbt + c1.bn : nullptr;
+            xf.m_per_group = (int64_t)(Nc / G) * c1.Ho * c1.Wo;
+            if ((rc = run_conv(n, ps->fwd[b.conv2], at(c1.y_off, c1), pack + c2.tf_off, at(c2.y_off, c2), EPI_STATS,
+                               stats + n->bns[c2.bn].arena_off, nullptr, nullptr, nullptr, nullptr, st, &xf)))
+                return rc;
+        } else {
+            if ((rc = bn_fwd(b.conv1, at(c1.y_off, c1), a1, nullptr, 1, st))) return rc;
+            if ((rc = conv_stats(b.conv2, a1, st))) return rc;
+        }
         if (b.convs >= 0 && side && (rc = side_join(n, st))) return rc;
         if ((rc = bn_fwd(b.conv2, at(c2.y_off, c2), z, res, 1, st))) return rc;
         cur = z;
@@ -719,12 +762,18 @@ int ocl_net_forward(ocl_net* n, const float* x, int N, int groups, uint32_t flag
     const bool feat_direct = feat_out && !out && !(flags & OCL_FWD_SAVE_TAPE);   // features only (ASER scoring, NCM): no copy
     float* feat = feat_direct ? feat_out : S + n->feat_off;
     const bool upd = (flags & OCL_FWD_UPDATE_RUNNING) != 0;
+    bool fused = false;
     if (train) {
         static const bool env_single = [] { const char* e = getenv("OCL_SINGLE_STREAM"); return e && e[0] == '1'; }();
         static const bool env_noextra = [] { const char* e = getenv("OCL_SIDE_EXTRA"); return e && e[0] == '0'; }();
         const bool side = n->dbg_stop < 0 && N >= kSideExtraMinBatch && !prof_on() && !env_single && !env_noextra;
         if (side && (rc = ensure_side_stream(n))) return rc;
-        if ((rc = trunk_forward_train(n, ps, P, S, N, groups, upd && !frozen, feat, s, side, frozen))) return rc;
+        static const bool env_nofuse = [] { const char* e = getenv("OCL_BN1_FUSE"); return e && e[0] == '0'; }();
+        fused = !frozen && !env_nofuse;
+        if ((rc = trunk_forward_train(n, ps, P, S, N, groups, upd && !frozen, feat, s, side, frozen, fused))) return rc;
+        n->slot_fused[slot] = fused;
+        n->slot_n[slot] = N;
+        n->slot_groups[slot] = groups;
     } else {
         float* fold = (float*)(n->ws + n->off_fold);
         if ((rc = launch_bn_fold(P, n->running, fold, fold_descs(n), (int)n->bns.size(), 1e-5f, s))) return rc;
@@ -778,7 +827,7 @@ int ocl_net_forward(ocl_net* n, const float* x, int N, int groups, uint32_t flag
 // gradients go to that stream behind events (large batches); null: everything on `s`, in order (small batches, measurements).
 // -----------------------------------------------------------------------------------------------------
 static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, float* S, int Nc, int G, int accumulate, const float* dfeat,
-                          hipStream_t s, hipStream_t side, bool frozen = false) {
+                          hipStream_t s, hipStream_t side, bool frozen = false, bool fused = false) {
     const int img0 = 0, g0 = 0;
     float* pack = (float*)(n->ws + n->off_pack);
     float* partial = n->partialbuf();
@@ -822,11 +871,13 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
         return OCL_OK;
     };
 
-    auto bn_bwd = [&](const float* dz, const float* zmask, int conv_a, float* dya, int conv_b, float* dyb) -> int {
+    // zmask == nullptr with from_y: the activation behind this BatchNorm was never written (fused forward): mask from the raw output
+    auto bn_bwd = [&](const float* dz, const float* zmask, int conv_a, float* dya, int conv_b, float* dyb, bool from_y = false) -> int {
         BnBwdArgs a;
         memset(&a, 0, sizeof(a));
         const ConvInfo& ca = n->convs[conv_a];
         a.dz = dz; a.z = zmask;
+        a.mask_from_y = from_y ? 1 : 0;
         a.m_per_group = (int64_t)(Nc / G) * ca.Ho * ca.Wo;
         a.G = G; a.C = ca.Cout;
         a.nsets = conv_b >= 0 ? 2 : 1;
@@ -839,6 +890,7 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
             a.mean[k] = S + b.save_off + (int64_t)g0 * b.C;
             a.invstd[k] = S + b.save_off + (int64_t)kGmax * b.C + (int64_t)g0 * b.C;
             a.gamma[k] = T(b.gamma_t);
+            a.beta[k] = T(b.beta_t);
             a.dy[k] = dys[k];
             a.dgamma[k] = GT(b.gamma_t);
             a.dbeta[k] = GT(b.beta_t);
@@ -865,10 +917,21 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
     const bool batched = !two_streams_arg && Nc < kTwoStreamMinBatch && ps->batched_reduce && !env_noreduce && n->dbg_stop < 0;
     WgradReduceMulti rm;
     rm.partial = partial; rm.grads = Gr; rm.accumulate = accumulate; rm.n = 0;
-    auto wgrad = [&](int conv_i, const float* xin, const float* dy) -> int {   // on the weight-gradient stream
+    // xf_conv >= 0: xin is the RAW output of that convolution; its BatchNorm + ReLU is applied while the kernel stages its patches
+    auto wgrad = [&](int conv_i, const float* xin, const float* dy, int xf_conv = -1) -> int {   // on the weight-gradient stream
         WgradPlan wp = ps->wgrad[conv_i];
         wp.a.x = xin;
         wp.a.dy = dy;
+        if (xf_conv >= 0) {
+            const BnInfo& b1 = n->bns[n->convs[xf_conv].bn];
+            wp.a.xf = 1;
+            wp.a.xf_groups = G;
+            wp.a.xf_group_size = Nc / G;
+            wp.a.xf_mean = S + b1.save_off;
+            wp.a.xf_invstd = S + b1.save_off + (int64_t)kGmax * b1.C;
+            wp.a.xf_gamma = T(b1.gamma_t);
+            wp.a.xf_beta = T(b1.beta_t);
+        }
         wp.a.partial = batched ? partial + ps->partial_off[conv_i] : partial;
         int r = launch_wgrad(wp, sw);
         if (r) return r;
@@ -913,13 +976,13 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
             if ((rc = wgrad(b.convs, xin, gC))) return rc;
             if ((rc = release(rC))) return rc;                               // (the shortcut's dgrad below reads gC on `s`)
         }
-        if ((rc = wgrad(b.conv2, a1, gB))) return rc;
+        if ((rc = fused ? wgrad(b.conv2, at(c1.y_off, c1), gB, b.conv1) : wgrad(b.conv2, a1, gB))) return rc;
         if ((rc = release(rB))) return rc;
         if ((rc = dgrad(b.conv2, gB, gD, nullptr, nullptr, 0))) return rc;   // gD = dL/da1 (pre-mask)
         if (stop_here(bi, 2)) return OCL_OK;
         int rB1;
         float* gB1 = take_dy(&rB1);
-        if ((rc = bn_bwd(gD, a1, b.conv1, gB1, -1, nullptr))) return rc;     // gB1 = dL/dy1
+        if ((rc = bn_bwd(gD, fused ? nullptr : a1, b.conv1, gB1, -1, nullptr, fused))) return rc;     // gB1 = dL/dy1
         gB = gB1;
         if (stop_here(bi, 3)) return OCL_OK;
         if ((rc = publish())) return rc;
@@ -1036,7 +1099,7 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
         }
     }
     // ---- trunk ------------------------------------------------------------------------------------
-    return trunk_backward(n, ps, P, Gr, S, N, G, accumulate, dfeat, s, two_streams ? n->s2 : nullptr, frozen);
+    return trunk_backward(n, ps, P, Gr, S, N, G, accumulate, dfeat, s, two_streams ? n->s2 : nullptr, frozen, n->slot_fused[slot]);
 }
 
 int ocl_net_debug_stop(ocl_net* n, int stage) {
@@ -1079,6 +1142,13 @@ int ocl_net_debug_copy(ocl_net* n, int slot, int what, int index, float* dst, in
         const ConvInfo& c = n->convs[n->blocks[index].conv1];
         src = S + n->blocks[index].a1_off;
         cnt = (int64_t)N * c.Ho * c.Wo * c.Cout;
+        if (n->slot_fused[slot]) {   // the pass never wrote a1: materialise it from the raw output and the saved statistics
+            const BnInfo& b1 = n->bns[c.bn];
+            const int G = std::max(1, n->slot_groups[slot]);
+            int rc = launch_bn_apply_saved(S + c.y_off, S + b1.save_off, S + b1.save_off + (int64_t)kGmax * b1.C, n->params + n->tensors[b1.gamma_t].off,
+                                           n->params + n->tensors[b1.beta_t].off, S + n->blocks[index].a1_off, (int64_t)(N / G) * c.Ho * c.Wo, G, b1.C, s);
+            if (rc != OCL_OK) return rc;
+        }
     } else {
         set_error("debug_copy: what=%d", what);
         return OCL_ERR_ARG;
