@@ -1364,69 +1364,35 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
             load_tile(cur);
         }
         const float* pb = dyt + (size_t)g * a.DP + r16;
-        // One iteration = 16 pixels of the tile = four MFMA k-blocks (lane quarter g supplies pixel 4u + g of block u): per block
-        // MTW A values (patch, through the pixel-offset table) and NTW B values (dy tile).  Rounds 1 - 2 ran an iteration as table
-        // look-up -> wait -> 4 * (MTW + NTW) operand reads -> wait -> MFMAs, i.e. two exposed dependent LDS round trips in front of
-        // every 4 * MTW * NTW MFMAs and nothing in flight across iterations.  Now (the conv kernel's recipe): two operand register
-        // sets, the reads of iteration i + 1 issued before the MFMAs of iteration i, and the table entries of iteration i + 2 read
-        // one iteration ahead of their use, so no wait falls on a read that has just been issued.
-        const int nfull = a.KP >> 4;
-        float av[2][4][MTW], bv[2][4][NTW];
-        int poN[4];
-        auto lookup = [&](int it) __attribute__((always_inline)) {   // table entries of iteration `it` (clamped: past the end they are never used)
-            const int s_ = min(it, nfull - 1) << 4;
+        // (A hand-pipelined form of this loop -- two operand register sets, the reads of iteration i + 1 issued in front of the MFMAs of
+        // iteration i, table entries one iteration further ahead, pinned with sched_barriers: the conv kernel's recipe -- measured 5 - 8 %
+        // SLOWER on every layer, profiles/r3_kbench_wgrad_pipelined_ab.txt: with two or three waves per SIMD the other waves already cover
+        // the two LDS round trips of an iteration, and the second register set costs occupancy.  What bounds this loop is the number of
+        // LDS instructions, one 4-byte read per MFMA; the remedy is K-grouped 16-byte operands, i.e. channel-major tiles.)
+        auto ksteps = [&](int s, auto UC) __attribute__((always_inline)) {
+            constexpr int U = decltype(UC)::value;
+            int po[U];
+            float av[U][MTW], bv[U][NTW];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) poN[u] = pixoff[s_ + 4 * u + g];
-        };
-        auto fetch = [&](int set, int it) __attribute__((always_inline)) {
-            const int s_ = min(it, nfull - 1) << 4;
+            for (int u = 0; u < U; ++u) po[u] = pixoff[s + 4 * u + g];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < U; ++u) {
 #pragma unroll
-                for (int mt = 0; mt < MTW; ++mt) av[set][u][mt] = patch[poN[u] + aoff[mt]];
+                for (int mt = 0; mt < MTW; ++mt) av[u][mt] = patch[po[u] + aoff[mt]];
 #pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) bv[set][u][nt] = pb[(size_t)(s_ + 4 * u) * a.DP + nt * 16];
+                for (int nt = 0; nt < NTW; ++nt) bv[u][nt] = pb[(size_t)(s + 4 * u) * a.DP + nt * 16];
             }
-            lookup(it + 1);
-        };
-        auto fma = [&](int set) __attribute__((always_inline)) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
+            for (int u = 0; u < U; ++u)
 #pragma unroll
                 for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NTW; ++nt)
-                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[set][u][mt], bv[set][u][nt], acc[mt][nt], 0, 0, 0);
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][mt], bv[u][nt], acc[mt][nt], 0, 0, 0);
         };
-        if (nfull > 0) {
-            lookup(0);
-            fetch(0, 0);
-            int it = 0;
-            for (; it + 2 <= nfull; it += 2) {
-                fetch(1, it + 1);
-                __builtin_amdgcn_sched_barrier(0);
-                fma(0);
-                __builtin_amdgcn_sched_barrier(0);
-                fetch(0, it + 2);
-                __builtin_amdgcn_sched_barrier(0);
-                fma(1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if (it < nfull) fma(0);
-        }
-        // pixels past the last whole iteration (tiles whose pixel count is not a multiple of 16: 11 x 11 maps), four at a time
-        for (int s = nfull << 4; s < a.KP; s += 4) {
-            const int po = pixoff[s + g];
-            float a1[MTW], b1[NTW];
-#pragma unroll
-            for (int mt = 0; mt < MTW; ++mt) a1[mt] = patch[po + aoff[mt]];
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) b1[nt] = pb[(size_t)s * a.DP + nt * 16];
-#pragma unroll
-            for (int mt = 0; mt < MTW; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[mt], b1[nt], acc[mt][nt], 0, 0, 0);
-        }
+        int s = 0;
+        for (; s + 16 <= a.KP; s += 16) ksteps(s, std::integral_constant<int, 4>());
+        for (; s < a.KP; s += 4) ksteps(s, std::integral_constant<int, 1>());
     }
     // partial tile out: rows (chunk, mblock, m), cols co
     const int mrows_chunk = a.mblocks_per_chunk * 64 * MTW;
