@@ -220,6 +220,83 @@ def gen_buffer_ops():
     print("buffer ops ok")
 
 
+def gen_mem_match():
+    """utils/buffer/mem_match.py:5-21 (`retrieve_methods['mem_match']`) through the reference's own plugin: random candidates, then
+    their label-matched partners from the BufferClassTracker, redrawn until every candidate has a partner outside the draw.  The
+    memory is filled by the reference's reservoir update (tracker kept by it); every image carries a unique id in its first
+    element, so the recorded ids name the slots the plugin picked.  numpy's and Python's global generators drive the draws."""
+    R.activate()
+    import random as pyrandom
+    from types import SimpleNamespace
+    import utils.buffer.mem_match as ref_mm
+    import utils.buffer.reservoir_update as ref_res
+    import utils.buffer.buffer_utils as ref_bu
+    out = {}
+    # (the reference's loop never ends when the memory cannot hold a partner for every candidate: warm-ups chosen so that it can)
+    cases = [(40, 10, 14, 6, 4, 4, 0), (24, 5, 20, 4, 3, 3, 1), (30, 10, 9, 8, 3, 2, 2)]   # mem, batch, steps, eps_mem_batch, warmup, classes, seed
+    for ci, (mem, bs, steps, nret, warmup, ncls, seed) in enumerate(cases):
+        p = SimpleNamespace(buffer_tracker=True, eps_mem_batch=nret, warmup=warmup)
+
+        class _B(object):
+            pass
+        b = _B()
+        b.buffer_img = torch.zeros(mem, 3, 32, 32)
+        b.buffer_label = torch.zeros(mem, dtype=torch.long)
+        b.current_index = b.n_seen_so_far = 0
+        b.params = p
+        b.buffer_tracker = ref_bu.BufferClassTracker(10, "cpu")
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        pyrandom.seed(seed)
+        upd, mm = ref_res.Reservoir_update(p), ref_mm.MemMatch_retrieve(p)
+        rng = np.random.default_rng(100 + seed)
+        next_id = 1
+        ys_all, ids_all, rec = [], [], []
+        for s_ in range(steps):
+            ys = rng.integers(0, ncls, bs).astype(np.int64)
+            ids = np.arange(next_id, next_id + bs).astype(np.float32)
+            next_id += bs
+            x = torch.zeros(bs, 3, 32, 32)
+            x[:, 0, 0, 0] = torch.from_numpy(ids)
+            with R.quiet():
+                cx, cy, mx, my = mm.retrieve(b)
+            rec.append((cx[:, 0, 0, 0].numpy().copy() if cx.numel() else np.zeros(0, np.float32), cy.numpy().astype(np.int64) if cy.numel() else np.zeros(0, np.int64),
+                        mx[:, 0, 0, 0].numpy().copy() if mx.numel() else np.zeros(0, np.float32), my.numpy().astype(np.int64) if my.numel() else np.zeros(0, np.int64)))
+            upd.update(b, x, torch.from_numpy(ys))
+            ys_all.append(ys); ids_all.append(ids)
+        # the oracle's restatement replayed with the same seeds: same candidates, same partners, same slots, same generator positions
+        st_np, st_py_draw = np.random.get_state()[1][:8].copy(), None
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        pyrandom.seed(seed)
+        ob, tr = O.OracleBuffer(mem, (3, 32, 32)), O.ClassTracker(10)
+        for s_ in range(steps):
+            cand, part = O.mem_match_indices(ob, tr, nret, warmup)
+            assert np.array_equal(ob.img[cand][:, 0, 0, 0].numpy() if len(cand) else np.zeros(0, np.float32), rec[s_][0]), (ci, s_)
+            assert np.array_equal(ob.img[part][:, 0, 0, 0].numpy() if len(part) else np.zeros(0, np.float32), rec[s_][2]), (ci, s_)
+            x = torch.zeros(bs, 3, 32, 32)
+            x[:, 0, 0, 0] = torch.from_numpy(ids_all[s_])
+            O.reservoir_update(ob, x, torch.from_numpy(ys_all[s_]), tracker=tr)
+        assert torch.equal(ob.label, b.buffer_label) and torch.equal(ob.img, b.buffer_img)
+        assert np.array_equal(np.random.get_state()[1][:8], st_np)
+        out["c%d_cfg" % ci] = np.array([mem, bs, steps, nret, warmup, ncls, seed], dtype=np.int64)
+        out["c%d_ys" % ci] = np.stack(ys_all)
+        out["c%d_ids" % ci] = np.stack(ids_all)
+        for k, name in enumerate(("cand_id", "cand_y", "match_id", "match_y")):
+            out["c%d_%s" % (ci, name)] = np.concatenate([r[k] for r in rec])
+            out["c%d_%s_counts" % (ci, name)] = np.array([len(r[k]) for r in rec], dtype=np.int64)
+        out["c%d_final_ids" % ci] = b.buffer_img[:, 0, 0, 0].numpy().copy()
+        out["c%d_final_label" % ci] = b.buffer_label.numpy().copy()
+        out["c%d_np_state" % ci] = np.random.get_state()[1][:8].astype(np.int64)
+        out["c%d_py_draw" % ci] = np.float64(pyrandom.random())
+        n_ret = int((out["c%d_match_id_counts" % ci] > 0).sum())
+        assert n_ret >= 3, "case %d retrieves too rarely (%d)" % (ci, n_ret)
+        print("mem_match case", ci, "retrievals with a match:", n_ret, "of", steps)
+    out["n_cases"] = np.int64(len(cases))
+    np.savez_compressed(os.path.join(GOLD, "mem_match.npz"), **out)
+    print("mem_match ok")
+
+
 def gen_resnet():
     """Seeded init + seeded input: forward outputs, loss, gradient / running-stat digests of the reference modules."""
     R.activate()
@@ -328,9 +405,17 @@ def run_oracle_case(name, sort_fn):
     return recs
 
 
-def gen_steps():
+def gen_steps(only=None):
+    """only: a list of case names to (re)generate into the existing fixture (the others keep their recorded arrays; a full run
+    reproduces them bit for bit -- every case is seeded on its own)."""
     out = {}
+    path = os.path.join(GOLD, "steps.npz")
+    if only and os.path.exists(path):
+        with np.load(path) as f:
+            out = {k: f[k] for k in f.files if not any(k.startswith(n + "_") for n in only)}
     for name, cfg in STEP_CASES.items():
+        if only and name not in only:
+            continue
         recs = run_reference_case(name)
         recs2 = run_reference_case(name)   # determinism of the reference at a fixed thread count
         golden = cfg.get("golden", True)
@@ -355,7 +440,7 @@ if __name__ == "__main__":
     assert R.available(), "reference tree not found"
     torch.set_num_threads(1)
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["knn", "supcon", "ce_tricks", "kd", "buffer", "resnet", "steps"]
+    which = sys.argv[1:] or ["knn", "supcon", "ce_tricks", "kd", "buffer", "mem_match", "resnet", "steps"]
     if "knn" in which:
         gen_knn_sv()
     if "supcon" in which:
@@ -366,7 +451,12 @@ if __name__ == "__main__":
         gen_kd()
     if "buffer" in which:
         gen_buffer_ops()
+    if "mem_match" in which:
+        gen_mem_match()
     if "resnet" in which:
         gen_resnet()
     if "steps" in which:
         gen_steps()
+    for w in which:   # steps:case_a,case_b -> only those cases
+        if w.startswith("steps:"):
+            gen_steps(w[len("steps:"):].split(","))

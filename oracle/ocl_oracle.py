@@ -404,6 +404,23 @@ def match_retrieve_indices(tracker, cur_y, exclude=None):
     return np.asarray(select, dtype=np.int64)
 
 
+def mem_match_indices(buf, tracker, num_retrieve, warmup):
+    """utils/buffer/mem_match.py:11-21: random candidates, then one label-matched partner per candidate from the slots outside the
+    draw; the candidates are redrawn until every one of them finds a partner.  -> (candidate slots, partner slots), both empty
+    before the warm-up or when the memory is empty.  (Like the reference, this never returns when the memory cannot hold a
+    partner for every candidate.)"""
+    empty = np.zeros(0, dtype=np.int64)
+    if not buf.n_seen_so_far > num_retrieve * warmup:
+        return empty, empty
+    while True:
+        cand = random_retrieve_indices(buf, num_retrieve)
+        if cand.shape[0] == 0:
+            return cand, empty
+        partners = match_retrieve_indices(tracker, buf.label[cand], exclude=cand)
+        if partners.shape[0] > 0:
+            return cand, partners
+
+
 class ClassCache(object):
     """utils/buffer/buffer_utils.py:74-160 (ClassBalancedRandomSampling): class -> set of slots, class counts."""
 
@@ -579,11 +596,14 @@ def scr_step(state, names, buf, batch_x, batch_y, params, aug=identity_aug, retr
     return (None if loss is None else float(loss.detach())), idx, slots
 
 
-def er_step(state, names, buf, batch_x, batch_y, params, retrieve="random", gss=None, tracker=None, warmup=4):
-    """agents/exp_replay.py:34-92 for ONE iteration with random / MIR / match retrieval and reservoir or GSS update."""
+def er_step(state, names, buf, batch_x, batch_y, params, retrieve="random", gss=None, tracker=None, warmup=4, kd=None):
+    """agents/exp_replay.py:34-92 for ONE iteration with random / MIR / match retrieval and reservoir or GSS update.
+    kd(loss, logits, x) -> loss: the KD tricks' blend of the cross-entropy with the distillation loss (exp_replay.py:42-47, :64-69)."""
     net = OracleNet(state, head=None, training=True)
     logits = net.forward(batch_x)
     loss = ce_mean(logits, batch_y)
+    if kd is not None:
+        loss = kd(loss, logits, batch_x)
     zero_grad(state, names)
     loss.backward()
     info = {"loss": float(loss.detach())}
@@ -618,6 +638,8 @@ def er_step(state, names, buf, batch_x, batch_y, params, retrieve="random", gss=
     if idx.shape[0] > 0:
         mem_logits = net.forward(buf.img[idx])
         loss_mem = ce_mean(mem_logits, buf.label[idx])
+        if kd is not None:
+            loss_mem = kd(loss_mem, mem_logits, buf.img[idx])
         loss_mem.backward()
         info["loss_mem"] = float(loss_mem.detach())
     sgd_step(state, names, params["lr"])
@@ -890,6 +912,24 @@ class OracleAgent(object):
         self.review_log = []
         self.gss = GssState(cfg) if cfg.get("update") == "GSS" else None
         self.tracker = ClassTracker(self.n_classes) if cfg.get("buffer_tracker") else None
+        self.task_seen = 0          # base.py:37, incremented by after_train (:61)
+        self.teacher = None         # kd_manager.teacher_model: a deep copy of the model, taken (and left) in train mode (kd_manager.py:18-19)
+
+    def _kd_mix(self, loss, logits, x):
+        """exp_replay.py:42-47 (and :64-69 for the memory pass): kd_trick blends with weight 1 / (t + 1), kd_trick_star with
+        1 / sqrt(t + 1); the distillation term is 0 while there is no teacher (kd_manager.py:27-28) -- kd_trick_star alone never gets
+        one (base.py:90), so it only scales the cross-entropy."""
+        def kd_loss():
+            if self.teacher is None:
+                return 0
+            with torch.no_grad():
+                t_logits = OracleNet(self.teacher, head=None, training=True).forward(x)   # the copy's own (train-mode) forward
+            return loss_fn_kd(logits, t_logits)
+        if self.trick.get("kd_trick"):
+            loss = 1 / (self.task_seen + 1) * loss + (1 - 1 / (self.task_seen + 1)) * kd_loss()
+        if self.trick.get("kd_trick_star"):
+            loss = 1 / ((self.task_seen + 1) ** 0.5) * loss + (1 - 1 / ((self.task_seen + 1) ** 0.5)) * kd_loss()
+        return loss
 
     def train_learner(self, x_u8, y):
         new = list(set(y.tolist()))                                            # base.py:43-44
@@ -904,16 +944,20 @@ class OracleAgent(object):
             elif self.cfg["retrieve"] == "ASER" or self.cfg["update"] == "ASER":
                 self.log.append(aser_er_step(self.state, self.names, self.buf, self.cache, bx, by, self.p))
             else:
+                kd = self._kd_mix if (self.trick.get("kd_trick") or self.trick.get("kd_trick_star")) else None
                 self.log.append(er_step(self.state, self.names, self.buf, bx, by, self.p, self.cfg["retrieve"], gss=self.gss,
-                                        tracker=self.tracker, warmup=self.cfg.get("warmup", 4)))
+                                        tracker=self.tracker, warmup=self.cfg.get("warmup", 4), kd=kd))
         self.after_train(new)
 
     def after_train(self, new):
         """base.py:56-91: label bookkeeping, then (review trick) one epoch over the buffer at batch eps_mem_batch with the
         gradients divided by 10."""
         self.old_labels += new                                                 # base.py:58
+        self.task_seen += 1                                                    # base.py:61
         if self.trick.get("review_trick"):
             self.review_log.append(review_epoch(self.state, self.names, self.buf, self.p, self.agent, self.aug))
+        if self.trick.get("kd_trick"):                                         # base.py:90-91
+            self.teacher = clone_state(self.state, requires_grad=False)
 
     def evaluate(self, tests, test_batch=128, detail=None):
         """base.py:118-227 (NCM for SCR / ncm_trick, argmax otherwise); test loaders shuffle (2 RNG draws each).  `detail`

@@ -45,6 +45,13 @@ STEP_CASES = {
     # ER --update GSS (utils/buffer/gss_greedy_update.py): eval-mode per-sample gradients, cosine similarity, multinomial draws
     # (single-class tasks: the first batches of class 1 have gradients pointing away from every memory gradient, max cosine < 0, so
     # the replacement branch :23-43 with its two multinomial draws is taken twice in this run)
+    # the KD tricks of the ER loop (agents/exp_replay.py:42-47,64-69; utils/kd_manager.py): kd_trick_star ALONE never gets a teacher
+    # (agents/base.py:90 takes the copy only for kd_trick), so from the second task on it just scales the cross-entropy by
+    # 1 / sqrt(t + 1); with BOTH tricks the distillation term enters twice, through the same teacher forward
+    "er_kdstar": dict(agent="ER", retrieve="random", update="random", data="cifar10", mem_size=50, eps_mem_batch=10, seed=11,
+                      tasks=[[0, 1], [2, 3]], n_train=30, n_test=20, trick=dict(kd_trick_star=True)),
+    "er_kdboth": dict(agent="ER", retrieve="random", update="random", data="cifar10", mem_size=50, eps_mem_batch=10, seed=12,
+                      tasks=[[0, 1], [2, 3], [4, 5]], n_train=30, n_test=20, trick=dict(kd_trick=True, kd_trick_star=True)),
     "er_gss": dict(agent="ER", retrieve="random", update="GSS", data="cifar10", mem_size=20, eps_mem_batch=10, seed=9,
                    tasks=[[0], [1]], n_train=30, n_test=20, gss_mem_strength=3, gss_batch_size=5, free_run_gpu=False),
 }

@@ -89,6 +89,33 @@ def test_reservoir_and_random_retrieve_sequences_exact():
         assert [buf.current_index, buf.n_seen_so_far] == g["c%d_final_n" % ci].tolist()
 
 
+def test_mem_match_retrieve_matches_reference_plugin():
+    """utils/buffer/mem_match.py through the oracle's restatement against the reference plugin's recorded picks (ids of the samples
+    it returned), the memory it leaves behind and the position of numpy's / Python's global generators."""
+    import random
+    g = gold("mem_match")
+    for ci in range(int(g["n_cases"])):
+        mem, bs, steps, nret, warmup, ncls, seed = [int(v) for v in g["c%d_cfg" % ci]]
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        random.seed(seed)
+        buf, tr = O.OracleBuffer(mem, (3, 32, 32)), O.ClassTracker(10)
+        pos = {"cand_id": 0, "match_id": 0}
+        for s in range(steps):
+            cand, part = O.mem_match_indices(buf, tr, nret, warmup)
+            for k, idx in (("cand_id", cand), ("match_id", part)):
+                n = int(g["c%d_%s_counts" % (ci, k)][s])
+                exp = g["c%d_%s" % (ci, k)][pos[k]:pos[k] + n]
+                pos[k] += n
+                assert np.array_equal(buf.img[idx][:, 0, 0, 0].numpy() if len(idx) else np.zeros(0, np.float32), exp), (ci, s, k)
+            x = torch.zeros(bs, 3, 32, 32)
+            x[:, 0, 0, 0] = torch.from_numpy(g["c%d_ids" % ci][s])
+            O.reservoir_update(buf, x, torch.from_numpy(g["c%d_ys" % ci][s]), tracker=tr)
+        assert np.array_equal(buf.img[:, 0, 0, 0].numpy(), g["c%d_final_ids" % ci]) and np.array_equal(buf.label.numpy(), g["c%d_final_label" % ci])
+        assert np.array_equal(np.random.get_state()[1][:8].astype(np.int64), g["c%d_np_state" % ci])
+        assert random.random() == float(g["c%d_py_draw" % ci])
+
+
 @pytest.mark.parametrize("name,agent,data,hw,n,head", [("rr18_c100", "ER", "cifar100", 32, 6, None), ("scr_mlp", "SCR", "cifar100", 32, 6, "mlp"),
                                                        ("rr18_mini", "ER", "mini_imagenet", 84, 3, None)])
 def test_resnet_forward_backward_matches_reference(name, agent, data, hw, n, head):

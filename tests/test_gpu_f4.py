@@ -1,0 +1,114 @@
+"""GPU: the remaining rows of SURVEY §8f (rank 4) that had no executed test, and the one BASELINE config without an at-size co-simulation.
+
+ * `retrieve_methods['mem_match']` (utils/buffer/mem_match.py:5-21) against the outputs of the REFERENCE plugin recorded by
+   oracle/make_golden.py (tests/golden/mem_match.npz): candidates, label-matched partners, the slots the reservoir update wrote in
+   between, and the positions numpy's / Python's global generators are left in;
+ * the KD tricks of the ER loop (agents/exp_replay.py:42-47,64-69): kd_trick alone, kd_trick_star alone (which never gets a teacher:
+   agents/base.py:90) and both together, co-simulated step by step against the oracle -- whose whole-task runs of the two new cases
+   reproduce the real reference bit for bit (tests/golden/steps.npz: er_kdstar, er_kdboth; their free runs on the GPU are part of
+   test_gpu_steps.test_free_running_cases_vs_reference_golden);
+ * ER random / random at BASELINE config[0]'s memory size (mem_size 1000, full)."""
+import random
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import gold
+from oracle import ocl_oracle as O
+from oracle.synth import STEP_CASES
+from test_gpu_steps import TRICK, _buffers_equal, _prefill_fn, build_agent, cosim, make_params
+
+pytestmark = pytest.mark.gpu
+
+
+def test_mem_match_retrieve_vs_reference_plugin(cuda):
+    from ocl_amd.buffer import Buffer
+    g = gold("mem_match")
+    for ci in range(int(g["n_cases"])):
+        mem, bs, steps, nret, warmup, ncls, seed = [int(v) for v in g["c%d_cfg" % ci]]
+        params = make_params(dict(agent="ER", retrieve="mem_match", update="random", data="cifar10", mem_size=mem, eps_mem_batch=nret, seed=seed,
+                                  tasks=[[0]], buffer_tracker=True, warmup=warmup))
+        buf = Buffer(None, params)
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        random.seed(seed)
+        pos = {k: 0 for k in ("cand_id", "cand_y", "match_id", "match_y")}
+        n_matched = 0
+        for s in range(steps):
+            cx, cy, mx, my = buf.retrieve()
+            got = dict(cand_id=cx[:, 0, 0, 0].cpu().numpy() if cx.numel() else np.zeros(0, np.float32),
+                       cand_y=cy.cpu().numpy() if cy.numel() else np.zeros(0, np.int64),
+                       match_id=mx[:, 0, 0, 0].cpu().numpy() if mx.numel() else np.zeros(0, np.float32),
+                       match_y=my.cpu().numpy() if my.numel() else np.zeros(0, np.int64))
+            for k, v in got.items():
+                n = int(g["c%d_%s_counts" % (ci, k)][s])
+                exp = g["c%d_%s" % (ci, k)][pos[k]:pos[k] + n]
+                pos[k] += n
+                assert len(v) == n and np.array_equal(np.asarray(v, dtype=exp.dtype), exp), (ci, s, k, v, exp)
+            if len(got["match_id"]):
+                n_matched += 1
+                assert np.array_equal(got["cand_y"], got["match_y"])                       # partners carry the candidates' labels ...
+                assert not set(got["cand_id"].tolist()) & set(got["match_id"].tolist())    # ... and are other samples
+            ys = g["c%d_ys" % ci][s]
+            x = torch.zeros(bs, 3, 32, 32)
+            x[:, 0, 0, 0] = torch.from_numpy(g["c%d_ids" % ci][s])
+            buf.update(x.to(cuda), torch.from_numpy(ys).to(cuda), y_host=ys)
+        assert n_matched >= 3
+        assert np.array_equal(buf.buffer_img[:, 0, 0, 0].cpu().numpy(), g["c%d_final_ids" % ci])
+        assert np.array_equal(buf.buffer_label.cpu().numpy(), g["c%d_final_label" % ci]) and np.array_equal(buf.label_host, g["c%d_final_label" % ci])
+        assert np.array_equal(np.random.get_state()[1][:8].astype(np.int64), g["c%d_np_state" % ci])
+        assert random.random() == float(g["c%d_py_draw" % ci])
+
+
+def _sync_teacher(agent, oa):
+    """Teacher forcing for the KD tricks: the HIP teacher snapshot := the oracle's teacher, task counter in step."""
+    agent.task_seen = oa.task_seen
+    if oa.teacher is None:
+        agent.kd_manager.teacher_model = None
+        return
+    model = agent.model
+    student = {k: v.clone() for k, v in model.state_dict().items()}
+    model.load_state_dict({k: v.detach() for k, v in oa.teacher.items()})
+    agent.kd_manager.update_teacher(model)
+    model.load_state_dict(student)
+
+
+@pytest.mark.parametrize("tricks", [("kd_trick",), ("kd_trick_star",), ("kd_trick", "kd_trick_star")])
+def test_cosim_er_kd_tricks(cuda, tricks):
+    """Every iteration is one 10-image `train_learner` call on both sides (so the task counter advances and, with kd_trick, the
+    teacher is re-taken every iteration): blended losses of the batch and the memory pass within 1e-4, indices / slots / RNG
+    exact, update within 1e-2.  With kd_trick_star alone the teacher must stay None on both sides."""
+    cfg = dict(STEP_CASES["er_c10"], mem_size=30, seed=13, trick={k: True for k in tricks})
+    worst, n_kd = 0.0, 0
+    for it, ev, ol, chk in cosim(cfg, 6, cuda, sync_extra=_sync_teacher):
+        agent, oa = chk["agent"], chk["oa"]
+        assert chk["rng_equal"], "host RNG streams diverged at iteration %d" % it
+        assert abs([e["loss"] for t, e in ev if t == "er_loss"][0] - ol["loss"]) < 1e-4
+        assert np.array_equal([e["indices"] for t, e in ev if t == "random_retrieve"][0], ol["idx"])
+        if "loss_mem" in ol:
+            assert abs([e["loss"] for t, e in ev if t == "er_loss_mem"][0] - ol["loss_mem"]) < 1e-4
+        assert [list(e["slots"]) for t, e in ev if t == "reservoir"][0] == list(ol["slots"])
+        assert _buffers_equal(agent, oa) and agent.task_seen == oa.task_seen == it + 1
+        assert (agent.kd_manager.teacher_model is None) == (oa.teacher is None) == ("kd_trick" not in tricks)
+        n_kd += oa.teacher is not None
+        worst = max(worst, chk["upd_err"])
+        print("kd", tricks, "it", it, "loss", ol["loss"], "update err", chk["upd_err"])
+    assert worst < 1e-2 and (n_kd == 6 if "kd_trick" in tricks else n_kd == 0)
+
+
+def test_cosim_er_random_at_baseline_size(cuda):
+    """BASELINE config[0]: ER random / random, Split-CIFAR10 shape, mem_size 1000 with every slot filled, batch 10 + 10."""
+    cfg = dict(STEP_CASES["er_c10"], mem_size=1000, seed=31)
+    worst = 0.0
+    for it, ev, ol, chk in cosim(cfg, 5, cuda, prefill=_prefill_fn(1000, 4321, list(range(10)), 32, 79)):
+        assert chk["rng_equal"]
+        assert abs([e["loss"] for t, e in ev if t == "er_loss"][0] - ol["loss"]) < 1e-4
+        rr = [e["indices"] for t, e in ev if t == "random_retrieve"][0]
+        assert len(rr) == 10 and np.array_equal(rr, ol["idx"]) and int(rr.max()) >= 100      # draws range over the whole memory
+        assert abs([e["loss"] for t, e in ev if t == "er_loss_mem"][0] - ol["loss_mem"]) < 1e-4
+        assert [list(e["slots"]) for t, e in ev if t == "reservoir"][0] == list(ol["slots"])
+        assert _buffers_equal(chk["agent"], chk["oa"])
+        worst = max(worst, chk["upd_err"])
+        print("er@1000 it", it, "update err", chk["upd_err"])
+    assert worst < 1e-2
