@@ -62,6 +62,7 @@ struct ConvArgs {
     // statistics).  Halo positions outside the image stay zero (the convolution pads the ACTIVATION, not the raw output).
     int xf;
     int patch_floats;           // LDS floats of the patch area (the transform table follows it)
+    int qstat_off;              // conv_q_kernel: byte offset of its statistics scratch in LDS ([4 waves][4 rows + 1][2 * 20] floats)
     const double* xf_stats;     // producer's statistics [kStatReps][groups][2][Cin], replica stride xf_rep_stride doubles
     int64_t xf_rep_stride;
     int64_t xf_m_per_group;     // pixels per BatchNorm group of the producer's output
@@ -82,6 +83,7 @@ struct ConvArgs {
 
 struct ConvPlan {
     ConvArgs a;
+    int q4;                     // > 0: conv_q_kernel<q4, ...> (4x4x1 MFMA, <= 20 output channels), q4 = 64-pixel sets per wave; MT = 5 blocks of 4 channels, NT = q4
     int MT, NT;                 // 16-channel tiles and 16-pixel tiles per wave (conv_t_kernel<MT, NT, ...>)
     int grid_x, grid_y;
     size_t lds_bytes;
@@ -96,6 +98,7 @@ struct ConvGeomDesc {
     int ntaps;
     int tdy[9], tdx[9], tw[9];
     int force_MT, force_NT, force_bpc;   // 0 = planner's choice (benchmarks / tests)
+    int force_q4;                        // conv_q_kernel for <= 20 output channels: 0 = planner (OCL_CONV_Q4, default on), 1 = always where it fits, -1 = never
     int force_pipe;                      // staged-weight schedule: 0 = environment (OCL_CONV_PIPE, default on), 1 = ring, -1 = two-buffer
     int WPT;                    // row stride of the K-grouped weight pack (0: the plan's own CoutP)
     int xf;                     // reserve LDS for the input-transform table (ConvArgs::xf may then be set at launch)

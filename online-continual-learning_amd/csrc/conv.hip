@@ -764,6 +764,307 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
     stamp();
 }
 
+
+// =====================================================================================================
+// conv_q_kernel: the convolutions with at most 20 output channels (stem, layer 1, their data gradients) on v_mfma_f32_4x4x1_16b_f32
+// =====================================================================================================
+// A 16x16x4 tile pads 20 output channels to 32 and 45 (tap, channel-quad) groups to 48: 41 % of the MFMAs issued by conv_t_kernel on
+// layer 1 multiply zeros, and layer 1 is the largest single item of a replay step (8 launches, 28 % of the convolution time).  The
+// 4x4x1 form is sixteen independent 4x4 outer products per instruction at the same MACs per cycle (profiles/r3_mfma_4x4x1_calibration.txt:
+// 10.5 - 12 cycles against 8 ideal with this kernel's operand traffic):
+//   block b = 4 consecutive pixels of the wave's 64-pixel set;  B: lane L supplies ITS pixel's input value x[pixel L][k];
+//   A: lane L supplies w[channel 4m + (L & 3)][k] (every block multiplies the same four channels);  D: register i of lane L is
+//   output channel 4m + i of pixel L.
+// So a lane owns one pixel per set and, per block m of four channels, the same "4 consecutive channels of one pixel" accumulator
+// layout as conv_t_kernel: the register epilogue carries over.  Nothing is padded: K runs over the 45 groups themselves (one group =
+// one 16-byte read of the lane's pixel + 5 broadcast reads of the weights' k-quads for 4 * 5 * NTQ MFMAs), channels over 5 blocks.
+// The operand traffic per MFMA is what limits the form (the weights are re-read per 64-pixel set), hence NTQ >= 2 sets per wave and one
+// workgroups per CU kept at two by LDS and registers.  Weights are always resident (<= 14.4 KB); tables, patch staging, input transform and epilogue flags as in
+// conv_t_kernel.
+constexpr int kQBlocks = 5;   // blocks of four output channels (Cout <= 20)
+template <int NTQ, int PF, bool STATS>
+__global__ void __launch_bounds__(256, 2) conv_q_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    constexpr int MB = kQBlocks, COPW = 4 * MB;
+    int* tdesc = (int*)lds_raw;
+    int* ctab = tdesc + kMaxWgTiles * 8;
+    int* qoff = ctab + 16;
+    int* qrow = qoff + a.Qpad;
+    float* wl = (float*)(qrow + a.Qpad);                  // [Qpad][COPW][4]
+    float* patch = wl + (size_t)a.Qpad * COPW * 4;
+    float* xft = patch + a.patch_floats;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int LP = a.LH * a.LW;
+    const int ntiles_all = a.groups * a.tiles_per_group;
+    const int t_begin = (int)(((int64_t)blockIdx.x * ntiles_all) / gridDim.x), t_end = (int)(((int64_t)(blockIdx.x + 1) * ntiles_all) / gridDim.x);
+    const int nwt = t_end - t_begin;
+    if (nwt <= 0) return;
+    const int flags = STATS ? a.flags : (a.flags & ~EPI_STATS);   // (instantiated without the statistics: no partial sums in registers)
+    // ---- plan tables (conv_plan_tables) ----------------------------------------------------------------------------------------
+    const int* __restrict__ blob = a.blob;
+    // Register budget (two workgroups per CU: 256 registers, accumulators in ArchVGPRs so that the K loop carries no accvgpr copies
+    // across its back edge): of the per-thread patch units only the LDS offset and the row word stay resident; the global offsets are
+    // re-read from the plan tables whenever a patch is requested (12 coalesced loads from L2, a whole tile of MFMAs ahead of their use).
+    int pu_lds[PF], pu_rp[PF];
+    const int* pu_tab = blob + a.off_pu + tid;
+    {
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            pu_lds[i] = pu_tab[(3 * i + 1) * 256];
+            pu_rp[i] = pu_tab[(3 * i + 2) * 256];
+        }
+    }
+    int loc_p[NTQ], loc_o[NTQ], loc_il[NTQ];
+    {
+        const int* lc = blob + a.off_loc + tid;
+#pragma unroll
+        for (int nt = 0; nt < NTQ; ++nt) {
+            loc_p[nt] = lc[(3 * nt + 0) * 256];
+            loc_o[nt] = lc[(3 * nt + 1) * 256];
+            loc_il[nt] = lc[(3 * nt + 2) * 256];
+        }
+    }
+    const int4 tile0 = *(const int4*)(blob + a.off_tdesc + (size_t)t_begin * 8);
+    const int ntab = 16 + 2 * a.Qpad, ntd = nwt * 8;
+    const int* td = blob + a.off_tdesc + (size_t)t_begin * 8;
+    const int tab0 = tid < ntab ? blob[tid] : 0, tab1 = tid + 256 < ntab ? blob[tid + 256] : 0;
+    const int td0 = tid < ntd ? td[tid] : 0, td1 = tid + 256 < ntd ? td[tid + 256] : 0;
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in), rs_w = make_rsrc(a.wT);
+    float4 pv[PF];
+    unsigned okm = 0;
+    auto load_patch_d = [&](const int4 d) __attribute__((always_inline)) {
+        okm = 0;
+        int goff[PF];
+#pragma unroll
+        for (int i = 0; i < PF; ++i) goff[i] = pu_tab[(3 * i + 0) * 256];
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int row = pu_rp[i] & 0xffff, pr = (pu_rp[i] >> 16) & 0xff;
+            const bool ok = (row < d.z) & ((unsigned)(d.y + pr) < (unsigned)a.Hin) & (goff[i] >= 0);
+            pv[i] = buf_load16(rs_in, ok ? d.x + goff[i] : kOob);
+            okm |= ok ? (1u << i) : 0u;
+        }
+    };
+    auto store_patch = [&](int nrows, int grp) __attribute__((always_inline)) {
+        const float* tb = xft + (size_t)(grp * a.C4tot) * 8;
+#pragma unroll
+        for (int i = 0; i < PF; ++i)
+            if ((pu_rp[i] & 0xffff) < nrows) {
+                float4 v = pv[i];
+                if (a.xf) {   // block-uniform (ConvArgs::xf)
+                    const float* t = tb + (pu_rp[i] >> 24) * 8;
+                    const float4 sc = *(const float4*)t, sh = *(const float4*)(t + 4);
+                    v.x = fmaxf(__fmaf_rn(v.x, sc.x, sh.x), 0.f); v.y = fmaxf(__fmaf_rn(v.y, sc.y, sh.y), 0.f);
+                    v.z = fmaxf(__fmaf_rn(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(__fmaf_rn(v.w, sc.w, sh.w), 0.f);
+                    if (!((okm >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                *(float4*)(patch + pu_lds[i]) = v;
+            }
+    };
+    load_patch_d(tile0);
+    if (a.xf) {
+        const int C = a.Cin;
+        const double M = (double)a.xf_m_per_group;
+        const bool lead = blockIdx.x == 0;
+        for (int j = tid; j < a.groups * C; j += 256) {
+            const int gq = j / C, c = j - gq * C;
+            double mean, var;
+            bn_batch_moments(a.xf_stats, a.xf_rep_stride, gq, c, C, M, a.xf_eps, mean, var);
+            const double xv = var + (double)a.xf_eps;
+            double invstd = (double)rsqrtf((float)xv);
+            invstd = invstd * (1.5 - 0.5 * xv * invstd * invstd);
+            invstd = invstd * (1.5 - 0.5 * xv * invstd * invstd);
+            float sc, sh;
+            bn_scale_shift(a.xf_gamma[c], a.xf_beta[c], (float)mean, (float)invstd, sc, sh);
+            float* t = xft + (size_t)(gq * (C >> 2) + (c >> 2)) * 8 + (c & 3);
+            t[0] = sc;
+            t[4] = sh;
+            if (lead) {
+                a.xf_save_mean[j] = (float)mean;
+                a.xf_save_invstd[j] = (float)invstd;
+            }
+        }
+        if (lead && a.xf_running_mean)
+            bn_running_update(a.xf_stats, a.xf_rep_stride, a.groups, C, M, a.xf_momentum, a.xf_eps, a.xf_running_mean, a.xf_running_var, a.xf_nbt, tid, 256);
+    }
+    if (tid < ntab) ctab[tid] = tab0;
+    if (tid + 256 < ntab) ctab[tid + 256] = tab1;
+    if (tid < ntd) tdesc[tid] = td0;
+    if (tid + 256 < ntd) tdesc[tid + 256] = td1;
+    __syncthreads();
+    {   // resident weights: global -> LDS without registers, as conv_t_kernel (pack rows [tap * C4tot + c4][WPT][4], columns < Cout <= WPT)
+        const int units = a.Qpad * COPW;
+#pragma unroll 4
+        for (int u0 = wave * 64; u0 < units; u0 += 256) {
+            const int u = u0 + lane;
+            const int q = min(u, units - 1) / COPW, c = min(u, units - 1) - q * COPW;
+            const int row = qrow[q];
+            const int off = (u < units && row >= 0 && c < a.WPT) ? ((row * a.WPT + c) * 4) * 4 : kOob;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (__attribute__((address_space(3))) void*)(wl + (size_t)u0 * 4), 16, off, 0, 0, 0);
+        }
+    }
+    // BatchNorm statistics without partial sums in registers (they would cost 40 registers across the K loop and, with them, the second
+    // workgroup per CU): after every tile a wave reduces its 2 * 20 values over its 64 pixels -- DPP over the 16-lane rows, the four
+    // row sums through a wave-private LDS slot -- and adds them to its own accumulator slot in a fixed order (deterministic); the
+    // flush sums the four waves' slots in fp64 and issues one atomic per channel, as conv_t_kernel does.
+    float* qrows = (float*)(lds_raw + a.qstat_off);   // [4 waves][4 rows][2 * COPW]
+    float* qacc = qrows + 4 * 4 * 2 * COPW;            // [4 waves][2 * COPW]
+    if (STATS && tid < 4 * 2 * COPW) qacc[tid] = 0.f;
+    int run_grp = -1;
+    auto flush_stats = [&]() __attribute__((always_inline)) {
+        __syncthreads();
+        if (STATS && tid < 2 * COPW && run_grp >= 0) {
+            const int which = tid / COPW, c = tid - which * COPW;
+            if (c < a.Cout) {
+                const double v = ((double)qacc[0 * 2 * COPW + tid] + (double)qacc[1 * 2 * COPW + tid]) +
+                                 ((double)qacc[2 * 2 * COPW + tid] + (double)qacc[3 * 2 * COPW + tid]);
+                double* st_ = a.stats + (int64_t)(blockIdx.x % kStatReps) * a.stat_rep_stride;
+                atomicAdd(&st_[((int64_t)run_grp * 2 + which) * a.Cout + c], v);
+            }
+        }
+        __syncthreads();
+        if (STATS && tid < 4 * 2 * COPW) qacc[tid] = 0.f;
+        __syncthreads();
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own weight DMA (and the first patch) landed; the tile loop's barriers publish
+    const float* wlane = wl + (size_t)(lane & 3) * 4;
+    for (int k = 0; k < nwt; ++k) {
+        const int4 d0 = *(const int4*)(tdesc + k * 8);
+        const int4 d1 = *(const int4*)(tdesc + k * 8 + 4);
+        if ((flags & EPI_STATS) && d1.y != run_grp) {
+            if (run_grp >= 0) flush_stats();
+            run_grp = d1.y;
+        }
+        int pbase[NTQ], ooff[NTQ];
+        if (a.aligned) {
+#pragma unroll
+            for (int nt = 0; nt < NTQ; ++nt) {
+                const bool v = loc_il[nt] < d1.x;
+                pbase[nt] = v ? loc_p[nt] : 0;
+                ooff[nt] = v ? d0.w + loc_o[nt] : -1;
+            }
+        } else {
+            const int img0 = d1.w & 0xfffff, ly0 = d1.w >> 20;
+            const int grp_end = min(a.N, (d1.y + 1) * a.group_size);
+#pragma unroll
+            for (int nt = 0; nt < NTQ; ++nt) {
+                const int r = wave * 64 * NTQ + nt * 64 + lane;
+                int pl, lx;
+                const int il = mdiv(r, a.m_ppi, a.ppi, pl);
+                const int p = d1.z + pl;
+                const int n = img0 + il;
+                const bool v = (il < a.imgs) & (n < grp_end) & (p < LP);
+                const int ly = mdiv(p, a.m_lw, a.LW, lx);
+                pbase[nt] = v ? ((il * a.PR + (ly - ly0) * a.is) * a.PC + lx * a.is) * a.CP : 0;
+                ooff[nt] = v ? ((n * a.Hout + ly * a.os + a.oy0) * a.Wout + lx * a.os + a.ox0) * a.Cout : -1;
+            }
+        }
+        f32x4 acc[MB][NTQ];
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int nt = 0; nt < NTQ; ++nt) acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        __syncthreads();   // consumers of the previous patch are done
+        store_patch(d0.z, d1.y);
+        if (k + 1 < nwt) load_patch_d(*(const int4*)(tdesc + (k + 1) * 8));
+        __syncthreads();   // patch (and, the first time, the weights and the transform table) visible
+        {   // K loop: one (tap, channel quad) group per step, operands of group q + 1 read while the MFMAs of group q issue
+            const int nq = a.Qc;
+            float4 bv[2][NTQ], av[2][MB];
+            int fq = 0;
+            int po = qoff[0], po1 = qoff[min(1, nq - 1)];
+            auto fetch = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+                for (int nt = 0; nt < NTQ; ++nt) bv[set][nt] = *(const float4*)(patch + pbase[nt] + po);
+#pragma unroll
+                for (int m = 0; m < MB; ++m) av[set][m] = *(const float4*)(wlane + (size_t)(fq * COPW + 4 * m) * 4);
+                ++fq;
+                po = po1;
+                po1 = qoff[min(fq + 1, nq - 1)];
+            };
+            auto fma = [&](int set) __attribute__((always_inline)) {
+#define OCL_QSTEP(E)                                                                                                      \
+    _Pragma("unroll") for (int m = 0; m < MB; ++m) _Pragma("unroll") for (int nt = 0; nt < NTQ; ++nt)                     \
+        acc[m][nt] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[set][m].E, bv[set][nt].E, acc[m][nt], 0, 0, 0);
+                OCL_QSTEP(x) OCL_QSTEP(y) OCL_QSTEP(z) OCL_QSTEP(w)
+#undef OCL_QSTEP
+            };
+            fetch(0);
+            int q = 0;
+            for (; q + 2 <= nq; q += 2) {
+                fetch(1);
+                __builtin_amdgcn_sched_barrier(0);
+                fma(0);
+                __builtin_amdgcn_sched_barrier(0);
+                fetch(0);
+                __builtin_amdgcn_sched_barrier(0);
+                fma(1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (q < nq) fma(0);
+        }
+        if (STATS && (flags & EPI_STATS)) {   // this tile's sums over the wave's pixels -> the wave's accumulator slot
+            float* rw = qrows + (size_t)(wave * 4 + (lane >> 4)) * 2 * COPW;
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                    for (int nt = 0; nt < NTQ; ++nt) {
+                        const float v = ooff[nt] >= 0 ? acc[m][nt][e] : 0.f;
+                        t1 += v;
+                        t2 = fmaf(v, v, t2);
+                    }
+                    t1 = row16_sum(t1);
+                    t2 = row16_sum(t2);
+                    if ((lane & 15) == 0) {
+                        rw[m * 4 + e] = t1;
+                        rw[COPW + m * 4 + e] = t2;
+                    }
+                }
+            if (lane < 2 * COPW) {   // (same wave: the writes above are ordered before these reads)
+                const float* r0 = qrows + (size_t)(wave * 4) * 2 * COPW + lane;
+                qacc[wave * 2 * COPW + lane] += (r0[0] + r0[2 * COPW]) + (r0[4 * COPW] + r0[6 * COPW]);
+            }
+        }
+        // ---- epilogue from registers: the lane holds channels 4m .. 4m + 3 of its NTQ pixels ---------------------------------------
+#pragma unroll
+        for (int nt = 0; nt < NTQ; ++nt) {
+            const bool pv_ok = ooff[nt] >= 0;
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                const int co = 4 * m;
+                if (!pv_ok || co >= a.Cout) continue;
+                float4 v = make_float4(acc[m][nt][0], acc[m][nt][1], acc[m][nt][2], acc[m][nt][3]);
+                float* op = a.out + (int64_t)ooff[nt] + co;
+                if (flags & EPI_AFFINE) {
+                    const float4 sc = *(const float4*)(a.scale + co), sh = *(const float4*)(a.shift + co);
+                    v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+                }
+                if (flags & EPI_RES) {
+                    const float4 r = *(const float4*)(a.res + (int64_t)ooff[nt] + co);
+                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                }
+                if (flags & EPI_RESMASK) {
+                    const float4 r = *(const float4*)(a.res + (int64_t)ooff[nt] + co);
+                    const float4 mk = *(const float4*)(a.resmask + (int64_t)ooff[nt] + co);
+                    v.x += mk.x > 0.f ? r.x : 0.f; v.y += mk.y > 0.f ? r.y : 0.f; v.z += mk.z > 0.f ? r.z : 0.f; v.w += mk.w > 0.f ? r.w : 0.f;
+                }
+                if (flags & EPI_ACCUM) {
+                    const float4 o = *(const float4*)op;
+                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+                }
+                if (flags & EPI_RELU) {
+                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                }
+                *(float4*)op = v;
+            }
+        }
+    }
+    if ((flags & EPI_STATS) && run_grp >= 0) flush_stats();
+}
+
 #define OCL_CONVT_TILINGS(X) X(1, 1) X(2, 1) X(3, 1) X(4, 1) X(5, 1) X(1, 2) X(2, 2) X(3, 2) X(4, 2) X(5, 2)
 typedef void (*conv_fn_t)(const ConvArgs);
 static conv_fn_t convt_fn(int MT, int NT, int PF, int res, int cls = 0, int pipe = 0) {
@@ -851,8 +1152,95 @@ found:
     return bytes;
 }
 
+// ---- conv_q_kernel plan: 5 blocks of 4 channels, NTQ 64-pixel sets per wave (tile = 256 * NTQ pixels), weights resident, one chunk
+static int plan_conv_q(const ConvGeomDesc& g, ConvPlan* p) {
+    ConvArgs& a = p->a;
+    constexpr int NTQ = 2, COPW = 4 * kQBlocks;
+    if (g.Cout > COPW || g.Cout % 4 || g.ncls > 1) return OCL_ERR_ARG;
+    a.n_splits = 1;
+    a.CoutP = COPW;
+    a.group_size = g.N / g.groups;
+    const int LP = g.LH * g.LW, BM = 256 * NTQ;
+    if (LP >= BM) {
+        a.imgs = 1; a.ppi = BM; a.tiles_per_img = cdiv(LP, BM);
+    } else {
+        a.imgs = std::min(BM / LP, a.group_size); a.ppi = LP; a.tiles_per_img = 1;
+    }
+    a.PC = (g.LW - 1) * g.is + (a.max_dx - a.min_dx) + 1;
+    // lattice rows a tile can touch: exactly BM / LW when tiles start at row boundaries, one more when they straddle
+    const bool whole_rows = BM % g.LW == 0 && LP % BM == 0;
+    const int rows_l = (a.imgs == 1 && LP >= BM) ? (whole_rows ? BM / g.LW : std::min(g.LH, (BM + g.LW - 2) / g.LW + 1)) : g.LH;
+    a.PR = (rows_l - 1) * g.is + (a.max_dy - a.min_dy) + 1;
+    a.C4tot = g.Cin / 4;
+    a.KC = g.Cin;
+    a.CP = ((a.KC / 4) & 1) ? a.KC : a.KC + 4;
+    a.Qc = g.ntaps * (a.KC / 4);
+    a.Qpad = (int)round_up(a.Qc, 4);
+    a.wres = 1; a.pipe = 0; a.QS = a.Qpad; a.nstage = 1;
+    const int units = a.imgs * a.PR * a.PC * (a.KC / 4);
+    if (units > 256 * 12 || a.imgs > 127 || a.PR >= 256 || a.PC >= 256 || a.KC / 4 >= 64) return OCL_ERR_ARG;
+    const int PF = units <= 1024 ? 4 : 12;
+    const size_t patch_b = (size_t)round_up(std::max((size_t)a.imgs * a.PR * a.PC * a.CP * 4, (size_t)8 * COPW * 8), 16);
+    a.patch_floats = (int)(patch_b / 4);
+    size_t lds = (size_t)kMaxWgTiles * 32 + 64 + (size_t)2 * a.Qpad * 4 + (size_t)a.Qpad * COPW * 16 + patch_b + (g.xf ? (size_t)g.groups * g.Cin * 8 : 0);
+    a.qstat_off = (int)round_up(lds, 16);
+    lds = (size_t)a.qstat_off + (size_t)(4 * 4 + 4) * 2 * COPW * 4;   // statistics scratch: row sums + per-wave accumulators
+    if (lds > kLdsLimit - 2048) return OCL_ERR_ARG;
+    a.tiles_per_group = cdiv(a.group_size, a.imgs) * a.tiles_per_img;
+    const int ntiles = g.groups * a.tiles_per_group;
+    // the form wants the machine full of whole tiles: below ~half a tile per CU the 64-pixel tiles of conv_t_kernel spread better
+    if (ntiles < 128 && g.force_q4 <= 0) return OCL_ERR_ARG;
+    a.cls_pack = 1 | (g.ntaps << 4);
+    a.cls_oyx = 0;
+    p->q4 = NTQ; p->MT = kQBlocks; p->NT = NTQ;
+    p->lds_bytes = lds;
+    a.WPT = g.WPT > 0 ? g.WPT : (int)round_up(g.Cout, 16);
+    for (int t = 0; t < 9; ++t) a.tpo[t] = t < a.ntaps ? ((a.tdy[t] - a.min_dy) * a.PC + (a.tdx[t] - a.min_dx)) * a.CP : 0;
+    {
+        const int kc4 = a.KC / 4;
+        a.d_c4 = 256 % kc4;
+        const int d_pix = 256 / kc4;
+        a.d_pc = d_pix % a.PC;
+        a.d_row = d_pix / a.PC;
+    }
+    a.groups = g.groups;
+    a.aligned = a.imgs > 1 ? 1 : ((BM % g.LW == 0 && LP % BM == 0) ? 1 : 0);
+    {
+        auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); };
+        a.m_tpg = magic(a.tiles_per_group); a.m_tpi = magic(a.tiles_per_img); a.m_lw = magic(a.LW); a.m_ppi = magic(a.ppi);
+        a.m_kc4 = magic(a.KC / 4); a.m_pc = magic(a.PC); a.m_pr = magic(a.PR);
+        const int64_t xmax = std::max<int64_t>(std::max<int64_t>(ntiles, (int64_t)LP + BM), 4096);
+        const int64_t dmax = std::max(std::max(a.tiles_per_group, a.tiles_per_img), std::max(std::max(a.LW, a.ppi), std::max(a.PC, a.PR)));
+        if (xmax * dmax >= (1ll << 32)) return OCL_ERR_ARG;
+    }
+    {   // two workgroups per CU where the LDS allows it: the second wave per SIMD covers the other's operand reads
+        int bpc = (int)std::min<size_t>(2, kLdsLimit / (lds + 512));
+        if (g.force_bpc) bpc = g.force_bpc;
+        p->grid_x = std::max(1, std::min(ntiles, 256 * std::max(1, bpc)));
+    }
+    p->grid_x = std::max(p->grid_x, cdiv(ntiles, kMaxWgTiles));
+    p->grid_y = 1;
+    a.off_tdesc = (int)round_up(16 + 2 * a.Qpad, 4);
+    a.off_pu = a.off_tdesc + ntiles * 8;
+    a.off_loc = a.off_pu + 3 * PF * 256;
+    a.blob_ints = a.off_loc + 3 * NTQ * 256;
+    a.blob = nullptr;
+    return OCL_OK;
+}
+
 static int plan_conv_t(const ConvGeomDesc& g, ConvPlan* p) {
     ConvArgs& a = p->a;
+    {   // <= 20 output channels: the 4x4x1 form (no channel / K padding) where it fits and the launch is large enough
+        static const bool env_q4 = [] { const char* e = getenv("OCL_CONV_Q4"); return !(e && atoi(e) == 0); }();
+        if (g.force_q4 > 0 || (g.force_q4 == 0 && env_q4 && !g.force_MT && !g.force_NT)) {
+            ConvPlan q = *p;
+            if (plan_conv_q(g, &q) == OCL_OK) {
+                *p = q;
+                return OCL_OK;
+            }
+        }
+    }
+    p->q4 = 0;
     const int nt16 = cdiv(g.Cout, 16);
     const int LPx = g.LH * g.LW;
     const int64_t tiles64 = (int64_t)g.groups * (LPx >= 64 ? (int64_t)(g.N / g.groups) * cdiv(LPx, 64)
@@ -1025,9 +1413,10 @@ void conv_plan_tables(const ConvPlan& p, std::vector<int>* out) {
     // per-lane output pixels relative to the tile origin
     int* lc = b.data() + a.off_loc;
     for (int tid = 0; tid < 256; ++tid) {
-        const int wave = tid >> 6, r16 = tid & 15;
+        const int wave = tid >> 6, r16 = tid & 15, lane = tid & 63;
         for (int nt = 0; nt < NT; ++nt) {
-            const int r = wave * 16 * NT + nt * 16 + r16;
+            // conv_t_kernel: 16-pixel tiles, the lane's pixel = its r16; conv_q_kernel: 64-pixel sets, one pixel per lane
+            const int r = p.q4 ? wave * 64 * NT + nt * 64 + lane : wave * 16 * NT + nt * 16 + r16;
             const int il = r / a.ppi, pl = r % a.ppi;
             const int ly = pl / a.LW, lx = pl % a.LW;
             lc[(3 * nt + 0) * 256 + tid] = ((il * a.PR + ly * a.is) * a.PC + lx * a.is) * a.CP;
@@ -1171,7 +1560,24 @@ void geom_dgrad(const ConvShape& c, int N, std::vector<ConvGeomDesc>* out, bool 
     }
 }
 
+static conv_fn_t convq_fn(int ntq, int pf, int stats) {
+    if (ntq == 2 && pf == 4) return stats ? conv_q_kernel<2, 4, true> : conv_q_kernel<2, 4, false>;
+    if (ntq == 2 && pf == 12) return stats ? conv_q_kernel<2, 12, true> : conv_q_kernel<2, 12, false>;
+    return nullptr;
+}
+
 int launch_conv(const ConvPlan& p, hipStream_t s) {
+    if (p.q4) {
+        conv_fn_t fq = convq_fn(p.q4, (p.a.off_loc - p.a.off_pu) / (3 * 256), (p.a.flags & EPI_STATS) ? 1 : 0);
+        if (!fq || !p.a.blob) {
+            set_error("launch_conv: no conv_q_kernel for q4=%d / plan without device tables", p.q4);
+            return OCL_ERR_STATE;
+        }
+        ProfScope ps(PROF_CONV, s);
+        hipLaunchKernelGGL(fq, dim3(p.grid_x, p.grid_y), dim3(256), p.lds_bytes, s, p.a);
+        OCL_LAUNCH_CHECK();
+        return OCL_OK;
+    }
     conv_fn_t fn = convt_fn(p.MT, p.NT, convt_pf_for(p.a.imgs * p.a.PR * p.a.PC * (p.a.KC / 4)), p.a.wres, (p.a.cls_pack & 15) > 1, p.a.pipe);
     if (!fn) {
         set_error("launch_conv: no kernel for MT=%d NT=%d", p.MT, p.NT);
@@ -2373,6 +2779,10 @@ int conv_kernels_init() {
         for (int pf = 4; pf <= 8; pf += 4)
             for (int cls = 0; cls < 2; ++cls)
                 OCL_HIP(hipFuncSetAttribute((const void*)convt_fn(m, 1, pf, 0, cls, 1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+    for (int st = 0; st < 2; ++st) {
+        OCL_HIP(hipFuncSetAttribute((const void*)convq_fn(2, 4, st), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+        OCL_HIP(hipFuncSetAttribute((const void*)convq_fn(2, 12, st), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+    }
     done = true;
     return OCL_OK;
 }

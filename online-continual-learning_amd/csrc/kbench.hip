@@ -203,13 +203,20 @@ static void bench_geom(const char* lname, const char* kind, ConvGeomDesc g, cons
         CK(hipMalloc(&stats2, kStatReps * 8 * 2 * 1024 * 8));
         for (int mt = 0; mt <= (sweep ? 5 : 0); ++mt)
             for (int nt = (mt ? 1 : 0); nt <= (mt ? 2 : 0); ++nt)
-            for (int pipe = 0; pipe < 2; ++pipe) {   // staged-weight plans: the two-buffer schedule, then the three-buffer ring
+            for (int pipe = 0; pipe < 3; ++pipe) {   // staged-weight plans: the two-buffer schedule, then the three-buffer ring; 2: conv_t_kernel where the planner takes conv_q_kernel
                 ConvGeomDesc gt = g;
                 gt.force_MT = mt; gt.force_NT = nt;
-                gt.force_pipe = pipe ? 1 : -1;
+                gt.force_pipe = pipe == 1 ? 1 : -1;
+                gt.force_q4 = pipe == 2 ? -1 : 0;
                 ConvPlan pt;
                 if (plan_conv(gt, &pt) != OCL_OK) continue;
-                if (pipe && !pt.a.pipe) continue;
+                if (pipe == 1 && !pt.a.pipe) continue;
+                if (pipe == 2) {   // only when the default plan is the 4x4x1 form
+                    ConvGeomDesc g0 = gt;
+                    g0.force_q4 = 0;
+                    ConvPlan p0;
+                    if (mt || plan_conv(g0, &p0) != OCL_OK || !p0.q4) continue;
+                }
                 OK(conv_plan_finalize(&pt));   // (kbench leaks the plans' device tables: a measurement tool that exits right after)
                 CK(hipMemset(out, 0, out_elems * 4));
                 CK(hipMemset(stats2, 0, kStatReps * 8 * 2 * 1024 * 8));
@@ -284,8 +291,8 @@ static void bench_geom(const char* lname, const char* kind, ConvGeomDesc g, cons
                     }
                     CK(hipFree(tr));
                 }
-                printf("    conv_t%s%s MT=%d NT=%d grid=%5dx%d lds=%6zu KC=%3d Q=%3d QS=%3d res=%d  %7.1f us %6.1f TF/s  maxdiff=%.2e statdiff=%.1e%s\n",
-                       mt ? "      " : " (auto)", pipe ? " ring" : "     ", pt.MT, pt.NT, pt.grid_x, pt.grid_y, pt.lds_bytes, pt.a.KC, pt.a.Qc, pt.a.QS, pt.a.wres, t,
+                printf("    conv_%c%s%s MT=%d NT=%d grid=%5dx%d lds=%6zu KC=%3d Q=%3d QS=%3d res=%d  %7.1f us %6.1f TF/s  maxdiff=%.2e statdiff=%.1e%s\n",
+                       pt.q4 ? 'q' : 't', mt ? "      " : (pipe == 2 ? " (no-q)" : " (auto)"), pipe == 1 ? " ring" : "     ", pt.MT, pt.NT, pt.grid_x, pt.grid_y, pt.lds_bytes, pt.a.KC, pt.a.Qc, pt.a.QS, pt.a.wres, t,
                        flops / t * 1e-6, d, ds, (d > 1e-3 || ds > 1e-3) ? "  <-- MISMATCH" : "");
             }
         CK(hipFree(stats2));
