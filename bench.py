@@ -334,15 +334,18 @@ def accuracy_oracle(seeds, threads):
     all at once on the host cores (test infrastructure: the checker, not the thing measured)."""
     import subprocess
     t0 = time.perf_counter()
+    # every seed of the smooth stream (its spread over the seeds is the yardstick for the augmentation comparison), the first seed of
+    # the white-noise stream (the like-for-like check of the identity-augmentation run): four concurrent runs keep the leg bounded
+    todo = {"smooth_prototype": list(seeds), "noise_prototype": list(seeds[:1])}
     procs = {(k, s): subprocess.Popen([sys.executable, os.path.abspath(__file__), "--oracle-accuracy-worker", str(s), k, str(threads)],
                                       stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=dict(os.environ, OMP_NUM_THREADS=str(threads)))
-             for k in ACC_STREAMS for s in seeds}
+             for k in ACC_STREAMS for s in todo[k]}
     res = {k: json.loads(p.communicate()[0].strip().splitlines()[-1]) for k, p in procs.items()}
     out = {}
     for kind in ACC_STREAMS:
-        accs = np.array([res[(kind, s)]["acc"] for s in seeds])
-        out[kind] = dict(summarise_accuracy(accs), runs=len(seeds), end_acc_per_run=[float(a[-1].mean()) for a in accs],
-                         run_wall_s=[res[(kind, s)]["wall_s"] for s in seeds])
+        accs = np.array([res[(kind, s)]["acc"] for s in todo[kind]])
+        out[kind] = dict(summarise_accuracy(accs), runs=len(todo[kind]), seeds=todo[kind], end_acc_per_run=[float(a[-1].mean()) for a in accs],
+                         run_wall_s=[res[(kind, s)]["wall_s"] for s in todo[kind]])
     out.update(wall_s=time.perf_counter() - t0, threads_per_run=threads, kind="port (oracle restatement, identity augmentation)")
     return out
 
@@ -488,9 +491,10 @@ def main():
             acc_res["cpu_oracle"] = orc
             for kind in ACC_STREAMS:
                 h, hi, o = acc_res[kind]["hip"], acc_res[kind]["hip_identity_augmentation"], orc[kind]
-                spread = max(o["end_acc_per_run"]) - min(o["end_acc_per_run"])
+                spread = (max(o["end_acc_per_run"]) - min(o["end_acc_per_run"])) if o["runs"] > 1 else None
+                same = [hi["end_acc_per_run"][acc_seeds.index(s)] for s in o["seeds"]]     # the HIP identity runs of the oracle's seeds
                 acc_res[kind]["summary"] = dict(
-                    abs_diff_avg_end_acc_identity_vs_oracle=abs(hi["avg_end_acc"]["mean"] - o["avg_end_acc"]["mean"]),
+                    abs_diff_avg_end_acc_identity_vs_oracle=abs(float(np.mean(same)) - o["avg_end_acc"]["mean"]),
                     oracle_spread_over_seeds=spread,
                     product_minus_identity_augmentation=h["avg_end_acc"]["mean"] - hi["avg_end_acc"]["mean"])
         line["accuracy"] = acc_res

@@ -107,12 +107,21 @@ struct ConvGeomDesc {
 };
 
 int plan_conv(const ConvGeomDesc& g, ConvPlan* p);
-// the plan's tables as the kernel reads them (host arithmetic only); conv_plan_finalize puts them into device memory (one hipMalloc +
-// one blocking copy per plan: plans are made once per batch shape) and sets p->a.blob -- a plan must be finalized before launch_conv;
-// conv_plan_release frees them
+// the plan's tables as the kernel reads them (host arithmetic only); conv_plan_finalize puts them into device memory and sets
+// p->a.blob -- a plan must be finalized before launch_conv (the engine does it at a plan's first launch)
 void conv_plan_tables(const ConvPlan& p, std::vector<int>* out);
-int conv_plan_finalize(ConvPlan* p);
-void conv_plan_release(ConvPlan* p);
+// Device memory for plan tables: 8 MB chunks (hipMalloc only when a chunk fills up -- batch shapes first seen in the steady state, like
+// the varying evaluation-set sizes of the ASER update, must not pay an allocation + a blocking copy per plan), uploads are asynchronous
+// on the stream the plan is about to be launched on, the host copies stay alive with the arena.
+struct PlanArena {
+    std::vector<void*> chunks;
+    size_t used = 0, cap = 0;
+    std::vector<std::vector<int>*> host_keep;
+};
+void plan_arena_release(PlanArena* a);
+// arena == nullptr: one hipMalloc + one blocking copy for this plan (measurement tools)
+int conv_plan_finalize(ConvPlan* p, PlanArena* arena = nullptr, hipStream_t s = nullptr);
+void conv_plan_release(ConvPlan* p);   // plans finalized without an arena
 
 // One convolution layer of the network (models/resnet.py:10-12,25-30): shapes and weight-pack row strides.
 struct ConvShape {

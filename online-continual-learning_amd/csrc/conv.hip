@@ -1129,7 +1129,8 @@ static size_t convt_layout(const ConvGeomDesc& g, ConvArgs& a, int MT, int NT, b
             a.Qpad = 0;   // every class's groups are padded to whole rounds of 4
             for (int c = 0; c < std::max(1, g.ncls); ++c) a.Qpad += (int)round_up((g.ncls > 1 ? g.cls_ntaps[c] : g.ntaps) * (KC / 4), 4);
             const size_t w_all = (size_t)a.Qpad * COPW * 16;
-            a.wres = (KC == g.Cin && w_all <= kResidentBytes) ? 1 : 0;
+            static const size_t res_limit = [] { const char* e = getenv("OCL_RES_KB"); return e ? (size_t)atoi(e) * 1024 : kResidentBytes; }();   // (measurement knob)
+            a.wres = (KC == g.Cin && w_all <= res_limit) ? 1 : 0;
             a.pipe = (pipe && !a.wres && NT == 1) ? 1 : 0;   // ring of three stage buffers of pipe_qs(MT) groups (conv_t_kernel<..., PIPE>)
             a.QS = a.wres ? a.Qpad : a.pipe ? pipe_qs(MT) : std::min(a.Qpad, ((256 * kWPF) / COPW) & ~3);
             a.nstage = cdiv(a.Qpad, a.QS);
@@ -1426,15 +1427,41 @@ void conv_plan_tables(const ConvPlan& p, std::vector<int>* out) {
     }
 }
 
-int conv_plan_finalize(ConvPlan* p) {
+int conv_plan_finalize(ConvPlan* p, PlanArena* arena, hipStream_t s) {
     if (p->a.blob) return OCL_OK;
-    std::vector<int> t;
-    conv_plan_tables(*p, &t);
-    int* d = nullptr;
-    OCL_HIP(hipMalloc((void**)&d, t.size() * sizeof(int)));
-    OCL_HIP(hipMemcpy(d, t.data(), t.size() * sizeof(int), hipMemcpyHostToDevice));
+    if (!arena) {
+        std::vector<int> t;
+        conv_plan_tables(*p, &t);
+        int* d = nullptr;
+        OCL_HIP(hipMalloc((void**)&d, t.size() * sizeof(int)));
+        OCL_HIP(hipMemcpy(d, t.data(), t.size() * sizeof(int), hipMemcpyHostToDevice));
+        p->a.blob = d;
+        return OCL_OK;
+    }
+    std::vector<int>* t = new std::vector<int>();
+    arena->host_keep.push_back(t);
+    conv_plan_tables(*p, t);
+    const size_t bytes = (size_t)round_up((int64_t)t->size() * sizeof(int), 256);
+    if (arena->chunks.empty() || arena->used + bytes > arena->cap) {
+        const size_t cap = std::max<size_t>(8u << 20, bytes);
+        void* c = nullptr;
+        OCL_HIP(hipMalloc(&c, cap));
+        arena->chunks.push_back(c);
+        arena->used = 0;
+        arena->cap = cap;
+    }
+    int* d = (int*)((char*)arena->chunks.back() + arena->used);
+    arena->used += bytes;
+    OCL_HIP(hipMemcpyAsync(d, t->data(), t->size() * sizeof(int), hipMemcpyHostToDevice, s));
     p->a.blob = d;
     return OCL_OK;
+}
+void plan_arena_release(PlanArena* a) {
+    for (void* c : a->chunks) (void)hipFree(c);
+    for (auto* v : a->host_keep) delete v;
+    a->chunks.clear();
+    a->host_keep.clear();
+    a->used = a->cap = 0;
 }
 void conv_plan_release(ConvPlan* p) {
     if (p->a.blob) (void)hipFree((void*)p->a.blob);

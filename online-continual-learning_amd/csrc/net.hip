@@ -100,6 +100,7 @@ struct ocl_net {
     std::vector<int> slot_n, slot_groups;
     std::vector<bool> slot_valid, slot_frozen, slot_fused;   // fused: bn1 + ReLU of every block ran inside conv2 (no a1 on the tape)
     std::map<std::pair<int, int>, PlanSet> plans;
+    PlanArena plan_arena;         // device tables of the plans (written at a plan's first launch)
 
     float* slotf(int slot) const { return (float*)(ws + slot_base + (int64_t)slot * slot_bytes); }
     float* gbuf(int i) const { return (float*)(ws + off_g[i]); }
@@ -356,7 +357,6 @@ static int get_plans(ocl_net* n, int N, int groups, PlanSet** out) {
         g.xf = c.xf_src >= 0 ? 1 : 0;   // room for the input-transform table (used by train-mode passes only)
         int rc = plan_conv(g, &ps.fwd[i]);
         if (rc != OCL_OK) return rc;
-        if ((rc = conv_plan_finalize(&ps.fwd[i])) != OCL_OK) return rc;
         n->pack_need_fwd |= PACK_TF;
         if (c.Cin != 3) {
             // stride-2 3x3: the four parity classes as one launch where conv_t_kernel can take them (OCL_DGRAD_MERGE=0: four launches)
@@ -371,7 +371,6 @@ static int get_plans(ocl_net* n, int N, int groups, PlanSet** out) {
                 ConvPlan p;
                 rc = plan_conv(q, &p);
                 if (rc != OCL_OK) return rc;
-                if ((rc = conv_plan_finalize(&p)) != OCL_OK) return rc;
                 ps.dgrad[i].push_back(p);
                 n->pack_need_bwd |= PACK_TD;
             }
@@ -444,8 +443,13 @@ struct XfBn {
     int64_t m_per_group;
 };
 
-static int run_conv(ocl_net* n, ConvPlan p, const float* in, const float* wT, float* out, int flags, double* stats,
+static int run_conv(ocl_net* n, ConvPlan& cached, const float* in, const float* wT, float* out, int flags, double* stats,
                     const float* scale, const float* shift, const float* res, const float* resmask, hipStream_t s, const XfBn* xf = nullptr) {
+    if (!cached.a.blob) {   // first launch of this plan: its tables go to the device, on this stream, in front of the launch
+        int rc = conv_plan_finalize(&cached, &n->plan_arena, s);
+        if (rc != OCL_OK) return rc;
+    }
+    ConvPlan p = cached;
     if (xf) {
         p.a.xf = 1;
         p.a.xf_stats = xf->stats;
@@ -562,11 +566,7 @@ void ocl_net_destroy(ocl_net* net) {
     if (net->ev_join) (void)hipEventDestroy(net->ev_join);
     if (net->ev_fork) (void)hipEventDestroy(net->ev_fork);
     if (net->s2) (void)hipStreamDestroy(net->s2);
-    for (auto& kv : net->plans) {   // the plans' device tables
-        for (auto& p : kv.second.fwd) conv_plan_release(&p);
-        for (auto& v : kv.second.dgrad)
-            for (auto& p : v) conv_plan_release(&p);
-    }
+    plan_arena_release(&net->plan_arena);   // the plans' device tables
     delete net;
 }
 
@@ -737,7 +737,11 @@ int ocl_net_forward(ocl_net* n, const float* x, int N, int groups, uint32_t flag
     }
     const float* P = params_override ? params_override : n->params;
     PlanSet* ps = nullptr;
-    int rc = get_plans(n, N, train ? groups : 1, &ps);
+    // Eval-mode passes have no cross-image terms (folded BatchNorm): their plans are made for the batch rounded up to 16 images (the
+    // extra images are whatever the activation buffers hold; nothing reads their outputs), so the evaluation sets of the ASER update,
+    // whose size changes from step to step, share a handful of plan sets instead of planning a new one almost every step.
+    const int Nplan = train ? N : std::min(n->d.max_batch, (N + 15) / 16 * 16);
+    int rc = get_plans(n, Nplan, train ? groups : 1, &ps);
     if (rc != OCL_OK) return rc;
     float* pack = (float*)(n->ws + n->off_pack);
     int max_elems = 0;

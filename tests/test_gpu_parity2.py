@@ -583,3 +583,22 @@ def test_sharded_runs_two_processes(cuda):
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert "SHARDED_OK world=2" in r.stdout, r.stdout[-2000:]
+
+
+def test_bench_gpus_2_launches_its_own_ranks(cuda):
+    """`python bench.py --gpus 2` with no launcher around it: bench.py re-executes itself under torch.distributed.run with two ranks
+    (one per GPU over RCCL; on a one-GPU box both ranks share GPU 0 and the scalars travel over gloo), each rank runs its own
+    independent stream (experiment/run.py:34 sharded), and rank 0 prints ONE line with n_gpus = 2 and the per-rank rates."""
+    import json
+    env = dict(os.environ, PYTHONPATH=ROOT, PYTHONDONTWRITEBYTECODE="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--workload", "er", "--no-roofline"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and len(d["per_rank_images_per_s"]) == 2
+    assert d["value"] > 0 and abs(d["value"] - 2 * 20 * 10 / (d["ms_per_step"] * 20 * 1e-3)) < 1e-6 * d["value"]   # whole-job rate = all ranks' images / max-over-ranks time
+    assert "cpu_baseline" not in d and "accuracy" not in d                                                       # single-GPU record only
