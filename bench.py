@@ -96,7 +96,7 @@ def pmc_traffic(kernel):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 k = json.load(f)["kernels"]
-                k = k.get(kernel) or k["conv_gemm_kernel"]   # (the round-2 file still carries the name of the kernel conv_t_kernel replaced)
+                k = k.get("conv_fwd_dgrad") or k.get(kernel) or k["conv_gemm_kernel"]   # r3: conv_t + conv_q launches together; (the round-2 file still carries the name of the kernel conv_t_kernel replaced)
                 return k["hbm_bytes_per_launch"], "profiles/" + name
         except Exception:
             continue

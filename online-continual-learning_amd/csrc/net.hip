@@ -1006,15 +1006,26 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
     int rS;
     float* gS = take_dy(&rS);
     if ((rc = bn_bwd(gA, at(n->zstem_off, c0), 0, gS, -1, nullptr))) return rc;
-    // The stem's weight gradient is the tail of the backward (nothing left to overlap it with): it runs on the caller's stream, after
-    // the join (the side stream's last kernels share the split-K slab buffer), without two more cross-stream hand-offs (~30 us of
-    // event latency in the trace) around it.
+    // The stem's weight gradient is the tail of the backward: it runs on the caller's stream (no two more cross-stream hand-offs, ~30 us
+    // of event latency in the trace) BESIDE the side stream's last kernels -- layer 1's weight gradients, the largest of the step, are
+    // still running there when the chain ends -- with its own slab region (the slabs of one layer stay under 12 MB; the stem's start
+    // 16 MB into the buffer), and the join follows it.
     (void)rS;
     if (two_streams) {
+        WgradPlan wp = ps->wgrad[0];
+        wp.a.x = S + n->x4_off + (int64_t)img0 * n->d.in_h * n->d.in_w * 4;
+        wp.a.dy = gS;
+        wp.a.partial = partial + (int64_t)(16ll << 20) / 4;
+        if ((int64_t)(16ll << 20) / 4 + (int64_t)wp.partial_floats > n->partial_floats) wp.a.partial = nullptr;   // (workspace too small: after the join)
+        if (wp.a.partial) {
+            if ((rc = launch_wgrad(wp, s))) return rc;
+            if ((rc = launch_wgrad_reduce(wp, GT(n->convs[0].w_t), accumulate, s))) return rc;
+        }
         OCL_HIP(hipEventRecord(n->ev_join, sw));
         OCL_HIP(hipStreamWaitEvent(s, n->ev_join, 0));
         for (int i = 0; i < ocl_net::kDyRing; ++i) n->ev_done_pending[i] = false;   // covered by the join
         sw = s;
+        if (wp.a.partial) return OCL_OK;
     }
     if ((rc = wgrad(0, S + n->x4_off + (int64_t)img0 * n->d.in_h * n->d.in_w * 4, gS))) return rc;
     if (batched && rm.n > 0 && (rc = launch_wgrad_reduce_multi(rm, s))) return rc;
