@@ -509,7 +509,13 @@ static const int kSideExtraMinBatch = 96;   // projection shortcut / head weight
 
 static int ensure_side_stream(ocl_net* n) {
     if (n->s2) return OCL_OK;
-    OCL_HIP(hipStreamCreateWithFlags(&n->s2, hipStreamNonBlocking));
+    {   // the weight gradients are needed by nobody until the optimiser step: their stream yields to the dependent chain when both
+        // have workgroups to place (OCL_SIDE_PRIO=0: same priority)
+        int lo = 0, hi = 0;
+        OCL_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = least urgent (numerically greatest)
+        static const bool env_noprio = [] { const char* e = getenv("OCL_SIDE_PRIO"); return e && e[0] == '0'; }();
+        OCL_HIP(hipStreamCreateWithPriority(&n->s2, hipStreamNonBlocking, env_noprio ? 0 : lo));
+    }
     for (int i = 0; i < ocl_net::kDyRing; ++i) OCL_HIP(hipEventCreateWithFlags(&n->ev_done[i], hipEventDisableTiming));
     OCL_HIP(hipEventCreateWithFlags(&n->ev_join, hipEventDisableTiming));
     OCL_HIP(hipEventCreateWithFlags(&n->ev_fork, hipEventDisableTiming));
