@@ -240,6 +240,32 @@ def test_eval_forward_features_vs_oracle(cuda, agent, data, head, n):
             assert torch.equal(sd2[k].cpu(), sd[k]), "eval forward must not touch BatchNorm buffers"
 
 
+def test_eval_forward_one_large_batch_with_rounded_plans(cuda):
+    """One eval-mode pass of 150 images (the shape of ASER's scoring passes): its plans are made for the batch rounded up to 160
+    (net.hip: eval-mode plans are bucketed to 16 images; the extra images are whatever the buffers hold), the 20-channel layers run on
+    conv_q_kernel's folded-BatchNorm epilogue (>= 128 tiles of 512 pixels).  Features of the 150 real images against the oracle, and a
+    second pass of 146 images -- same plan set, different garbage in the padding -- must reproduce the first 146 rows bit for bit."""
+    m, sd = build("ER", "cifar100", "mlp", cuda=cuda, max_batch=256)
+    rng = np.random.default_rng(4)
+    for k in sd:
+        if k.endswith("running_mean"):
+            sd[k] = torch.from_numpy(rng.standard_normal(sd[k].shape).astype(np.float32) * 0.1)
+        if k.endswith("running_var"):
+            sd[k] = torch.from_numpy((0.5 + rng.random(sd[k].shape)).astype(np.float32))
+    m.load_state_dict(sd)
+    x = rng.random((150, 3, 32, 32)).astype(np.float32)
+    net = O.OracleNet(O.clone_state(sd, requires_grad=False), head=None, training=False)
+    with torch.no_grad():
+        f_ref = net.features(torch.from_numpy(x)).numpy()
+    m.eval()
+    xd = torch.from_numpy(x).to(cuda)
+    with torch.no_grad():
+        f = m.features_batched(xd).cpu().numpy()
+        f2 = m.features_batched(xd[:146]).cpu().numpy()
+    assert f.shape == f_ref.shape and relmax(f, f_ref) < 1e-4
+    assert np.array_equal(f2, f[:146])
+
+
 def test_virtual_params_forward_does_not_touch_model(cuda):
     """MIR's theta - lr*grad forward (mir_retrieve.py:21,25) through params_override."""
     m, sd = build("ER", "cifar100", cuda=cuda)
