@@ -8,8 +8,14 @@ proportion to their scores.
 All gradients are those of an EVAL-mode forward (the plugin switches the model to eval() first): the engine records such a pass
 with OCL_FWD_FROZEN_BN and back-propagates through the running-statistics BatchNorm.  Gradient vectors never leave the GPU: the
 engine's flat gradient array is the get_grad_vector layout, `ocl_cosine_max` reduces a [k, n_params] stack against it.  What the
-reference draws on the CPU generator (randperm, the two multinomials) is drawn there, so the decisions need the scores on the
-host: one small device->host copy per similarity batch, as in the reference's `.cpu()` / `if batch_sim < 0`."""
+reference draws on the CPU generator is drawn there, so the decisions need the scores on the host: one small device->host copy per
+similarity batch, as in the reference's `.cpu()` / `if batch_sim < 0`.
+
+Generator parity is with the reference running on the CPU DEVICE (params.cuda = False, the configuration the oracle and the golden
+run `er_gss` pin): there randperm and both multinomials consume the CPU generator.  In a CUDA run of the reference only the first
+multinomial does (`buffer_score.cpu()`, gss_greedy_update.py:28-30); the second (`outcome`, :41) is drawn from CUDA tensors, i.e. from
+the CUDA generator, whose stream this path neither has nor imitates -- here it consumes CPU-generator draws instead, so every later
+`torch.randperm` / `uniform_` of a run is shifted relative to a CUDA reference run."""
 import torch
 
 from .. import debug
