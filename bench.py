@@ -182,7 +182,7 @@ def gpu_leg(args, rank, world, local, workload=None, steps=None, warmup=None):
         g = cls["conv_gemm"]
         wg = cls["conv_wgrad"]
         out["roofline"] = dict(
-            bound="mfma", kernel="conv_t_kernel (implicit-GEMM forward + data-gradient; class PROF_CONV of ocl_prof_*)",
+            bound="mfma", kernel="conv_t_kernel + conv_q_kernel + conv_s_kernel (implicit-GEMM forward + data-gradient; class PROF_CONV of ocl_prof_*)",
             achieved=(gemm_fl * n_prof / (g["ms"] * 1e-3) / 1e12) if g["ms"] > 0 else None,
             peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
             frac=(gemm_fl * n_prof / (g["ms"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if g["ms"] > 0 else None,

@@ -83,6 +83,7 @@ struct ConvArgs {
 
 struct ConvPlan {
     ConvArgs a;
+    int cs;                     // 1: conv_s_kernel (16-pixel tiles, the four waves split the input channels; MT = NT = 1)
     int q4;                     // > 0: conv_q_kernel<q4, ...> (4x4x1 MFMA, <= 20 output channels), q4 = 64-pixel sets per wave; MT = 5 blocks of 4 channels, NT = q4
     int MT, NT;                 // 16-channel tiles and 16-pixel tiles per wave (conv_t_kernel<MT, NT, ...>)
     int grid_x, grid_y;
@@ -98,6 +99,7 @@ struct ConvGeomDesc {
     int ntaps;
     int tdy[9], tdx[9], tw[9];
     int force_MT, force_NT, force_bpc;   // 0 = planner's choice (benchmarks / tests)
+    int force_cs;                        // conv_s_kernel for few output pixels: 0 = planner (OCL_CONV_S, default on), 1 = always where it fits, -1 = never
     int force_q4;                        // conv_q_kernel for <= 20 output channels: 0 = planner (OCL_CONV_Q4, default on), 1 = always where it fits, -1 = never
     int force_pipe;                      // staged-weight schedule: 0 = environment (OCL_CONV_PIPE, default on), 1 = ring, -1 = two-buffer
     int WPT;                    // row stride of the K-grouped weight pack (0: the plan's own CoutP)

@@ -1065,8 +1065,227 @@ __global__ void __launch_bounds__(256, 2) conv_q_kernel(const ConvArgs a) {
     if ((flags & EPI_STATS) && run_grp >= 0) flush_stats();
 }
 
-#define OCL_CONVT_TILINGS(X) X(1, 1) X(2, 1) X(3, 1) X(4, 1) X(5, 1) X(1, 2) X(2, 2) X(3, 2) X(4, 2) X(5, 2)
+
+// =====================================================================================================
+// conv_s_kernel: few output pixels, deep K (layers 3 - 4 of a 10 - 20-image pass)
+// =====================================================================================================
+// A 20-image pass has 320 output pixels on layer 4 and 1280 on layer 3: five / twenty 64-pixel tiles.  conv_t_kernel gives every
+// wave 16 of a tile's pixels and the WHOLE K dimension -- 360 dependent-chain MFMAs per wave on layer 4, on 20 - 60 workgroups of
+// the 256 CUs: 14 - 20 us for 0.15 GFLOP (profiles/r3_aser_kernel_stats_v2_single_stream.csv: 25 such launches per ASER step).
+// Here a workgroup owns 16 NT pixels x 16 channels and its four waves split K by INPUT CHANNELS (wave w: channels [w, w + 1) * Cin / 4,
+// all taps): 4x the workgroups, a quarter of the chain; each wave stages its own channel slice of the (shared-halo) patch, takes its
+// weights straight from the pack in global memory / L2 into registers (16 bytes per lane and round, requested kDepthS rounds ahead:
+// nothing about them is shared between waves, so LDS would only add a copy), and the four partial tiles meet in LDS, where wave j adds
+// those of pixel tile j in a fixed order and runs the usual register epilogue.  Tables, input transform and epilogue flags as in
+// conv_t_kernel.  NT = 16-pixel tiles per workgroup: every weight quad read from L2 feeds NT MFMAs -- at NT = 1 the kernel moves 256 bytes
+// of weights per MFMA and a launch of more than ~1000 workgroups sits at the L2's ~6.8 TB/s (54 TFLOP/s; profiles/r3_conv_s_ab.md).
+constexpr int kDepthS = 4;    // weight rounds in flight per wave
+constexpr int kPFS = 8;       // patch units (16 bytes) per lane and staging pass: a wave stages 512 units per pass
+template <int NT>
+__global__ void __launch_bounds__(256, NT == 1 ? 5 : 4) conv_s_kernel(const ConvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    int* ctab = (int*)lds_raw;
+    int* qoff = ctab + 16;                           // [Qpad] patch offset of group q (one wave's channel slice)
+    int* qrow = qoff + a.Qpad;                       // [Qpad] pack row of group q relative to the slice's first channel quad
+    float* patch0 = (float*)(qrow + a.Qpad);         // [4 waves][patch_floats]; after the K loop each wave's slice holds its partial tiles [NT][64 lanes][4]
+    float* xft = patch0 + (size_t)4 * a.patch_floats;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, g = lane >> 4;
+    const int n0 = blockIdx.y * 16;
+    const int flags = a.flags;
+    const int* __restrict__ blob = a.blob;
+    const int tile = blockIdx.x;
+    const int c0 = wave * a.KC;                      // this wave's channel slice
+    float* patch = patch0 + (size_t)wave * a.patch_floats;
+    const int4 d0 = *(const int4*)(blob + a.off_tdesc + (size_t)tile * 8);       // in_base, iy0, nrows, obase
+    const int4 d1 = *(const int4*)(blob + a.off_tdesc + (size_t)tile * 8 + 4);   // nimg, grp, p0, img0 | ly0 << 20
+    const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in), rs_w = make_rsrc(a.wT);
+    const int c4base = c0 >> 2;
+    // ---- the lane's patch units (64-lane walk), kPFS per staging pass: table entries -> loads -> (transform) -> the wave's LDS slice ------
+    int pu_lds[kPFS], pu_rp[kPFS];
+    float4 pv[kPFS];
+    unsigned okm = 0;
+    auto stage_load = [&](int pass) __attribute__((always_inline)) {
+        const int* pu = blob + a.off_pu + pass * (3 * kPFS * 256) + lane;
+        okm = 0;
+#pragma unroll
+        for (int i = 0; i < kPFS; ++i) {
+            const int goff = pu[(3 * i + 0) * 256];
+            pu_lds[i] = pu[(3 * i + 1) * 256];
+            pu_rp[i] = pu[(3 * i + 2) * 256];
+            const int row = pu_rp[i] & 0xffff, pr = (pu_rp[i] >> 16) & 0xff;
+            const bool ok = (row < d0.z) & ((unsigned)(d0.y + pr) < (unsigned)a.Hin) & (goff >= 0);
+            pv[i] = buf_load16(rs_in, ok ? d0.x + c0 * 4 + goff : kOob);
+            okm |= ok ? (1u << i) : 0u;
+        }
+    };
+    auto stage_store = [&]() __attribute__((always_inline)) {
+        const float* tb = xft + (size_t)(d1.y * a.C4tot + c4base) * 8;
+#pragma unroll
+        for (int i = 0; i < kPFS; ++i)
+            if ((pu_rp[i] & 0xffff) < d0.z) {
+                float4 v = pv[i];
+                if (a.xf) {
+                    const float* t = tb + (pu_rp[i] >> 24) * 8;
+                    const float4 sc = *(const float4*)t, sh = *(const float4*)(t + 4);
+                    v.x = fmaxf(__fmaf_rn(v.x, sc.x, sh.x), 0.f); v.y = fmaxf(__fmaf_rn(v.y, sc.y, sh.y), 0.f);
+                    v.z = fmaxf(__fmaf_rn(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(__fmaf_rn(v.w, sc.w, sh.w), 0.f);
+                    if (!((okm >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                *(float4*)(patch + pu_lds[i]) = v;
+            }
+    };
+    stage_load(0);
+    // ---- the lane's output pixels, the group tables ------------------------------------------------------------------------------------------
+    int loc_p[NT], loc_o[NT], loc_il[NT];
+    {
+        const int* lc = blob + a.off_loc + r16;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            loc_p[nt] = lc[(3 * nt + 0) * 256];
+            loc_o[nt] = lc[(3 * nt + 1) * 256];
+            loc_il[nt] = lc[(3 * nt + 2) * 256];
+        }
+    }
+    const int ntab = 16 + 2 * a.Qpad;
+    const int tab0 = tid < ntab ? blob[tid] : 0, tab1 = tid + 256 < ntab ? blob[tid + 256] : 0;
+    if (a.xf) {
+        const int C = a.Cin;
+        const double M = (double)a.xf_m_per_group;
+        const bool lead = blockIdx.x == 0 && blockIdx.y == 0;
+        for (int j = tid; j < a.groups * C; j += 256) {
+            const int gq = j / C, c = j - gq * C;
+            double mean, var;
+            bn_batch_moments(a.xf_stats, a.xf_rep_stride, gq, c, C, M, a.xf_eps, mean, var);
+            const double xv = var + (double)a.xf_eps;
+            double invstd = (double)rsqrtf((float)xv);
+            invstd = invstd * (1.5 - 0.5 * xv * invstd * invstd);
+            invstd = invstd * (1.5 - 0.5 * xv * invstd * invstd);
+            float sc, sh;
+            bn_scale_shift(a.xf_gamma[c], a.xf_beta[c], (float)mean, (float)invstd, sc, sh);
+            float* t = xft + (size_t)(gq * (C >> 2) + (c >> 2)) * 8 + (c & 3);
+            t[0] = sc;
+            t[4] = sh;
+            if (lead) {
+                a.xf_save_mean[j] = (float)mean;
+                a.xf_save_invstd[j] = (float)invstd;
+            }
+        }
+        if (lead && a.xf_running_mean)
+            bn_running_update(a.xf_stats, a.xf_rep_stride, a.groups, C, M, a.xf_momentum, a.xf_eps, a.xf_running_mean, a.xf_running_var, a.xf_nbt, tid, 256);
+    }
+    if (tid < ntab) ctab[tid] = tab0;
+    if (tid + 256 < ntab) ctab[tid + 256] = tab1;
+    __syncthreads();   // group tables (and the transform table) visible
+    // ---- weights: round rho of this wave = groups 4 rho + g, one 16-byte load per lane ---------------------------------------------------
+    const int nr = a.Qpad >> 2;
+    const int wcol = n0 + r16;
+    auto w_load = [&](int rho) __attribute__((always_inline)) -> float4 {
+        const int row = qrow[min(rho, nr - 1) * 4 + g];
+        return buf_load16(rs_w, (row >= 0 && wcol < a.WPT && rho < nr) ? (((row + c4base) * a.WPT + wcol) * 4) * 4 : kOob);
+    };
+    float4 aw[kDepthS];
+#pragma unroll
+    for (int i = 0; i < kDepthS; ++i) aw[i] = w_load(i);
+    // ---- this wave's patch slice (private to the wave: no workgroup barrier, its own LDS writes are ordered before its reads) -------------
+    stage_store();
+    for (int pass = 1; pass < a.nstage; ++pass) {
+        stage_load(pass);
+        stage_store();
+    }
+    int pbase[NT], ooff[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const bool pix_ok = loc_il[nt] < d1.x;
+        pbase[nt] = pix_ok ? loc_p[nt] : 0;
+        ooff[nt] = pix_ok ? d0.w + loc_o[nt] : -1;
+    }
+    f32x4 acc[NT][2];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[nt][0] = acc[nt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int rho = 0; rho < nr; rho += kDepthS) {
+#pragma unroll
+        for (int i = 0; i < kDepthS; ++i) {
+            if (rho + i < nr) {   // wave-uniform
+                const float4 av = aw[i];
+                aw[i] = w_load(rho + i + kDepthS);
+                const int qo = qoff[(rho + i) * 4 + g];
+                float4 bv[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) bv[nt] = *(const float4*)(patch + pbase[nt] + qo);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt][i & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv[nt].x, acc[nt][i & 1], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt][i & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv[nt].y, acc[nt][i & 1], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt][i & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv[nt].z, acc[nt][i & 1], 0, 0, 0);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[nt][i & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv[nt].w, acc[nt][i & 1], 0, 0, 0);
+            }
+        }
+    }
+    // (the wave's own patch slice is dead once its K loop is done: the partial tiles go there, no extra buffer and no extra barrier)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const f32x4 t = acc[nt][0] + acc[nt][1];
+        *(float4*)(patch + (size_t)(nt * 64 + lane) * 4) = make_float4(t[0], t[1], t[2], t[3]);
+    }
+    __syncthreads();
+    if (wave >= NT) return;   // wave j adds the four partial tiles of pixel tile j in a fixed order and runs its epilogue
+    float4 v;
+    {
+        const float* rj = patch0 + (size_t)(wave * 64 + lane) * 4;
+        const size_t ws = (size_t)a.patch_floats;
+        const float4 p0 = *(const float4*)(rj), p1 = *(const float4*)(rj + ws);
+        const float4 p2 = *(const float4*)(rj + 2 * ws), p3 = *(const float4*)(rj + 3 * ws);
+        v = make_float4((p0.x + p1.x) + (p2.x + p3.x), (p0.y + p1.y) + (p2.y + p3.y), (p0.z + p1.z) + (p2.z + p3.z), (p0.w + p1.w) + (p2.w + p3.w));
+    }
+    // ---- epilogue: lane (r16 = pixel of tile `wave`, g) holds channels n0 + 4g .. + 3 -------------------------------------------------------
+    int oo = ooff[0];
+#pragma unroll
+    for (int nt = 1; nt < NT; ++nt) oo = wave == nt ? ooff[nt] : oo;
+    const int co = n0 + 4 * g;
+    const bool live = oo >= 0 && co < a.Cout;
+    if (flags & EPI_STATS) {   // sums over the tile's pixels (DPP row of 16 lanes), one fp64 atomic per channel
+        const float4 z = live ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float s1x = row16_sum(z.x), s1y = row16_sum(z.y), s1z = row16_sum(z.z), s1w = row16_sum(z.w);
+        const float s2x = row16_sum(z.x * z.x), s2y = row16_sum(z.y * z.y), s2z = row16_sum(z.z * z.z), s2w = row16_sum(z.w * z.w);
+        if (r16 == 0 && co < a.Cout) {
+            double* st_ = a.stats + (int64_t)((blockIdx.x + blockIdx.y + wave) % kStatReps) * a.stat_rep_stride + ((int64_t)d1.y * 2) * a.Cout + co;
+            atomicAdd(st_ + 0, (double)s1x); atomicAdd(st_ + 1, (double)s1y); atomicAdd(st_ + 2, (double)s1z); atomicAdd(st_ + 3, (double)s1w);
+            atomicAdd(st_ + a.Cout + 0, (double)s2x); atomicAdd(st_ + a.Cout + 1, (double)s2y);
+            atomicAdd(st_ + a.Cout + 2, (double)s2z); atomicAdd(st_ + a.Cout + 3, (double)s2w);
+        }
+    }
+    if (!live) return;
+    float* op = a.out + (int64_t)oo + co;
+    if (flags & EPI_AFFINE) {
+        const float4 sc = *(const float4*)(a.scale + co), sh = *(const float4*)(a.shift + co);
+        v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+    }
+    if (flags & EPI_RES) {
+        const float4 r = *(const float4*)(a.res + (int64_t)oo + co);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    }
+    if (flags & EPI_RESMASK) {
+        const float4 r = *(const float4*)(a.res + (int64_t)oo + co);
+        const float4 mk = *(const float4*)(a.resmask + (int64_t)oo + co);
+        v.x += mk.x > 0.f ? r.x : 0.f; v.y += mk.y > 0.f ? r.y : 0.f; v.z += mk.z > 0.f ? r.z : 0.f; v.w += mk.w > 0.f ? r.w : 0.f;
+    }
+    if (flags & EPI_ACCUM) {
+        const float4 o = *(const float4*)op;
+        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+    }
+    if (flags & EPI_RELU) {
+        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    }
+    *(float4*)op = v;
+}
+
 typedef void (*conv_fn_t)(const ConvArgs);
+static conv_fn_t convs_fn(int nt) { return nt == 2 ? conv_s_kernel<2> : conv_s_kernel<1>; }
+
+#define OCL_CONVT_TILINGS(X) X(1, 1) X(2, 1) X(3, 1) X(4, 1) X(5, 1) X(1, 2) X(2, 2) X(3, 2) X(4, 2) X(5, 2)
 static conv_fn_t convt_fn(int MT, int NT, int PF, int res, int cls = 0, int pipe = 0) {
     if (pipe) {   // staged weights through the ring: one pixel tile per wave
         if (res || NT != 1) return nullptr;
@@ -1229,8 +1448,99 @@ static int plan_conv_q(const ConvGeomDesc& g, ConvPlan* p) {
     return OCL_OK;
 }
 
+// ---- conv_s_kernel plan: (16 NT)-pixel x 16-channel workgroups, input channels split over the four waves --------------------------
+static int plan_conv_s_nt(const ConvGeomDesc& g, ConvPlan* p, int NT) {
+    ConvArgs& a = p->a;
+    if (g.ncls > 1 || g.Cin % 16 || g.Cout % 4) return OCL_ERR_ARG;
+    const int LP = g.LH * g.LW, TP = 16 * NT;
+    // a tile = whole lattice rows of one image, or whole images
+    if (!((LP >= TP && TP % g.LW == 0 && LP % TP == 0) || (LP < TP && TP % LP == 0))) return OCL_ERR_ARG;
+    a.n_splits = cdiv(g.Cout, 16);
+    a.CoutP = a.n_splits * 16;
+    a.group_size = g.N / g.groups;
+    if (LP >= TP) {
+        a.imgs = 1; a.ppi = TP; a.tiles_per_img = LP / TP;
+    } else {
+        a.imgs = std::min(TP / LP, a.group_size); a.ppi = LP; a.tiles_per_img = 1;
+    }
+    a.PC = (g.LW - 1) * g.is + (a.max_dx - a.min_dx) + 1;
+    const int rows_l = LP >= TP ? TP / g.LW : g.LH;
+    a.PR = (rows_l - 1) * g.is + (a.max_dy - a.min_dy) + 1;
+    a.C4tot = g.Cin / 4;
+    a.KC = g.Cin / 4;                                   // one wave's channel slice
+    a.CP = ((a.KC / 4) & 1) ? a.KC : a.KC + 4;
+    a.Qc = g.ntaps * (a.KC / 4);
+    a.Qpad = (int)round_up(a.Qc, 4);
+    if (16 + 2 * a.Qpad > 512) return OCL_ERR_ARG;
+    a.wres = 0; a.pipe = 0; a.QS = a.Qpad;
+    const int units = a.imgs * a.PR * a.PC * (a.KC / 4);
+    a.nstage = cdiv(units, 64 * kPFS);                  // staging passes of 512 units per wave
+    if (a.nstage > 3 || a.imgs > 127 || a.PR >= 256 || a.PC >= 256 || a.KC / 4 >= 64) return OCL_ERR_ARG;
+    a.patch_floats = std::max((int)round_up((int64_t)a.imgs * a.PR * a.PC * a.CP, 4), NT * 64 * 4);   // (>= the partial tiles it holds at the end)
+    a.tiles_per_group = cdiv(a.group_size, a.imgs) * a.tiles_per_img;
+    const int ntiles = g.groups * a.tiles_per_group;
+    const size_t lds = 64 + (size_t)2 * a.Qpad * 4 + (size_t)4 * a.patch_floats * 4 + (g.xf ? (size_t)g.groups * g.Cin * 8 : 0);
+    if (lds > 64 * 1024) return OCL_ERR_ARG;
+    // Worth it (profiles/r3_conv_s_ab.md) where conv_t_kernel's 64-pixel tiles leave most of the machine idle behind a long K chain:
+    // few tiles (a 10 - 50-image pass), or lattices of <= 16 pixels per image (layer 4: a 64-pixel tile is four images, each with its
+    // own halo, and K = 720 - 1440 behind every wave) at any batch size.
+    const int64_t tiles64 = (int64_t)g.groups * (LP >= 64 ? (int64_t)a.group_size * cdiv(LP, 64) : cdiv(a.group_size, std::max(1, 64 / LP)));
+    static const int env_units = [] { const char* e = getenv("OCL_CONV_S_UNITS"); return e ? atoi(e) : 200; }();   // measurement knob
+    if (g.force_cs <= 0 && ((LP > 16 && tiles64 * cdiv(g.Cout, 16) >= env_units) || a.Qpad < 40)) return OCL_ERR_ARG;
+    a.cls_pack = 1 | (g.ntaps << 4);
+    a.cls_oyx = 0;
+    p->cs = 1; p->q4 = 0; p->MT = 1; p->NT = NT;
+    p->lds_bytes = lds;
+    a.WPT = g.WPT > 0 ? g.WPT : a.CoutP;
+    for (int t = 0; t < 9; ++t) a.tpo[t] = t < a.ntaps ? ((a.tdy[t] - a.min_dy) * a.PC + (a.tdx[t] - a.min_dx)) * a.CP : 0;
+    {   // a wave's 64 lanes walk the patch units
+        const int kc4 = a.KC / 4;
+        a.d_c4 = 64 % kc4;
+        const int d_pix = 64 / kc4;
+        a.d_pc = d_pix % a.PC;
+        a.d_row = d_pix / a.PC;
+    }
+    a.groups = g.groups;
+    a.aligned = 1;
+    a.m_tpg = a.m_tpi = a.m_lw = a.m_ppi = a.m_kc4 = a.m_pc = a.m_pr = 0;
+    p->grid_x = ntiles;
+    p->grid_y = a.n_splits;
+    a.off_tdesc = (int)round_up(16 + 2 * a.Qpad, 4);
+    a.off_pu = a.off_tdesc + ntiles * 8;
+    a.off_loc = a.off_pu + 3 * kPFS * a.nstage * 256;
+    a.blob_ints = a.off_loc + 3 * NT * 256;
+    a.blob = nullptr;
+    return OCL_OK;
+}
+
+static int plan_conv_s(const ConvGeomDesc& g, ConvPlan* p) {
+    // One pixel tile per workgroup.  Two (every weight quad feeds two MFMAs, half the weight bytes from L2) is a measurement knob: it
+    // wins only on layer 3 at ~100 images, where conv_t_kernel is as fast (profiles/r3_conv_s_ab.md).
+    static const int env_nt = [] { const char* e = getenv("OCL_CONV_S_NT"); return e ? atoi(e) : 1; }();
+    ConvPlan q = *p;
+    if (env_nt == 2 && plan_conv_s_nt(g, &q, 2) == OCL_OK) {
+        *p = q;
+        return OCL_OK;
+    }
+    q = *p;
+    const int r = plan_conv_s_nt(g, &q, 1);
+    if (r == OCL_OK) *p = q;
+    return r;
+}
+
 static int plan_conv_t(const ConvGeomDesc& g, ConvPlan* p) {
     ConvArgs& a = p->a;
+    p->cs = 0;
+    {   // few output pixels behind a deep K (layers 3 - 4 of a replay-sized pass): K split over the waves
+        static const bool env_cs = [] { const char* e = getenv("OCL_CONV_S"); return !(e && atoi(e) == 0); }();
+        if (g.force_cs > 0 || (g.force_cs == 0 && env_cs && !g.force_MT && !g.force_NT)) {
+            ConvPlan q = *p;
+            if (plan_conv_s(g, &q) == OCL_OK) {
+                *p = q;
+                return OCL_OK;
+            }
+        }
+    }
     {   // <= 20 output channels: the 4x4x1 form (no channel / K padding) where it fits and the launch is large enough
         static const bool env_q4 = [] { const char* e = getenv("OCL_CONV_Q4"); return !(e && atoi(e) == 0); }();
         if (g.force_q4 > 0 || (g.force_q4 == 0 && env_q4 && !g.force_MT && !g.force_NT)) {
@@ -1393,7 +1703,7 @@ void conv_plan_tables(const ConvPlan& p, std::vector<int>* out) {
     // per-thread patch units: unit u = tid + i * 256 of the flat [row][pc][c4] patch
     const int PF = (a.off_loc - a.off_pu) / (3 * 256);
     int* pu = b.data() + a.off_pu;
-    for (int tid = 0; tid < 256; ++tid) {
+    for (int tid = 0; tid < (p.cs ? 64 : 256); ++tid) {   // (conv_s_kernel: a wave's 64 lanes walk the units, stride 64)
         const int pix = tid / kc4;
         int c4 = tid % kc4, row = pix / a.PC, pc = pix % a.PC;
         for (int i = 0; i < PF; ++i) {
@@ -1417,7 +1727,8 @@ void conv_plan_tables(const ConvPlan& p, std::vector<int>* out) {
         const int wave = tid >> 6, r16 = tid & 15, lane = tid & 63;
         for (int nt = 0; nt < NT; ++nt) {
             // conv_t_kernel: 16-pixel tiles, the lane's pixel = its r16; conv_q_kernel: 64-pixel sets, one pixel per lane
-            const int r = p.q4 ? wave * 64 * NT + nt * 64 + lane : wave * 16 * NT + nt * 16 + r16;
+            // conv_s_kernel: every wave holds the same 16 NT pixels
+            const int r = p.cs ? nt * 16 + r16 : p.q4 ? wave * 64 * NT + nt * 64 + lane : wave * 16 * NT + nt * 16 + r16;
             const int il = r / a.ppi, pl = r % a.ppi;
             const int ly = pl / a.LW, lx = pl % a.LW;
             lc[(3 * nt + 0) * 256 + tid] = ((il * a.PR + ly * a.is) * a.PC + lx * a.is) * a.CP;
@@ -1594,6 +1905,16 @@ static conv_fn_t convq_fn(int ntq, int pf, int stats) {
 }
 
 int launch_conv(const ConvPlan& p, hipStream_t s) {
+    if (p.cs) {
+        if (!p.a.blob) {
+            set_error("launch_conv: plan without device tables (conv_plan_finalize)");
+            return OCL_ERR_STATE;
+        }
+        ProfScope ps(PROF_CONV, s);
+        hipLaunchKernelGGL(convs_fn(p.NT), dim3(p.grid_x, p.grid_y), dim3(256), p.lds_bytes, s, p.a);
+        OCL_LAUNCH_CHECK();
+        return OCL_OK;
+    }
     if (p.q4) {
         conv_fn_t fq = convq_fn(p.q4, (p.a.off_loc - p.a.off_pu) / (3 * 256), (p.a.flags & EPI_STATS) ? 1 : 0);
         if (!fq || !p.a.blob) {
@@ -2806,6 +3127,8 @@ int conv_kernels_init() {
         for (int pf = 4; pf <= 8; pf += 4)
             for (int cls = 0; cls < 2; ++cls)
                 OCL_HIP(hipFuncSetAttribute((const void*)convt_fn(m, 1, pf, 0, cls, 1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+    for (int nt = 1; nt <= 2; ++nt)
+        OCL_HIP(hipFuncSetAttribute((const void*)convs_fn(nt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     for (int st = 0; st < 2; ++st) {
         OCL_HIP(hipFuncSetAttribute((const void*)convq_fn(2, 4, st), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
         OCL_HIP(hipFuncSetAttribute((const void*)convq_fn(2, 12, st), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));

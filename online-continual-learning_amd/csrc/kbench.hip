@@ -206,8 +206,9 @@ static void bench_geom(const char* lname, const char* kind, ConvGeomDesc g, cons
             for (int pipe = 0; pipe < 3; ++pipe) {   // staged-weight plans: the two-buffer schedule, then the three-buffer ring; 2: conv_t_kernel where the planner takes conv_q_kernel
                 ConvGeomDesc gt = g;
                 gt.force_MT = mt; gt.force_NT = nt;
-                gt.force_pipe = pipe == 1 ? 1 : -1;
+                gt.force_pipe = pipe == 1 ? 1 : pipe == 2 ? 0 : -1;   // (the comparison line runs conv_t_kernel's DEFAULT plan, ring included)
                 gt.force_q4 = pipe == 2 ? -1 : 0;
+                gt.force_cs = pipe == 2 ? -1 : 0;
                 ConvPlan pt;
                 if (plan_conv(gt, &pt) != OCL_OK) continue;
                 if (pipe == 1 && !pt.a.pipe) continue;
@@ -215,7 +216,8 @@ static void bench_geom(const char* lname, const char* kind, ConvGeomDesc g, cons
                     ConvGeomDesc g0 = gt;
                     g0.force_q4 = 0;
                     ConvPlan p0;
-                    if (mt || plan_conv(g0, &p0) != OCL_OK || !p0.q4) continue;
+                    g0.force_cs = 0;
+                    if (mt || plan_conv(g0, &p0) != OCL_OK || !(p0.q4 || p0.cs)) continue;
                 }
                 OK(conv_plan_finalize(&pt));   // (kbench leaks the plans' device tables: a measurement tool that exits right after)
                 CK(hipMemset(out, 0, out_elems * 4));
@@ -292,7 +294,7 @@ static void bench_geom(const char* lname, const char* kind, ConvGeomDesc g, cons
                     CK(hipFree(tr));
                 }
                 printf("    conv_%c%s%s MT=%d NT=%d grid=%5dx%d lds=%6zu KC=%3d Q=%3d QS=%3d res=%d  %7.1f us %6.1f TF/s  maxdiff=%.2e statdiff=%.1e%s\n",
-                       pt.q4 ? 'q' : 't', mt ? "      " : (pipe == 2 ? " (no-q)" : " (auto)"), pipe == 1 ? " ring" : "     ", pt.MT, pt.NT, pt.grid_x, pt.grid_y, pt.lds_bytes, pt.a.KC, pt.a.Qc, pt.a.QS, pt.a.wres, t,
+                       pt.cs ? 's' : pt.q4 ? 'q' : 't', mt ? "      " : (pipe == 2 ? " (no-q)" : " (auto)"), pipe == 1 ? " ring" : "     ", pt.MT, pt.NT, pt.grid_x, pt.grid_y, pt.lds_bytes, pt.a.KC, pt.a.Qc, pt.a.QS, pt.a.wres, t,
                        flops / t * 1e-6, d, ds, (d > 1e-3 || ds > 1e-3) ? "  <-- MISMATCH" : "");
             }
         CK(hipFree(stats2));
@@ -624,9 +626,10 @@ int main(int argc, char** argv) {
                 ConvGeomDesc g2 = all[i];
                 g2.force_pipe = -1;   // this line: resident weights or the two-buffer schedule; the default (ring) plan follows as "ring:"
                 OK(plan_conv(g2, &p));
-                printf("%-20s %-6s M=%7d N=%3d K=%4d  MT=%d NT=%d grid=%5dx%d lds=%6zu KC=%3d CP=%3d Qpad=%d QS=%d res=%d classes=%d imgs=%d ppi=%d PR=%d PC=%d\n",
+                printf("%-20s %-6s M=%7d N=%3d K=%4d  MT=%d NT=%d grid=%5dx%d lds=%6zu KC=%3d CP=%3d Qpad=%d QS=%d res=%d classes=%d imgs=%d ppi=%d PR=%d PC=%d%s\n",
                        l.name.c_str(), i == 0 ? "fwd" : "dgrad", all[i].N * all[i].LH * all[i].LW, all[i].Cout, all[i].ntaps * all[i].Cin,
-                       p.MT, p.NT, p.grid_x, p.grid_y, p.lds_bytes, p.a.KC, p.a.CP, p.a.Qpad, p.a.QS, p.a.wres, p.a.cls_pack & 15, p.a.imgs, p.a.ppi, p.a.PR, p.a.PC);
+                       p.MT, p.NT, p.grid_x, p.grid_y, p.lds_bytes, p.a.KC, p.a.CP, p.a.Qpad, p.a.QS, p.a.wres, p.a.cls_pack & 15, p.a.imgs, p.a.ppi, p.a.PR, p.a.PC,
+                       p.cs ? "  conv_s" : p.q4 ? "  conv_q" : "");
                 if (!p.a.wres) {   // staged weights: the default plan, when it is the three-buffer ring
                     ConvGeomDesc gp = all[i];
                     gp.force_pipe = 0;

@@ -21,7 +21,7 @@ def rows(f):
     for l in open(f):
         m = re.match(r"^(\S+)\s+(fwd|dgrad\S*)\s+M=", l)
         if m: name = m.group(1) + " " + m.group(2); continue
-        m = re.search(r"conv_([tq]) \((auto|no-q)\)( ring)?\s+MT=(\d) NT=(\d).*?res=(\d)\s+([\d.]+) us", l)
+        m = re.search(r"conv_([tqs]) \((auto|no-q)\)( ring)?\s+MT=(\d) NT=(\d).*?res=(\d)\s+([\d.]+) us", l)
         if m and name and m.group(2) == "auto": out.append((name + (" ring" if m.group(3) else ""), float(m.group(7))))
         m = re.search(r"^(\S+)\s+dgradM\*.*merged( \(ring\))? MT.*?res=\d\s+([\d.]+) us", l)
         if m: out.append((m.group(1) + " dgradM" + (" ring" if m.group(2) else ""), float(m.group(3))))

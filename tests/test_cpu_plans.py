@@ -64,6 +64,15 @@ def test_every_layer_gets_a_plan_that_fits(n, groups, hw):
         assert f["lds"] - base["lds"] == 3 * f["QS"] * 16 * f["MT"] * 16 - 2 * base["QS"] * 16 * base["MT"] * 16
     if hw == 32 and n >= 220:
         assert ring, "layers 3 - 4 stream their weights at these sizes"
+    # conv_s_kernel (K split over the four waves): layer 4 at every batch size, layer 3 on replay-sized passes; one wave's slice in <= 64 KB
+    cs = [l for l in conv if l.rstrip().endswith("conv_s")]
+    if hw == 32:
+        assert any(l.startswith("layer4.1.conv2") for l in cs)
+        assert any(l.startswith("layer3.1.conv2") for l in cs) == (n <= 20)
+    for l in cs:
+        f = _fields(l)
+        assert f["classes"] == 1 and f["MT"] == 1 and f["NT"] == 1 and f["res"] == 0 and f["lds"] <= 64 * 1024 and f["Qpad"] >= 40
+        assert not l.startswith(("conv1", "layer1", "layer2"))
 
 
 def test_ring_schedule_index_model():

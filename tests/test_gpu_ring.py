@@ -60,3 +60,64 @@ def test_ring_schedule_is_bit_identical_to_the_two_buffer_schedule():
     assert off.keys() == on.keys() and len(off) == 5
     for k in off:
         assert off[k] == on[k], "forward output / gradients differ with OCL_CONV_PIPE=1 for %s" % k
+
+
+# ---- conv_s_kernel (K split over the waves) against conv_t_kernel on the whole network --------------------------------
+_SCRIPT_S = r"""
+import sys
+from types import SimpleNamespace
+import numpy as np
+import torch
+sys.path.insert(0, %(root)r)
+import ocl_amd
+from ocl_amd.setup_elements import setup_architecture
+out = {}
+for agent, data, head, n, groups in [("ER", "cifar100", None, 20, 1), ("SCR", "cifar100", "mlp", 20, 2), ("ER", "cifar100", None, 7, 1),
+                                     ("SCR", "cifar100", "mlp", 50, 2), ("ER", "mini_imagenet", None, 6, 1)]:
+    torch.manual_seed(5)
+    m = setup_architecture(SimpleNamespace(agent=agent, data=data, head=head))
+    m.max_batch = max(64, n)
+    m = m.cuda()
+    hw = 84 if data == "mini_imagenet" else 32
+    x = torch.randn(n, 3, hw, hw, generator=torch.Generator().manual_seed(n)).cuda()
+    m.train()
+    y = m.forward(x) if groups == 1 else m.forward_views([x[: n // 2], x[n // 2:]])
+    loss = (y * torch.linspace(-1, 1, y.numel(), device=y.device).view_as(y)).sum()   # (SCR's outputs are unit vectors: (y * y).mean() is a constant)
+    m.zero_grad()
+    loss.backward()
+    key = "%%s-%%s-%%d" %% (agent, data, n)
+    out[key + ":y"] = y.detach().cpu().numpy()
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            out[key + ":" + k] = p.grad.detach().cpu().numpy()
+    m.eval()
+    with torch.no_grad():
+        out[key + ":eval"] = m.forward(x).detach().cpu().numpy()
+np.savez(sys.argv[1], **out)
+"""
+
+
+def _run_s(tmp_path, tag, **env_over):
+    import numpy as np
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", **env_over)
+    f = str(tmp_path / (tag + ".npz"))
+    r = subprocess.run([sys.executable, "-c", _SCRIPT_S % {"root": ROOT}, f], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return dict(np.load(f))
+
+
+def test_conv_s_kernel_matches_conv_t_kernel_on_the_whole_network(tmp_path):
+    """Same MFMAs, different summation order over K (four partial tiles per output, added in a fixed order): outputs and gradients agree
+    to fp32 round-off.  Also the two-pixel-tile form (measurement knob OCL_CONV_S_NT=2)."""
+    import numpy as np
+    ref = _run_s(tmp_path, "t", OCL_CONV_S="0")
+    for tag, env in (("s1", dict(OCL_CONV_S="1")), ("s2", dict(OCL_CONV_S="1", OCL_CONV_S_NT="2"))):
+        got = _run_s(tmp_path, tag, **env)
+        assert got.keys() == ref.keys() and len(ref) > 100
+        worst = ("", 0.0)
+        for k in ref:
+            e = float(np.abs(got[k] - ref[k]).max() / (1e-12 + np.abs(ref[k]).max()))
+            if e > worst[1]:
+                worst = (k, e)
+        print(tag, "worst", worst)
+        assert worst[1] < 2e-4, worst
