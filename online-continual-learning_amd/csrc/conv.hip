@@ -1080,14 +1080,14 @@ __global__ void __launch_bounds__(256, 2) conv_q_kernel(const ConvArgs a) {
 // conv_t_kernel.  NT = 16-pixel tiles per workgroup: every weight quad read from L2 feeds NT MFMAs -- at NT = 1 the kernel moves 256 bytes
 // of weights per MFMA and a launch of more than ~1000 workgroups sits at the L2's ~6.8 TB/s (54 TFLOP/s; profiles/r3_conv_s_ab.md).
 constexpr int kDepthS = 4;    // weight rounds in flight per wave
-constexpr int kPFS = 8;       // patch units (16 bytes) per lane and staging pass: a wave stages 512 units per pass
-template <int NT>
+constexpr int kPFS = 7;       // patch units (16 bytes) per lane and staging pass: a wave stages 448 units per pass (layer 4 needs 360 - 405; 8 would spill at 96 VGPRs)
+template <int NT, bool TRACE>
 __global__ void __launch_bounds__(256, NT == 1 ? 5 : 4) conv_s_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     int* ctab = (int*)lds_raw;
-    int* qoff = ctab + 16;                           // [Qpad] patch offset of group q (one wave's channel slice)
-    int* qrow = qoff + a.Qpad;                       // [Qpad] pack row of group q relative to the slice's first channel quad
-    float* patch0 = (float*)(qrow + a.Qpad);         // [4 waves][patch_floats]; after the K loop each wave's slice holds its partial tiles [NT][64 lanes][4]
+    int* qoff = ctab + 16;                           // [4][Qpad / 4] patch offset of group q = 4 rho + g, stored [g][rho] (one wave's channel slice)
+    int* qrow = qoff + a.Qpad;                       // [4][Qpad / 4 + 4] pack row of group q relative to the slice's first channel quad, same order; each row ends in four -1 ("no load")
+    float* patch0 = (float*)(qrow + a.Qpad + 16);    // [4 waves][patch_floats]; after the K loop each wave's slice holds its partial tiles [NT][64 lanes][4]
     float* xft = patch0 + (size_t)4 * a.patch_floats;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, g = lane >> 4;
@@ -1097,6 +1097,10 @@ __global__ void __launch_bounds__(256, NT == 1 ? 5 : 4) conv_s_kernel(const Conv
     const int tile = blockIdx.x;
     const int c0 = wave * a.KC;                      // this wave's channel slice
     float* patch = patch0 + (size_t)wave * a.patch_floats;
+    // (TRACE, a measurement build launched when ConvArgs::trace is set: s_memtime stamps of lane 0 of every wave, 8 slots per wave -- kbench KBENCH_TRACE)
+    unsigned long long* trp = TRACE ? a.trace + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 64 + wave * 8 : nullptr;
+    auto stamp = [&](int i) __attribute__((always_inline)) { if (TRACE && lane == 0) trp[i] = __builtin_amdgcn_s_memtime(); };
+    stamp(0);
     const int4 d0 = *(const int4*)(blob + a.off_tdesc + (size_t)tile * 8);       // in_base, iy0, nrows, obase
     const int4 d1 = *(const int4*)(blob + a.off_tdesc + (size_t)tile * 8 + 4);   // nimg, grp, p0, img0 | ly0 << 20
     const __amdgpu_buffer_rsrc_t rs_in = make_rsrc(a.in), rs_w = make_rsrc(a.wT);
@@ -1174,25 +1178,42 @@ __global__ void __launch_bounds__(256, NT == 1 ? 5 : 4) conv_s_kernel(const Conv
         if (lead && a.xf_running_mean)
             bn_running_update(a.xf_stats, a.xf_rep_stride, a.groups, C, M, a.xf_momentum, a.xf_eps, a.xf_running_mean, a.xf_running_var, a.xf_nbt, tid, 256);
     }
-    if (tid < ntab) ctab[tid] = tab0;
-    if (tid + 256 < ntab) ctab[tid + 256] = tab1;
+    stamp(1);
+    const int nr = a.Qpad >> 2;                      // rounds of 4 groups; a multiple of 4 (the planner pads with zero-weight groups)
+    {   // the group tables transposed to [g][rho]: a lane fetches four rounds of its g with one 16-byte read
+        auto tpos = [&](int t) __attribute__((always_inline)) -> int {
+            if (t < 16) return t;
+            int e = t - 16, base = 16;
+            if (e >= a.Qpad) return 16 + a.Qpad + ((e - a.Qpad) & 3) * (nr + 4) + ((e - a.Qpad) >> 2);
+            return base + (e & 3) * nr + (e >> 2);
+        };
+        if (tid < ntab) ctab[tpos(tid)] = tab0;
+        if (tid + 256 < ntab) ctab[tpos(tid + 256)] = tab1;
+        if (tid < 16) qrow[(tid >> 2) * (nr + 4) + nr + (tid & 3)] = -1;
+    }
     __syncthreads();   // group tables (and the transform table) visible
-    // ---- weights: round rho of this wave = groups 4 rho + g, one 16-byte load per lane ---------------------------------------------------
-    const int nr = a.Qpad >> 2;
+    stamp(2);
+    // ---- weights: round rho of this wave = groups 4 rho + g, one 16-byte load per lane, four rounds (one loop body) ahead -----------------
     const int wcol = n0 + r16;
-    auto w_load = [&](int rho) __attribute__((always_inline)) -> float4 {
-        const int row = qrow[min(rho, nr - 1) * 4 + g];
-        return buf_load16(rs_w, (row >= 0 && wcol < a.WPT && rho < nr) ? (((row + c4base) * a.WPT + wcol) * 4) * 4 : kOob);
-    };
+    const int* qoffT = qoff + g * nr;
+    const int* qrowT = qrow + g * (nr + 4);
+    const bool wok = wcol < a.WPT;
+    const int wbase = (c4base * a.WPT + wcol) * 16, wstride = a.WPT * 16;
+    auto w_addr = [&](int row) __attribute__((always_inline)) -> int { return (row >= 0 && wok) ? row * wstride + wbase : kOob; };
+    int4 qr = *(const int4*)qrowT;                   // pack rows of rounds 0 .. 3
     float4 aw[kDepthS];
-#pragma unroll
-    for (int i = 0; i < kDepthS; ++i) aw[i] = w_load(i);
+    aw[0] = buf_load16(rs_w, w_addr(qr.x)); aw[1] = buf_load16(rs_w, w_addr(qr.y));
+    aw[2] = buf_load16(rs_w, w_addr(qr.z)); aw[3] = buf_load16(rs_w, w_addr(qr.w));
+    qr = *(const int4*)(qrowT + 4);                  // rounds 4 .. 7: the loads the first body issues (past the last round: -1, no load)
+    int4 qo = *(const int4*)qoffT;                   // patch offsets of rounds 0 .. 3
     // ---- this wave's patch slice (private to the wave: no workgroup barrier, its own LDS writes are ordered before its reads) -------------
+    stamp(3);
     stage_store();
     for (int pass = 1; pass < a.nstage; ++pass) {
         stage_load(pass);
         stage_store();
     }
+    stamp(4);
     int pbase[NT], ooff[NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -1203,27 +1224,50 @@ __global__ void __launch_bounds__(256, NT == 1 ? 5 : 4) conv_s_kernel(const Conv
     f32x4 acc[NT][2];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) acc[nt][0] = acc[nt][1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int rho = 0; rho < nr; rho += kDepthS) {
+    // One body = four rounds, no branches: the B operands of the body and the tables of the next are requested at its top, each
+    // weight register is refilled (for the next body) right after it is read, and the MFMAs of two rounds alternate between two
+    // accumulators per pixel tile.  With one wave per SIMD (a 20-image pass) the loop ran at 578 cycles per round of 4 MFMAs -- two
+    // dependent LDS round trips (table, then operand) and a 4-MFMA chain per round; profiles/r3_conv_s_ab.md.
+    for (int rho = 0; rho < nr; rho += 4) {
+        float4 bv[NT][4];
 #pragma unroll
-        for (int i = 0; i < kDepthS; ++i) {
-            if (rho + i < nr) {   // wave-uniform
-                const float4 av = aw[i];
-                aw[i] = w_load(rho + i + kDepthS);
-                const int qo = qoff[(rho + i) * 4 + g];
-                float4 bv[NT];
+        for (int nt = 0; nt < NT; ++nt) {
+            bv[nt][0] = *(const float4*)(patch + pbase[nt] + qo.x); bv[nt][1] = *(const float4*)(patch + pbase[nt] + qo.y);
+            bv[nt][2] = *(const float4*)(patch + pbase[nt] + qo.z); bv[nt][3] = *(const float4*)(patch + pbase[nt] + qo.w);
+        }
+        const int4 qo_n = *(const int4*)(qoffT + min(rho + 4, nr - 4));
+        const int4 qr_n = *(const int4*)(qrowT + min(rho + 8, nr));
+        const int qrv[4] = {qr.x, qr.y, qr.z, qr.w};
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) bv[nt] = *(const float4*)(patch + pbase[nt] + qo);
+        for (int i = 0; i < 4; i += 2) {
+            const float4 a0 = aw[i], a1 = aw[i + 1];
+            aw[i] = buf_load16(rs_w, w_addr(qrv[i]));
+            aw[i + 1] = buf_load16(rs_w, w_addr(qrv[i + 1]));
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt][i & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv[nt].x, acc[nt][i & 1], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, bv[nt][i].x, acc[nt][0], 0, 0, 0);
+                acc[nt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, bv[nt][i + 1].x, acc[nt][1], 0, 0, 0);
+            }
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt][i & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv[nt].y, acc[nt][i & 1], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, bv[nt][i].y, acc[nt][0], 0, 0, 0);
+                acc[nt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, bv[nt][i + 1].y, acc[nt][1], 0, 0, 0);
+            }
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt][i & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv[nt].z, acc[nt][i & 1], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, bv[nt][i].z, acc[nt][0], 0, 0, 0);
+                acc[nt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, bv[nt][i + 1].z, acc[nt][1], 0, 0, 0);
+            }
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[nt][i & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv[nt].w, acc[nt][i & 1], 0, 0, 0);
+            for (int nt = 0; nt < NT; ++nt) {
+                acc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, bv[nt][i].w, acc[nt][0], 0, 0, 0);
+                acc[nt][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, bv[nt][i + 1].w, acc[nt][1], 0, 0, 0);
             }
         }
+        qo = qo_n;
+        qr = qr_n;
     }
+    stamp(5);
     // (the wave's own patch slice is dead once its K loop is done: the partial tiles go there, no extra buffer and no extra barrier)
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
@@ -1231,6 +1275,7 @@ __global__ void __launch_bounds__(256, NT == 1 ? 5 : 4) conv_s_kernel(const Conv
         *(float4*)(patch + (size_t)(nt * 64 + lane) * 4) = make_float4(t[0], t[1], t[2], t[3]);
     }
     __syncthreads();
+    stamp(6);
     if (wave >= NT) return;   // wave j adds the four partial tiles of pixel tile j in a fixed order and runs its epilogue
     float4 v;
     {
@@ -1280,10 +1325,14 @@ __global__ void __launch_bounds__(256, NT == 1 ? 5 : 4) conv_s_kernel(const Conv
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     }
     *(float4*)op = v;
+    stamp(7);
 }
 
 typedef void (*conv_fn_t)(const ConvArgs);
-static conv_fn_t convs_fn(int nt) { return nt == 2 ? conv_s_kernel<2> : conv_s_kernel<1>; }
+static conv_fn_t convs_fn(int nt, bool trace = false) {
+    if (trace) return nt == 2 ? conv_s_kernel<2, true> : conv_s_kernel<1, true>;
+    return nt == 2 ? conv_s_kernel<2, false> : conv_s_kernel<1, false>;
+}
 
 #define OCL_CONVT_TILINGS(X) X(1, 1) X(2, 1) X(3, 1) X(4, 1) X(5, 1) X(1, 2) X(2, 2) X(3, 2) X(4, 2) X(5, 2)
 static conv_fn_t convt_fn(int MT, int NT, int PF, int res, int cls = 0, int pipe = 0) {
@@ -1470,23 +1519,23 @@ static int plan_conv_s_nt(const ConvGeomDesc& g, ConvPlan* p, int NT) {
     a.KC = g.Cin / 4;                                   // one wave's channel slice
     a.CP = ((a.KC / 4) & 1) ? a.KC : a.KC + 4;
     a.Qc = g.ntaps * (a.KC / 4);
-    a.Qpad = (int)round_up(a.Qc, 4);
+    a.Qpad = (int)round_up(a.Qc, 16);                   // whole loop bodies of four rounds (the padding groups carry zero weights)
     if (16 + 2 * a.Qpad > 512) return OCL_ERR_ARG;
     a.wres = 0; a.pipe = 0; a.QS = a.Qpad;
     const int units = a.imgs * a.PR * a.PC * (a.KC / 4);
-    a.nstage = cdiv(units, 64 * kPFS);                  // staging passes of 512 units per wave
+    a.nstage = cdiv(units, 64 * kPFS);                  // staging passes of 64 kPFS units per wave
     if (a.nstage > 3 || a.imgs > 127 || a.PR >= 256 || a.PC >= 256 || a.KC / 4 >= 64) return OCL_ERR_ARG;
     a.patch_floats = std::max((int)round_up((int64_t)a.imgs * a.PR * a.PC * a.CP, 4), NT * 64 * 4);   // (>= the partial tiles it holds at the end)
     a.tiles_per_group = cdiv(a.group_size, a.imgs) * a.tiles_per_img;
     const int ntiles = g.groups * a.tiles_per_group;
-    const size_t lds = 64 + (size_t)2 * a.Qpad * 4 + (size_t)4 * a.patch_floats * 4 + (g.xf ? (size_t)g.groups * g.Cin * 8 : 0);
+    const size_t lds = 64 + (size_t)(2 * a.Qpad + 16) * 4 + (size_t)4 * a.patch_floats * 4 + (g.xf ? (size_t)g.groups * g.Cin * 8 : 0);
     if (lds > 64 * 1024) return OCL_ERR_ARG;
     // Worth it (profiles/r3_conv_s_ab.md) where conv_t_kernel's 64-pixel tiles leave most of the machine idle behind a long K chain:
     // few tiles (a 10 - 50-image pass), or lattices of <= 16 pixels per image (layer 4: a 64-pixel tile is four images, each with its
     // own halo, and K = 720 - 1440 behind every wave) at any batch size.
     const int64_t tiles64 = (int64_t)g.groups * (LP >= 64 ? (int64_t)a.group_size * cdiv(LP, 64) : cdiv(a.group_size, std::max(1, 64 / LP)));
     static const int env_units = [] { const char* e = getenv("OCL_CONV_S_UNITS"); return e ? atoi(e) : 200; }();   // measurement knob
-    if (g.force_cs <= 0 && ((LP > 16 && tiles64 * cdiv(g.Cout, 16) >= env_units) || a.Qpad < 40)) return OCL_ERR_ARG;
+    if (g.force_cs <= 0 && ((LP > 16 && tiles64 * cdiv(g.Cout, 16) >= env_units) || a.Qc <= 36)) return OCL_ERR_ARG;
     a.cls_pack = 1 | (g.ntaps << 4);
     a.cls_oyx = 0;
     p->cs = 1; p->q4 = 0; p->MT = 1; p->NT = NT;
@@ -1670,6 +1719,10 @@ void conv_plan_tables(const ConvPlan& p, std::vector<int>* out) {
                 ctab[c * 4 + 3] = res ? 1 : (nq + a.QS - 1) / a.QS;
             }
             q0 += nq; t0 += ntc;
+        }
+        for (int q = q0; q < a.Qpad; ++q) {   // (conv_s_kernel pads to whole loop bodies: groups that load no weights)
+            qoff[q] = 0;
+            qrow[q] = pipe ? (int)0x80000000 : -1;
         }
         if (ncls > 1)
             for (int c = ncls; c < 4; ++c) ctab[c * 4 + 0] = q0;   // (classes past the last: first group = end, no groups)
@@ -1911,7 +1964,7 @@ int launch_conv(const ConvPlan& p, hipStream_t s) {
             return OCL_ERR_STATE;
         }
         ProfScope ps(PROF_CONV, s);
-        hipLaunchKernelGGL(convs_fn(p.NT), dim3(p.grid_x, p.grid_y), dim3(256), p.lds_bytes, s, p.a);
+        hipLaunchKernelGGL(convs_fn(p.NT, p.a.trace != nullptr), dim3(p.grid_x, p.grid_y), dim3(256), p.lds_bytes, s, p.a);
         OCL_LAUNCH_CHECK();
         return OCL_OK;
     }
@@ -3128,7 +3181,8 @@ int conv_kernels_init() {
             for (int cls = 0; cls < 2; ++cls)
                 OCL_HIP(hipFuncSetAttribute((const void*)convt_fn(m, 1, pf, 0, cls, 1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     for (int nt = 1; nt <= 2; ++nt)
-        OCL_HIP(hipFuncSetAttribute((const void*)convs_fn(nt), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+        for (int tr = 0; tr < 2; ++tr)
+            OCL_HIP(hipFuncSetAttribute((const void*)convs_fn(nt, tr != 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     for (int st = 0; st < 2; ++st) {
         OCL_HIP(hipFuncSetAttribute((const void*)convq_fn(2, 4, st), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
         OCL_HIP(hipFuncSetAttribute((const void*)convq_fn(2, 12, st), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));

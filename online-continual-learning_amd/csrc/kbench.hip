@@ -241,7 +241,44 @@ static void bench_geom(const char* lname, const char* kind, ConvGeomDesc g, cons
                 stats = stats2;
                 const double t = time_us([&] { run(pt, out); });
                 stats = keep2;
-                if (mt == 0 && !pt.a.wres && getenv("KBENCH_TRACE")) {   // staged weights: raw phase deltas of wave 0 of two workgroups
+                if (mt == 0 && pt.cs && getenv("KBENCH_TRACE")) {   // conv_s_kernel: 8 stamps per wave
+                    const int nwg = pt.grid_x * pt.grid_y;
+                    unsigned long long* tr;
+                    CK(hipMalloc(&tr, (size_t)nwg * 64 * 8));
+                    CK(hipMemset(tr, 0, (size_t)nwg * 64 * 8));
+                    ConvPlan ptt = pt;
+                    ptt.a.trace = tr;
+                    stats = stats2;
+                    run(ptt, out);
+                    stats = keep2;
+                    CK(hipDeviceSynchronize());
+                    std::vector<unsigned long long> h((size_t)nwg * 64);
+                    CK(hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost));
+                    unsigned long long t0 = ~0ull, t1 = 0;
+                    for (int w = 0; w < nwg; ++w)
+                        for (int e = 0; e < 32; ++e) if (h[(size_t)w * 64 + e]) { t0 = std::min(t0, h[(size_t)w * 64 + e]); t1 = std::max(t1, h[(size_t)w * 64 + e]); }
+                    // averages over all workgroups, wave 0 and wave 3: phase lengths in s_memtime ticks (100 MHz on gfx950 -> 10 ns)
+                    double av[2][8] = {};
+                    double life = 0;
+                    for (int w = 0; w < nwg; ++w)
+                        for (int wv = 0; wv < 2; ++wv) {
+                            const unsigned long long* r = &h[(size_t)w * 64 + (wv ? 3 : 0) * 8];
+                            for (int e = 1; e < 7; ++e) av[wv][e] += (double)(r[e] - r[e - 1]);
+                            if (!wv) { av[0][7] += (double)(r[7] ? r[7] - r[6] : 0); life += (double)((r[7] ? r[7] : r[6]) - r[0]); }
+                        }
+                    printf("      trace conv_s: kernel span %llu ticks, %d workgroups; mean wave-0 lifetime %.0f ticks\n", t1 - t0, nwg, life / nwg);
+                    for (int wv = 0; wv < 2; ++wv)
+                        printf("        wave %d mean: tables+first loads issued %.0f | tables landed, barrier %.0f | weights issued %.0f | patch wait+store %.0f | K loop %.0f | partial store + barrier %.0f | epilogue %.0f\n",
+                               wv ? 3 : 0, av[wv][1] / nwg, av[wv][2] / nwg, av[wv][3] / nwg, av[wv][4] / nwg, av[wv][5] / nwg, av[wv][6] / nwg, av[wv][7] / nwg);
+                    for (int w : {0, nwg / 2, nwg - 1}) {
+                        const unsigned long long* r = &h[(size_t)w * 64];
+                        printf("        wg %5d wave 0: +%6llu |", w, r[0] - t0);
+                        for (int e = 1; e < 8 && r[e]; ++e) printf(" %llu", r[e] - r[e - 1]);
+                        printf("\n");
+                    }
+                    CK(hipFree(tr));
+                }
+                if (mt == 0 && !pt.cs && !pt.a.wres && getenv("KBENCH_TRACE")) {   // staged weights: raw phase deltas of wave 0 of two workgroups
                     const int nwg = pt.grid_x * pt.grid_y;
                     unsigned long long* tr;
                     CK(hipMalloc(&tr, (size_t)nwg * 64 * 8));
@@ -266,7 +303,7 @@ static void bench_geom(const char* lname, const char* kind, ConvGeomDesc g, cons
                     }
                     CK(hipFree(tr));
                 }
-                if (mt == 0 && pt.a.wres && getenv("KBENCH_TRACE")) {   // phase timeline of wave 0 of a few workgroups (s_memtime cycles)
+                if (mt == 0 && !pt.cs && pt.a.wres && getenv("KBENCH_TRACE")) {   // phase timeline of wave 0 of a few workgroups (s_memtime cycles)
                     const int nwg = pt.grid_x * pt.grid_y;
                     unsigned long long* tr;
                     CK(hipMalloc(&tr, (size_t)nwg * 64 * 8));
