@@ -1215,11 +1215,24 @@ __global__ void __launch_bounds__(256, NT == 1 ? 5 : 4) conv_s_kernel(const Conv
     }
     stamp(4);
     int pbase[NT], ooff[NT];
+    if (a.aligned) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const bool pix_ok = loc_il[nt] < d1.x;
-        pbase[nt] = pix_ok ? loc_p[nt] : 0;
-        ooff[nt] = pix_ok ? d0.w + loc_o[nt] : -1;
+        for (int nt = 0; nt < NT; ++nt) {
+            const bool pix_ok = loc_il[nt] < d1.x;
+            pbase[nt] = pix_ok ? loc_p[nt] : 0;
+            ooff[nt] = pix_ok ? d0.w + loc_o[nt] : -1;
+        }
+    } else {   // tiles that start inside a lattice row (11 x 11, 21 x 21 lattices of the 84 x 84 input): one image per tile
+        const int img0 = d1.w & 0xfffff, ly0 = d1.w >> 20;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int p = d1.z + nt * 16 + r16;
+            const bool v = p < a.LH * a.LW;
+            int lx;
+            const int ly = mdiv(p, a.m_lw, a.LW, lx);
+            pbase[nt] = v ? (((ly - ly0) * a.is) * a.PC + lx * a.is) * a.CP : 0;
+            ooff[nt] = v ? ((img0 * a.Hout + ly * a.os + a.oy0) * a.Wout + lx * a.os + a.ox0) * a.Cout : -1;
+        }
     }
     f32x4 acc[NT][2];
 #pragma unroll
@@ -1502,18 +1515,19 @@ static int plan_conv_s_nt(const ConvGeomDesc& g, ConvPlan* p, int NT) {
     ConvArgs& a = p->a;
     if (g.ncls > 1 || g.Cin % 16 || g.Cout % 4) return OCL_ERR_ARG;
     const int LP = g.LH * g.LW, TP = 16 * NT;
-    // a tile = whole lattice rows of one image, or whole images
-    if (!((LP >= TP && TP % g.LW == 0 && LP % TP == 0) || (LP < TP && TP % LP == 0))) return OCL_ERR_ARG;
+    // a tile = TP consecutive lattice pixels of one image (whole rows where the lattice allows: the lane -> pixel map is then the same
+    // for every tile and comes from the plan's table), or whole images
     a.n_splits = cdiv(g.Cout, 16);
     a.CoutP = a.n_splits * 16;
     a.group_size = g.N / g.groups;
     if (LP >= TP) {
-        a.imgs = 1; a.ppi = TP; a.tiles_per_img = LP / TP;
+        a.imgs = 1; a.ppi = TP; a.tiles_per_img = cdiv(LP, TP);
     } else {
         a.imgs = std::min(TP / LP, a.group_size); a.ppi = LP; a.tiles_per_img = 1;
     }
     a.PC = (g.LW - 1) * g.is + (a.max_dx - a.min_dx) + 1;
-    const int rows_l = LP >= TP ? TP / g.LW : g.LH;
+    const bool whole_rows = TP % g.LW == 0 && LP % TP == 0;
+    const int rows_l = LP >= TP ? (whole_rows ? TP / g.LW : std::min(g.LH, (TP + g.LW - 2) / g.LW + 1)) : g.LH;
     a.PR = (rows_l - 1) * g.is + (a.max_dy - a.min_dy) + 1;
     a.C4tot = g.Cin / 4;
     a.KC = g.Cin / 4;                                   // one wave's channel slice
@@ -1531,10 +1545,11 @@ static int plan_conv_s_nt(const ConvGeomDesc& g, ConvPlan* p, int NT) {
     const size_t lds = 64 + (size_t)(2 * a.Qpad + 16) * 4 + (size_t)4 * a.patch_floats * 4 + (g.xf ? (size_t)g.groups * g.Cin * 8 : 0);
     if (lds > 64 * 1024) return OCL_ERR_ARG;
     // Worth it (profiles/r3_conv_s_ab.md) where conv_t_kernel's 64-pixel tiles leave most of the machine idle behind a long K chain:
-    // few tiles (a 10 - 50-image pass), or lattices of <= 16 pixels per image (layer 4: a 64-pixel tile is four images, each with its
-    // own halo, and K = 720 - 1440 behind every wave) at any batch size.
+    // lattices of <= 16 pixels per image (layer 4: a 64-pixel tile is four images, each with its own halo, and K = 720 - 1440 behind
+    // every wave) at any batch size; larger lattices (layer 3) below 1000 units of conv_t_kernel work (< 200 images), where that
+    // kernel's resident-weight plan takes over (26.9 vs 30.2 us at 220 images).
     const int64_t tiles64 = (int64_t)g.groups * (LP >= 64 ? (int64_t)a.group_size * cdiv(LP, 64) : cdiv(a.group_size, std::max(1, 64 / LP)));
-    static const int env_units = [] { const char* e = getenv("OCL_CONV_S_UNITS"); return e ? atoi(e) : 200; }();   // measurement knob
+    static const int env_units = [] { const char* e = getenv("OCL_CONV_S_UNITS"); return e ? atoi(e) : 1000; }();   // measurement knob
     if (g.force_cs <= 0 && ((LP > 16 && tiles64 * cdiv(g.Cout, 16) >= env_units) || a.Qc <= 36)) return OCL_ERR_ARG;
     a.cls_pack = 1 | (g.ntaps << 4);
     a.cls_oyx = 0;
@@ -1550,8 +1565,13 @@ static int plan_conv_s_nt(const ConvGeomDesc& g, ConvPlan* p, int NT) {
         a.d_row = d_pix / a.PC;
     }
     a.groups = g.groups;
-    a.aligned = 1;
-    a.m_tpg = a.m_tpi = a.m_lw = a.m_ppi = a.m_kc4 = a.m_pc = a.m_pr = 0;
+    a.aligned = (LP < TP || whole_rows) ? 1 : 0;
+    {
+        auto magic = [](int d) { return d <= 1 ? 0u : (unsigned)(((1ull << 32) + (unsigned)d - 1) / (unsigned)d); };
+        a.m_tpg = a.m_tpi = a.m_kc4 = a.m_pc = a.m_pr = 0;
+        a.m_lw = magic(a.LW); a.m_ppi = magic(a.ppi);
+        if ((int64_t)(LP + TP) * std::max(a.LW, a.ppi) >= (1ll << 32)) return OCL_ERR_ARG;
+    }
     p->grid_x = ntiles;
     p->grid_y = a.n_splits;
     a.off_tdesc = (int)round_up(16 + 2 * a.Qpad, 4);
@@ -1563,18 +1583,22 @@ static int plan_conv_s_nt(const ConvGeomDesc& g, ConvPlan* p, int NT) {
 }
 
 static int plan_conv_s(const ConvGeomDesc& g, ConvPlan* p) {
-    // One pixel tile per workgroup.  Two (every weight quad feeds two MFMAs, half the weight bytes from L2) is a measurement knob: it
-    // wins only on layer 3 at ~100 images, where conv_t_kernel is as fast (profiles/r3_conv_s_ab.md).
-    static const int env_nt = [] { const char* e = getenv("OCL_CONV_S_NT"); return e ? atoi(e) : 1; }();
-    ConvPlan q = *p;
-    if (env_nt == 2 && plan_conv_s_nt(g, &q, 2) == OCL_OK) {
-        *p = q;
-        return OCL_OK;
+    // One pixel tile per workgroup; two (every weight quad feeds two MFMAs: half the weight and table bytes per MFMA, twice the patch per
+    // wave) on the 8x8 lattices of layer 3 once the one-tile grid has >= 800 workgroups -- 100 images: 14.6 vs 17.4 us, 150: 21.8 vs
+    // 24.1; on layer 4 (two whole images per workgroup) it only pays around 150 images (profiles/r3_conv_s_ab.md).
+    static const int env_nt = [] { const char* e = getenv("OCL_CONV_S_NT"); return e ? atoi(e) : 0; }();   // measurement knob: 1 / 2 = always
+    ConvPlan q1 = *p;
+    const int r1 = plan_conv_s_nt(g, &q1, 1);
+    const bool want2 = env_nt ? env_nt == 2 : (r1 == OCL_OK && g.LH * g.LW > 16 && (int64_t)q1.grid_x * q1.grid_y >= 800);
+    if (want2) {
+        ConvPlan q2 = *p;
+        if (plan_conv_s_nt(g, &q2, 2) == OCL_OK) {
+            *p = q2;
+            return OCL_OK;
+        }
     }
-    q = *p;
-    const int r = plan_conv_s_nt(g, &q, 1);
-    if (r == OCL_OK) *p = q;
-    return r;
+    if (r1 == OCL_OK) *p = q1;
+    return r1;
 }
 
 static int plan_conv_t(const ConvGeomDesc& g, ConvPlan* p) {
