@@ -1435,9 +1435,9 @@ found:
 }
 
 // ---- conv_q_kernel plan: 5 blocks of 4 channels, NTQ 64-pixel sets per wave (tile = 256 * NTQ pixels), weights resident, one chunk
-static int plan_conv_q(const ConvGeomDesc& g, ConvPlan* p) {
+static int plan_conv_q_ntq(const ConvGeomDesc& g, ConvPlan* p, const int NTQ, bool* too_wide = nullptr) {
     ConvArgs& a = p->a;
-    constexpr int NTQ = 2, COPW = 4 * kQBlocks;
+    constexpr int COPW = 4 * kQBlocks;
     if (g.Cout > COPW || g.Cout % 4 || g.ncls > 1) return OCL_ERR_ARG;
     a.n_splits = 1;
     a.CoutP = COPW;
@@ -1460,8 +1460,9 @@ static int plan_conv_q(const ConvGeomDesc& g, ConvPlan* p) {
     a.Qpad = (int)round_up(a.Qc, 4);
     a.wres = 1; a.pipe = 0; a.QS = a.Qpad; a.nstage = 1;
     const int units = a.imgs * a.PR * a.PC * (a.KC / 4);
+    if (too_wide) *too_wide = units > 256 * 12;
     if (units > 256 * 12 || a.imgs > 127 || a.PR >= 256 || a.PC >= 256 || a.KC / 4 >= 64) return OCL_ERR_ARG;
-    const int PF = units <= 1024 ? 4 : 12;
+    const int PF = (units <= 1024 && NTQ == 2) ? 4 : 12;
     const size_t patch_b = (size_t)round_up(std::max((size_t)a.imgs * a.PR * a.PC * a.CP * 4, (size_t)8 * COPW * 8), 16);
     a.patch_floats = (int)(patch_b / 4);
     size_t lds = (size_t)kMaxWgTiles * 32 + 64 + (size_t)2 * a.Qpad * 4 + (size_t)a.Qpad * COPW * 16 + patch_b + (g.xf ? (size_t)g.groups * g.Cin * 8 : 0);
@@ -1508,6 +1509,19 @@ static int plan_conv_q(const ConvGeomDesc& g, ConvPlan* p) {
     a.blob_ints = a.off_loc + 3 * NTQ * 256;
     a.blob = nullptr;
     return OCL_OK;
+}
+
+static int plan_conv_q(const ConvGeomDesc& g, ConvPlan* p) {
+    // 512-pixel tiles; 256-pixel tiles where the patch of 512 pixels has more units than a workgroup stages (84-pixel-wide rows)
+    ConvPlan q = *p;
+    bool too_wide = false;
+    int r = plan_conv_q_ntq(g, &q, 2, &too_wide);
+    if (r != OCL_OK && too_wide) {   // (not where 512-pixel tiles are merely too few: there conv_t_kernel's 64-pixel tiles spread better)
+        q = *p;
+        r = plan_conv_q_ntq(g, &q, 1);
+    }
+    if (r == OCL_OK) *p = q;
+    return r;
 }
 
 // ---- conv_s_kernel plan: (16 NT)-pixel x 16-channel workgroups, input channels split over the four waves --------------------------
@@ -1978,6 +1992,7 @@ void geom_dgrad(const ConvShape& c, int N, std::vector<ConvGeomDesc>* out, bool 
 static conv_fn_t convq_fn(int ntq, int pf, int stats) {
     if (ntq == 2 && pf == 4) return stats ? conv_q_kernel<2, 4, true> : conv_q_kernel<2, 4, false>;
     if (ntq == 2 && pf == 12) return stats ? conv_q_kernel<2, 12, true> : conv_q_kernel<2, 12, false>;
+    if (ntq == 1 && pf == 12) return stats ? conv_q_kernel<1, 12, true> : conv_q_kernel<1, 12, false>;
     return nullptr;
 }
 
@@ -3210,6 +3225,7 @@ int conv_kernels_init() {
     for (int st = 0; st < 2; ++st) {
         OCL_HIP(hipFuncSetAttribute((const void*)convq_fn(2, 4, st), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
         OCL_HIP(hipFuncSetAttribute((const void*)convq_fn(2, 12, st), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+        OCL_HIP(hipFuncSetAttribute((const void*)convq_fn(1, 12, st), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     }
     done = true;
     return OCL_OK;

@@ -57,6 +57,8 @@ CASES = [
     ("SCR", "cifar100", "mlp", 14, 2),
     ("SCR", "cifar100", "mlp", 220, 2),
     ("SCR", "cifar100", "mlp", 36, 2),
+    ("SCR", "cifar100", "mlp", 50, 2),      # layer 1 on conv_q_kernel's 256-pixel tiles, layer 3 on conv_s_kernel with two pixel tiles
+    ("ER", "cifar100", None, 100, 1),       # the same, one group; layer 4's 1000-workgroup conv_s launches
     ("ER", "mini_imagenet", None, 6, 1),
     ("ER", "mini_imagenet", None, 20, 2),
     ("SCR", "cifar100", "linear", 8, 2),
