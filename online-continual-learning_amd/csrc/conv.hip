@@ -1649,6 +1649,10 @@ static int plan_conv_t(const ConvGeomDesc& g, ConvPlan* p) {
     if (nt16 > 5) MT = cdiv(nt16, cdiv(nt16, 5));                    // balanced splits (10 tiles -> 2 x 5)
     while (MT > 1 && tiles64 * cdiv(nt16, MT) < 200) --MT;   // kbench sweep: 4x55 workgroups of 3 channel tiles beat 5x55 of 2 on layer 4
     if (nt16 > MT) MT = cdiv(nt16, cdiv(nt16, MT));
+    // 160 output channels behind a deep K that conv_s_kernel does not take (layer 4 of a 50-image 84x84 pass: 100 pixel tiles): two
+    // splits of five channel tiles are 200 workgroups with a 360-round chain each; five splits of two fill the machine twice
+    // (kbench sweep, profiles/r3_kbench_sweep_84.txt: 37.7 vs 48.6 us; three or four tiles per workgroup pad 10 tiles to 12)
+    if (nt16 == 10 && g.ntaps * g.Cin >= 1280 && tiles64 * 2 < 400) MT = 2;
     int NT = tiles64 * cdiv(nt16, MT) >= 2048 ? 2 : 1;
     if (g.ncls > 1) NT = 1;
     if (g.force_MT) MT = g.force_MT;
