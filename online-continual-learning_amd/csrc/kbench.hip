@@ -650,6 +650,126 @@ int main(int argc, char** argv) {
     const std::string mode = argc > 4 ? argv[4] : "all";
     const bool sweep = argc > 5 ? atoi(argv[5]) != 0 : true;
     std::vector<Layer> layers = make_layers(hw, 20);
+    if (mode == "cover") {   // host-only: every plan's tables replayed on the host -- the lane -> pixel maps of all tiles must hit every
+        // output pixel of the plan's lattice exactly once, every operand read must stay inside the patch, every patch unit inside the
+        // patch and (where it is loaded at all) inside the input tensor.  Mirrors the pixel-geometry statements of conv_t_kernel /
+        // conv_q_kernel / conv_s_kernel (aligned: the plan's per-lane table; unaligned: the per-tile division).
+        int bad = 0, checked = 0;
+        for (auto& l : layers) {
+            const ConvShape& c = l.s;
+            ConvGeomDesc g;
+            geom_fwd(c, N, groups, &g);
+            std::vector<ConvGeomDesc> all(1, g), dg;
+            if (c.Cin != 3) {
+                geom_dgrad(c, N, &dg, true);
+                all.insert(all.end(), dg.begin(), dg.end());
+                dg.clear();
+                geom_dgrad(c, N, &dg, false);   // the four parity classes as separate launches
+                all.insert(all.end(), dg.begin(), dg.end());
+            }
+            for (size_t gi = 0; gi < all.size(); ++gi) {
+                ConvPlan p;
+                OK(plan_conv(all[gi], &p));
+                std::vector<int> b;
+                conv_plan_tables(p, &b);
+                // (self-test of the checker, KBENCH_COVER_SELFTEST=1: read the per-tile maps of unaligned plans as if they were aligned --
+                // the check must then fail on the 84 x 84 lattices)
+                if (getenv("KBENCH_COVER_SELFTEST") && !p.a.aligned) p.a.aligned = 1;
+                const ConvArgs& a = p.a;
+                const int ncls = a.cls_pack & 15, NT = p.NT;
+                const int ntiles = a.groups * a.tiles_per_group, LP = a.LH * a.LW;
+                const int tile_px = p.cs ? 16 * NT : p.q4 ? 256 * NT : 64 * NT;
+                const int* ctab = b.data();
+                const int* qoff = ctab + 16;
+                const int* td = b.data() + a.off_tdesc;
+                const int* lc = b.data() + a.off_loc;
+                std::vector<unsigned char> hit((size_t)a.N * a.Hout * a.Wout, 0);
+                int errs = 0;
+                auto fail = [&](const char* what, int tile, int r) {
+                    if (errs++ < 3) printf("  COVER %s %s geom %zu: %s (tile %d, pixel %d)\n", l.name.c_str(), p.cs ? "conv_s" : p.q4 ? "conv_q" : "conv_t", gi, what, tile, r);
+                };
+                int max_nrows = 0;
+                for (int tile = 0; tile < ntiles; ++tile) {
+                    const int* d = td + (size_t)tile * 8;
+                    const int nrows = d[2], obase = d[3], nimg = d[4], grp = d[5], p0 = d[6], img0 = d[7] & 0xfffff, ly0 = d[7] >> 20;
+                    max_nrows = std::max(max_nrows, nrows);
+                    const int grp_end = std::min(a.N, (grp + 1) * a.group_size);
+                    for (int r = 0; r < tile_px; ++r) {
+                        int pbase, ooff;
+                        if (a.aligned) {
+                            // the table is indexed by (pixel set nt, thread): find a thread whose pixel r is
+                            int nt, tid;
+                            if (p.cs) { nt = r / 16; tid = r % 16; }
+                            else if (p.q4) { const int wave = r / (64 * NT); nt = (r / 64) % NT; tid = wave * 64 + r % 64; }
+                            else { const int wave = r / (16 * NT); nt = (r / 16) % NT; tid = wave * 64 + r % 16; }
+                            const int lp = lc[(3 * nt + 0) * 256 + tid], lo = lc[(3 * nt + 1) * 256 + tid], il = lc[(3 * nt + 2) * 256 + tid];
+                            const bool v = il < nimg;
+                            pbase = v ? lp : 0;
+                            ooff = v ? obase + lo : -1;
+                        } else {
+                            const int il = p.cs ? 0 : r / a.ppi, pl = p.cs ? r : r % a.ppi;
+                            const int pp = p0 + pl, n = img0 + il;
+                            const bool v = il < a.imgs && n < grp_end && pp < LP;
+                            const int ly = pp / a.LW, lx = pp % a.LW;
+                            pbase = v ? ((il * a.PR + (ly - ly0) * a.is) * a.PC + lx * a.is) * a.CP : 0;
+                            ooff = v ? ((n * a.Hout + ly * a.os + a.oy0) * a.Wout + lx * a.os + a.ox0) * a.Cout : -1;
+                        }
+                        if (ooff < 0) continue;
+                        for (int cls = 0; cls < std::max(1, ncls); ++cls) {
+                            const int o = ooff + (ncls > 1 ? ctab[cls * 4 + 2] : 0);
+                            if (o % a.Cout || o / a.Cout >= (int)hit.size()) { fail("output offset outside the tensor", tile, r); continue; }
+                            if (hit[o / a.Cout]++) fail("output pixel written twice", tile, r);
+                        }
+                        for (int q = 0; q < a.Qpad; ++q)
+                            if (pbase + qoff[q] < 0 || pbase + qoff[q] + 4 > a.patch_floats) { fail("operand read outside the patch", tile, r); break; }
+                    }
+                }
+                // expected: every lattice pixel of every image, once per class
+                size_t want = 0, got = 0;
+                for (int n = 0; n < a.N; ++n)
+                    for (int ly = 0; ly < a.LH; ++ly)
+                        for (int lx = 0; lx < a.LW; ++lx) {
+                            if (ncls > 1) {
+                                for (int cls = 0; cls < ncls; ++cls) {
+                                    const int o = ((n * a.Hout + ly * a.os + a.oy0) * a.Wout + lx * a.os + a.ox0) * a.Cout + ctab[cls * 4 + 2];
+                                    ++want;
+                                    if (o / a.Cout < (int)hit.size() && hit[o / a.Cout] == 1) ++got;
+                                }
+                            } else {
+                                const size_t o = ((size_t)n * a.Hout + ly * a.os + a.oy0) * a.Wout + lx * a.os + a.ox0;
+                                ++want;
+                                if (o < hit.size() && hit[o] == 1) ++got;
+                            }
+                        }
+                if (got != want) { fail("lattice pixels missing", -1, (int)(want - got)); }
+                // patch units: inside the patch; loaded ones inside the input tensor
+                const int PF = (a.off_loc - a.off_pu) / (3 * 256), lanes = p.cs ? 64 : 256;
+                const int* pu = b.data() + a.off_pu;
+                const int64_t in_bytes = (int64_t)a.N * a.Hin * a.Win * a.Cin * 4;
+                const int nchunk_c0 = p.cs ? 4 : a.Cin / a.KC;
+                for (int tile = 0; tile < ntiles && errs < 3; tile += std::max(1, ntiles / 64)) {
+                    const int* d = td + (size_t)tile * 8;
+                    for (int i = 0; i < PF; ++i)
+                        for (int t = 0; t < lanes; ++t) {
+                            const int goff = pu[(3 * i + 0) * 256 + t], plds = pu[(3 * i + 1) * 256 + t], rp = pu[(3 * i + 2) * 256 + t];
+                            const int row = rp & 0xffff, pr = (rp >> 16) & 0xff;
+                            if (row >= d[2]) continue;
+                            if (plds < 0 || plds + 4 > a.patch_floats) { fail("patch unit outside the patch", tile, t); break; }
+                            if (goff < 0 || (unsigned)(d[1] + pr) >= (unsigned)a.Hin) continue;
+                            for (int ch = 0; ch < nchunk_c0; ++ch) {
+                                const int64_t addr = (int64_t)d[0] + (int64_t)ch * a.KC * 4 + goff;
+                                if (addr < 0 || addr + 16 > in_bytes) { fail("patch load outside the input tensor", tile, t); break; }
+                            }
+                        }
+                }
+                (void)max_nrows;
+                bad += errs ? 1 : 0;
+                ++checked;
+            }
+        }
+        printf("cover: %d plans checked, %d with errors\n", checked, bad);
+        return bad ? 1 : 0;
+    }
     if (mode == "plan") {   // host-only: print the planner's choices (works without a GPU)
         for (auto& l : layers) {
             const ConvShape& c = l.s;

@@ -80,6 +80,25 @@ def test_every_layer_gets_a_plan_that_fits(n, groups, hw):
         assert not l.startswith(("conv1", "layer1", "layer2"))
 
 
+@pytest.mark.parametrize("n,groups,hw", [(1, 1, 32), (7, 1, 32), (10, 1, 32), (20, 2, 32), (50, 2, 32), (100, 1, 32), (150, 2, 32), (220, 2, 32), (272, 1, 32),
+                                         (410, 1, 32), (1, 1, 84), (6, 1, 84), (15, 1, 84), (20, 2, 84), (50, 1, 84), (60, 1, 84), (220, 2, 84)])
+def test_every_plan_covers_its_output_exactly_once(n, groups, hw):
+    """`kbench ... cover` replays every plan's tables on the host (the lane -> pixel maps of conv_t_kernel / conv_q_kernel /
+    conv_s_kernel, aligned and per-tile): every lattice pixel written exactly once, operand reads and patch units inside the patch,
+    patch loads inside the input tensor -- at batch sizes the GPU suite never runs as well."""
+    if not os.path.exists(KBENCH):
+        subprocess.run(["make", "-C", CSRC, "kbench"], check=True, stdout=subprocess.DEVNULL)
+    r = subprocess.run([KBENCH, str(n), str(groups), str(hw), "cover"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and " 0 with errors" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_the_coverage_check_detects_a_wrong_pixel_map():
+    """Self-test of the checker: unaligned plans read as aligned must fail it."""
+    env = dict(os.environ, KBENCH_COVER_SELFTEST="1")
+    r = subprocess.run([KBENCH, "6", "1", "84", "cover"], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 1 and "COVER" in r.stdout, r.stdout[-2000:]
+
+
 def test_ring_schedule_index_model():
     """The index arithmetic of the ring (prefetch cursor, buffer rotation, operand fetches across stage boundaries) replayed for random
     plans: scripts/ring_schedule_model.py mirrors the control flow of conv_t_kernel's `seq`."""
