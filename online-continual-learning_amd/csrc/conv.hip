@@ -1067,18 +1067,20 @@ __global__ void __launch_bounds__(256, 2) conv_q_kernel(const ConvArgs a) {
 
 
 // =====================================================================================================
-// conv_s_kernel: few output pixels, deep K (layers 3 - 4 of a 10 - 20-image pass)
+// conv_s_kernel: few output pixels behind a deep K (layer 4 at every batch size, layer 3 below ~200 images)
 // =====================================================================================================
 // A 20-image pass has 320 output pixels on layer 4 and 1280 on layer 3: five / twenty 64-pixel tiles.  conv_t_kernel gives every
 // wave 16 of a tile's pixels and the WHOLE K dimension -- 360 dependent-chain MFMAs per wave on layer 4, on 20 - 60 workgroups of
 // the 256 CUs: 14 - 20 us for 0.15 GFLOP (profiles/r3_aser_kernel_stats_v2_single_stream.csv: 25 such launches per ASER step).
 // Here a workgroup owns 16 NT pixels x 16 channels and its four waves split K by INPUT CHANNELS (wave w: channels [w, w + 1) * Cin / 4,
 // all taps): 4x the workgroups, a quarter of the chain; each wave stages its own channel slice of the (shared-halo) patch, takes its
-// weights straight from the pack in global memory / L2 into registers (16 bytes per lane and round, requested kDepthS rounds ahead:
-// nothing about them is shared between waves, so LDS would only add a copy), and the four partial tiles meet in LDS, where wave j adds
-// those of pixel tile j in a fixed order and runs the usual register epilogue.  Tables, input transform and epilogue flags as in
-// conv_t_kernel.  NT = 16-pixel tiles per workgroup: every weight quad read from L2 feeds NT MFMAs -- at NT = 1 the kernel moves 256 bytes
-// of weights per MFMA and a launch of more than ~1000 workgroups sits at the L2's ~6.8 TB/s (54 TFLOP/s; profiles/r3_conv_s_ab.md).
+// weights straight from the pack in global memory / L2 into registers (16 bytes per lane and round, one loop body of four rounds
+// ahead: nothing about them is shared between waves, so LDS would only add a copy), and the four partial tiles meet in LDS, where
+// wave j adds those of pixel tile j in a fixed order and runs the usual register epilogue.  Tables, input transform and epilogue flags
+// as in conv_t_kernel.  NT = 16-pixel tiles per workgroup: at NT = 2 every weight quad and every table entry feeds two MFMAs, for
+// twice the patch per wave -- it pays on layer 3's 8x8 lattices from ~100 images on and on the 84x84 input's lattices, not on
+// layer 4's 4x4 images (profiles/r3_conv_s_ab.md, which also has the per-wave phase traces and the counter passes).
+// The kernel must stay free of scratch: a build with 10 spilled VGPRs was 1 - 4 us per launch slower than the one before it.
 constexpr int kDepthS = 4;    // weight rounds in flight per wave
 constexpr int kPFS = 7;       // patch units (16 bytes) per lane and staging pass: a wave stages 448 units per pass (layer 4 needs 360 - 405; 8 would spill at 96 VGPRs)
 template <int NT, bool TRACE>
