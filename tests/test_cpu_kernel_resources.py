@@ -1,0 +1,48 @@
+"""CPU: the hot kernels must not use scratch (a private segment is paid at wave launch: profiles/r3_conv_s_ab.md -- a conv_s_kernel build
+with 10 spilled VGPRs was 1 - 4 us per launch slower than the build before it, with a faster loop).  Compiles conv.hip for gfx950 with
+the compiler's resource remarks (no GPU needed) and reads ScratchSize per kernel."""
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+HIPCC = "/opt/rocm/bin/hipcc"
+SRC = ROOT + "/online-continual-learning_amd/csrc/conv.hip"
+
+# the kernels a training / eval step launches (templates: the instantiations the planner picks at the BASELINE sizes)
+HOT = [
+    r"conv_s_kernel<1, false>", r"conv_s_kernel<2, false>",
+    r"conv_q_kernel<2, 4, (true|false)>", r"conv_q_kernel<2, 12, (true|false)>", r"conv_q_kernel<1, 12, (true|false)>",
+    r"conv_t_kernel<3, 1, 8, true, false, false>", r"conv_t_kernel<5, 1, 8, false, false, true>", r"conv_t_kernel<3, 1, 8, false, false, true>",
+    r"conv_t_kernel<1, 1, 8, (true|false), (true|false), (true|false)>", r"conv_t_kernel<2, 1, 4, true, (true|false), false>",
+    r"conv_wgrad_kernel<2, 3, 8>", r"conv_wgrad_kernel<3, 2, 8>", r"conv_wgrad_kernel<1, 3, 8>", r"conv_wgrad_kernel<1, 2, 8>", r"conv_wgrad_kernel<1, 2, 4>",
+    r"bn_fwd_kernel", r"bn_bwd_fused_kernel<\d+, \d>", r"wgrad_reduce_kernel", r"wgrad_reduce_multi_kernel",
+]
+
+
+@pytest.mark.skipif(not shutil.which(HIPCC), reason="hipcc not installed")
+def test_hot_kernels_use_no_scratch():
+    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", SRC, "-o", "/dev/null",
+                        "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    scratch, cur = {}, None
+    for line in r.stderr.splitlines():
+        m = re.search(r"remark:\s+(.*?) \[-Rpass", line)
+        if not m:
+            continue
+        t = m.group(1).strip()
+        if t.startswith("Function Name:"):
+            name = t.split(":", 1)[1].strip()
+            cur = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
+            cur = re.sub(r"\(.*", "", cur).replace("void ", "").replace("ocl::", "")
+        elif cur and t.startswith("ScratchSize"):
+            scratch[cur] = int(re.search(r":\s*(\d+)", t).group(1))
+    assert len(scratch) > 100, "no resource remarks parsed"
+    for pat in HOT:
+        hits = {k: v for k, v in scratch.items() if re.fullmatch(pat, k)}
+        assert hits, "no kernel matches %s" % pat
+        bad = {k: v for k, v in hits.items() if v}
+        assert not bad, "scratch in a hot kernel: %s" % bad
