@@ -772,13 +772,14 @@ __global__ void __launch_bounds__(256) augment_kernel(const float* __restrict__ 
     if (jit) {
         // the 24 permutations of {0:brightness,1:contrast,2:saturation,3:hue} in lexicographic order
         int ord = (int)pr[10];
-        int avail[4] = {0, 1, 2, 3};
-        int fact[4] = {6, 2, 1, 1};
+        unsigned avail = 0x3210u;   // the operations still to run, one nibble each, in ascending order (registers: an indexed array would live in scratch)
+#pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int q = ord / fact[s];
-            ord -= q * fact[s];
-            const int op = avail[q];
-            for (int t = q; t < 3 - s; ++t) avail[t] = avail[t + 1];
+            const int f = s == 0 ? 6 : s == 1 ? 2 : 1;
+            const int q = ord / f;
+            ord -= q * f;
+            const int op = (int)((avail >> (4 * q)) & 15u);
+            avail = (avail & ((1u << (4 * q)) - 1u)) | ((avail >> (4 * (q + 1))) << (4 * q));   // drop nibble q
             if (op == 0) {  // additive brightness (kornia 0.4-style): x + (f - 1)
                 const float d = pr[6] - 1.f;
                 c[0] = clamp01(c[0] + d); c[1] = clamp01(c[1] + d); c[2] = clamp01(c[2] + d);
