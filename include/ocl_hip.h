@@ -256,6 +256,12 @@ int ocl_prof_reset(void);
 /* cls: 0 conv fwd/dgrad GEMM, 1 conv wgrad, 2 batchnorm/elementwise, 3 head/loss, 4 kNN/buffer.
  * Returns accumulated milliseconds and launch count since reset (synchronises the device). */
 int ocl_prof_query(int cls, double* ms, int64_t* launches);
+/* What the fp32 MFMA pipe of THIS box delivers right now: a register-only stream of v_mfma_f32_16x16x4_f32 (four independent
+ * accumulators per wave, one wave per SIMD on every CU, `iters` rounds; no memory traffic), timed with HIP events on `stream`
+ * (synchronises the host).  `scratch` receives 256 * n_cu floats (n_cu <= 1024).  bench.py reports it as `roofline.calibrated_peak`
+ * next to the nominal peak so that a clock- or power-limited box shows in the record (boxes of this pool differ by up to ~19 % on the
+ * MFMA-dense kernels).  There is no reference counterpart: measurement only. */
+int ocl_mfma_calibrate(int iters, float* scratch, double* tflops, double* us, void* stream);
 
 #ifdef __cplusplus
 }

@@ -134,6 +134,23 @@ int upload_small(const void* host, size_t nbytes, void* dev, hipStream_t s) {
     return OCL_OK;
 }
 
+// ---- calibration: the fp32 MFMA rate of this box, registers only (see ocl_mfma_calibrate) -------------------------------
+// __launch_bounds__(256, 2) keeps the accumulators in ArchVGPRs (no AccVGPR copies on the loop's back edge).
+__global__ void __launch_bounds__(256, 2) mfma_calibrate_kernel(float* out, int iters) {
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const float a = (float)(threadIdx.x & 3) * 0.25f, b = 1.0f;
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc[j], 0, 0, 0);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s += acc[j][0] + acc[j][1] + acc[j][2] + acc[j][3];
+    out[blockIdx.x * 256 + threadIdx.x] = s;
+}
+
 }  // namespace ocl
 
 using namespace ocl;
@@ -162,6 +179,31 @@ int ocl_init(int device) {
 int ocl_upload(const void* host, int64_t nbytes, void* dev, void* stream) {
     OCL_REQUIRE(nbytes >= 0 && (nbytes == 0 || (host && dev)), "ocl_upload: null pointer");
     return upload_small(host, (size_t)nbytes, dev, (hipStream_t)stream);
+}
+
+int ocl_mfma_calibrate(int iters, float* scratch, double* tflops, double* us, void* stream) {
+    OCL_REQUIRE(iters > 0 && scratch, "mfma_calibrate: iters > 0 and a scratch buffer of 256 * n_cu floats");
+    hipStream_t s = (hipStream_t)stream;
+    int dev = 0, n_cu = 0;
+    OCL_HIP(hipGetDevice(&dev));
+    OCL_HIP(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    OCL_REQUIRE(n_cu > 0 && n_cu <= 1024, "mfma_calibrate: %d compute units", n_cu);
+    hipEvent_t e0, e1;
+    OCL_HIP(hipEventCreate(&e0));
+    OCL_HIP(hipEventCreate(&e1));
+    hipLaunchKernelGGL(mfma_calibrate_kernel, dim3(n_cu), dim3(256), 0, s, scratch, 16);   // (code object load, clocks)
+    OCL_HIP(hipEventRecord(e0, s));
+    hipLaunchKernelGGL(mfma_calibrate_kernel, dim3(n_cu), dim3(256), 0, s, scratch, iters);
+    OCL_HIP(hipEventRecord(e1, s));
+    OCL_HIP(hipEventSynchronize(e1));
+    float ms = 0.f;
+    OCL_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    const double flops = (double)n_cu * 4 * iters * 4 * 2.0 * 16 * 16 * 4;   // 4 waves x iters x 4 MFMAs x 2 * 16 * 16 * 4
+    if (us) *us = ms * 1e3;
+    if (tflops) *tflops = ms > 0.f ? flops / (ms * 1e-3) / 1e12 : 0.0;
+    return OCL_OK;
 }
 
 int ocl_prof_enable(int on) {

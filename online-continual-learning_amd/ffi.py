@@ -74,6 +74,7 @@ SIGNATURES = {
     "ocl_prof_enable": (C.c_int, [C.c_int]),
     "ocl_prof_reset": (C.c_int, []),
     "ocl_prof_query": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(i64)]),
+    "ocl_mfma_calibrate": (C.c_int, [C.c_int, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), vp]),
 }
 
 FWD_TRAIN, FWD_SAVE_TAPE, FWD_UPDATE_RUNNING, FWD_FROZEN_BN = 1, 2, 4, 8

@@ -325,3 +325,14 @@ def prof_query(cls):
     n = C.c_int64(0)
     ffi.check(ffi.lib().ocl_prof_query(int(cls), C.byref(ms), C.byref(n)), "prof_query")
     return ms.value, n.value
+
+
+def mfma_calibrate(iters=20000):
+    """(TFLOP/s, us) of a register-only v_mfma_f32_16x16x4_f32 stream on the current device, right now (measurement only:
+    bench.py's `roofline.calibrated_peak`; blocks the host for ~iters * 60 ns)."""
+    import ctypes as C
+    ffi.init()
+    scratch = torch.empty(256 * 1024, dtype=torch.float32, device=torch.device("cuda", torch.cuda.current_device()))
+    tf, us = C.c_double(0), C.c_double(0)
+    ffi.check(ffi.lib().ocl_mfma_calibrate(int(iters), ffi.ptr(scratch), C.byref(tf), C.byref(us), ffi.stream()), "mfma_calibrate")
+    return tf.value, us.value
