@@ -226,6 +226,12 @@ int ocl_net_bind(ocl_net* net, float* params, float* grads, float* running, int6
 int ocl_net_forward(ocl_net* net, const float* x, int n, int groups, uint32_t flags,
                     const float* params_override, float* feat_out, float* out, int slot,
                     void* stream);
+/* The same pass over a batch given as `nseg` (1..8) separate tensors xs[i] of ns[i] images each, in batch order: the reference's
+ * torch.cat((mem_x, batch_x)) (agents/exp_replay.py:78, agents/scr.py:52) and its one-forward-call-per-view (agents/scr.py:55),
+ * torch.cat((eval_x, cand_x)) of utils/buffer/aser_utils.py:73 -- without materialising the concatenation: the engine's layout
+ * conversion reads the segments where they are. */
+int ocl_net_forward_segments(ocl_net* net, const float* const* xs, const int32_t* ns, int nseg, int groups, uint32_t flags,
+                             const float* params_override, float* feat_out, float* out, int slot, void* stream);
 /* Backward of the forward recorded in `slot`. dout: [n,out_dim] = d(loss)/d(out).
  * accumulate=0 overwrites the bound flat gradient, 1 adds to it (loss.backward() twice,
  * agents/exp_replay.py:55,77).  Tensors that take no part in the forward (SupConResNet's

@@ -95,11 +95,11 @@ class ExperienceReplay(ContinualLearner):
             # exp_replay.py:76-84: the update comes from one more pass over memory + batch; passes 1 and 2 only leave their
             # BatchNorm running-statistic updates behind
             self.opt.zero_grad()
-            combined_batch = torch.cat((mem_x, batch_x))
             combined_labels = torch.cat((mem_y, batch_y))
             if getattr(mem_y, 'host', None) is not None:
                 combined_labels.host = np.concatenate((np.asarray(mem_y.host), np.asarray(batch_y_host)))
-            loss_combined = self.criterion(self.model.forward(combined_batch), combined_labels)
+            # (torch.cat((mem_x, batch_x)) is not materialised: the engine reads the two pieces where they are)
+            loss_combined = self.criterion(self.model.forward((mem_x, batch_x)), combined_labels)
             self._emit("er_loss_combined", loss_combined)
             loss_combined.backward(unit_gradient(loss_combined))
         self.opt.step()

@@ -96,6 +96,20 @@ class ScrAugment(object):
         p[:, 11] = (e[:, 9] < self.p_gray).float()
         return p
 
+    def apply_parts(self, parts):
+        """The augmented view of torch.cat(parts) without the concatenation: ONE draw for all rows (the generator sees exactly what
+        __call__(torch.cat(parts)) would make it see), one kernel per piece writing its rows of one output tensor."""
+        n = sum(p.shape[0] for p in parts)
+        u = ops.upload(self.draw(n), parts[0].device)
+        out = torch.empty((n,) + tuple(parts[0].shape[1:]), dtype=torch.float32, device=parts[0].device)
+        cfg, off = self.config(), 0
+        for p in parts:
+            k = p.shape[0]
+            if k:
+                ops.scr_augment_uniform(p, u[off:off + k], cfg, out=out[off:off + k])
+            off += k
+        return out
+
     def __call__(self, x):
         # the draws on the host generator (one call, as before); everything derived from them on the device: the ~40 small CPU
         # tensor ops of params_from_uniform cost 0.25 ms of host time per step
@@ -163,14 +177,20 @@ class SupContrastReplay(ContinualLearner):
                         with on_data():
                             mem_x = maybe_cuda(mem_x, self.cuda)
                             mem_y = maybe_cuda(mem_y, self.cuda)
-                            combined_batch = torch.cat((mem_x, batch_x))
                             combined_labels = torch.cat((mem_y, batch_y))
-                            combined_batch_aug = self.transform(combined_batch)
+                            if isinstance(self.transform, ScrAugment) and not debug.on():
+                                # torch.cat((mem_x, batch_x)) is not materialised: the augmentation and the engine's layout conversion
+                                # read the two pieces where they are
+                                first_view = (mem_x, batch_x)
+                                combined_batch_aug = self.transform.apply_parts(first_view)
+                            else:
+                                first_view = (torch.cat((mem_x, batch_x)),)
+                                combined_batch_aug = self.transform(first_view[0])
                         if overlap:
                             main.wait_stream(ds)
-                            for t in (combined_batch, combined_batch_aug, combined_labels):
+                            for t in first_view + (combined_batch_aug, combined_labels):
                                 t.record_stream(main)   # allocated on the data stream, consumed on the main one
-                        features = self.model.forward_views([combined_batch, combined_batch_aug])
+                        features = self.model.forward_views([first_view, combined_batch_aug])
                         loss = self.criterion_views(features, combined_labels, 2)
                         if self.verbose:
                             losses.update(loss, batch_y.size(0))

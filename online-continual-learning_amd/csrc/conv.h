@@ -17,6 +17,7 @@ enum ConvEpi : int {
     EPI_RESMASK = 8,     // out += res * (resmask > 0)           (ReLU-masked gradient of an identity shortcut)
     EPI_RELU = 16,       // out = max(out, 0)
     EPI_ACCUM = 32,      // out = out_old + value                (second gradient contribution)
+    EPI_BNB = 64,        // data gradient that feeds a BatchNorm backward: ReLU mask + the BatchNorm's two batch sums here (ConvArgs::bnb_*)
 };
 
 struct ConvArgs {
@@ -76,6 +77,19 @@ struct ConvArgs {
     float xf_momentum, xf_eps;
     // plan-constant tables in device memory (conv_plan_finalize): [ctab 16 | qoff Qpad | qrow Qpad | pad] [tile descriptors ntiles x 8]
     // [patch units 3 * PF x 256] [output pixels 3 * NT x 256], offsets in ints
+    // ---- BatchNorm backward, reduction half, in this epilogue (EPI_BNB; autograd of models/resnet.py:33-36).  `out` is the gradient
+    // w.r.t. the ReLU'd output of a train-mode BatchNorm whose raw input is bnb_y (same shape as `out`): the epilogue applies the ReLU
+    // mask (from the post-ReLU activation bnb_z, or, when that was never written because the forward applied the BatchNorm inside the
+    // consuming convolution, recomputed as fma(y, scale, shift) > 0 with the forward's own arithmetic), stores the MASKED gradient d
+    // and adds sum(d) and sum(d * (y - mean)) per (group, channel) to `stats` (the forward's replicated fp64 scheme): what
+    // bn_bwd_fused_kernel needed a grid-wide arrival for.  bn_bwd_apply_e_kernel then only streams: dy = f(d, y, sums).
+    const float* bnb_y;
+    const float* bnb_z;         // null: mask recomputed from bnb_y
+    const float* bnb_mean;      // [groups][Cout]
+    const float* bnb_invstd;    // [groups][Cout]
+    const float* bnb_gamma;     // [Cout]
+    const float* bnb_beta;      // [Cout]
+    int bnb_lds;                // float offset (from the end of the patch area) of the epilogue's LDS table [groups][Cout/4][3][4]: scale, shift, mean quads (planner; -1: no room reserved)
     const int* blob;
     int off_tdesc, off_pu, off_loc, blob_ints;
     unsigned long long* trace;  // measurement only (kbench): per workgroup 64 s_memtime stamps of wave 0 at the phase boundaries
@@ -88,6 +102,10 @@ struct ConvPlan {
     int MT, NT;                 // 16-channel tiles and 16-pixel tiles per wave (conv_t_kernel<MT, NT, ...>)
     int grid_x, grid_y;
     size_t lds_bytes;
+    // the tables' upload (conv_plan_finalize with an arena: asynchronous, on the stream of the plan's first launch): a launch on ANOTHER
+    // stream waits for this event first
+    hipEvent_t ready;
+    hipStream_t ready_stream;
 };
 
 // geometry description used by the planner
@@ -104,6 +122,7 @@ struct ConvGeomDesc {
     int force_pipe;                      // staged-weight schedule: 0 = environment (OCL_CONV_PIPE, default on), 1 = ring, -1 = two-buffer
     int WPT;                    // row stride of the K-grouped weight pack (0: the plan's own CoutP)
     int xf;                     // reserve LDS for the input-transform table (ConvArgs::xf may then be set at launch)
+    int bnb;                    // reserve LDS for the BatchNorm-backward epilogue table (EPI_BNB may then be set at launch)
     int ncls;                   // > 1: output classes of one launch, taps listed class by class
     int cls_ntaps[4], cls_oy[4], cls_ox[4];
 };
@@ -119,6 +138,7 @@ struct PlanArena {
     std::vector<void*> chunks;
     size_t used = 0, cap = 0;
     std::vector<std::vector<int>*> host_keep;
+    std::vector<hipEvent_t> events;   // one per plan: its tables have landed
 };
 void plan_arena_release(PlanArena* a);
 // arena == nullptr: one hipMalloc + one blocking copy for this plan (measurement tools)
@@ -135,7 +155,8 @@ int pack_width(int channels);   // row stride of a weight pack with `channels` c
 // stride-2 shortcut, four dense parity classes of the dx lattice for 3x3 stride 2 (merge_classes: as ONE description with
 // four output classes when the lattices coincide, i.e. even input height and width).
 void geom_fwd(const ConvShape& c, int N, int groups, ConvGeomDesc* g);
-void geom_dgrad(const ConvShape& c, int N, std::vector<ConvGeomDesc>* out, bool merge_classes = false);
+// groups > 1: the tiles follow the BatchNorm groups of the pass (no tile straddles two groups: the EPI_BNB epilogue sums per group)
+void geom_dgrad(const ConvShape& c, int N, std::vector<ConvGeomDesc>* out, bool merge_classes = false, int groups = 1);
 int launch_conv(const ConvPlan& p, hipStream_t s);
 
 // ---- wgrad -------------------------------------------------------------------------------------------
@@ -211,6 +232,13 @@ int launch_pack_weights(const float* params, float* arena, const PackDesc* descs
 
 // ---- layout / elementwise ------------------------------------------------------------------------------
 int launch_nchw3_to_nhwc4(const float* x, float* out, int N, int H, int W, hipStream_t s);
+constexpr int kMaxInputSegments = 8;
+struct InputSegments {
+    const float* x[kMaxInputSegments];   // [n_i, 3, H, W] each
+    int first[kMaxInputSegments];        // index of the segment's first image in the batch
+    int n;                               // number of segments
+};
+int launch_nchw3_to_nhwc4_segments(const InputSegments& sg, float* out, int N, int H, int W, hipStream_t s);
 
 struct BnFwdArgs {
     const float* y;       // raw conv output [M,C]
@@ -270,6 +298,24 @@ struct BnBwdArgs {
     const float* beta[2];
 };
 int launch_bn_bwd(const BnBwdArgs& a, hipStream_t s);
+// Apply half of a BatchNorm backward whose reduction ran in the producing data gradient's epilogue (EPI_BNB): d is the masked gradient,
+// esums the replicated sums [kStatReps][G][2][C] (replica stride esums_rep_stride doubles) of d and d * (y - mean);
+// dy = gamma * invstd * (d - mean(d) - xhat * mean(d * xhat)); block 0 writes dgamma / dbeta.  Pure streaming: no atomics, no arrival.
+struct BnApplyEArgs {
+    const float* d;
+    const float* y;
+    const float* mean;      // [G][C]
+    const float* invstd;    // [G][C]
+    const float* gamma;     // [C]
+    float* dy;
+    float* dgamma;
+    float* dbeta;
+    const double* esums;
+    int64_t esums_rep_stride;
+    int64_t m_per_group;
+    int G, C, accumulate;
+};
+int launch_bn_apply_e(const BnApplyEArgs& a, hipStream_t s);
 void bn_bwd_tune(int block_cap, int unroll, int phase);
 void bn_bwd_fused_enable(int on);   // one-pass kernel on/off (-1: OCL_BN_FUSED from the environment, default on)   // micro-benchmark overrides; 0 = default (phase 1 reduce only, 2 apply only)
 

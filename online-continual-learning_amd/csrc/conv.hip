@@ -101,6 +101,35 @@ __device__ __forceinline__ void bn_running_update(const double* __restrict__ sta
     if (tid == 0 && nbt) *nbt += G;
 }
 
+// ---- EPI_BNB: the reduction half of a BatchNorm backward in the epilogue of the data gradient that produces its input gradient ------
+// table [groups][Cout/4][3][4]: scale quad, shift quad (the forward's bn_scale_shift: the recomputed ReLU mask has the forward's bits),
+// mean quad
+__device__ __forceinline__ void bnb_table(const ConvArgs& a, float* tab, int tid, int nthreads) {
+    const int C = a.Cout;
+    for (int j = tid; j < a.groups * C; j += nthreads) {
+        const int gq = j / C, c = j - gq * C;
+        const float mean = a.bnb_mean[j];
+        float sc, sh;
+        bn_scale_shift(a.bnb_gamma[c], a.bnb_beta[c], mean, a.bnb_invstd[j], sc, sh);
+        float* t = tab + (size_t)(gq * (C >> 2) + (c >> 2)) * 12 + (c & 3);
+        t[0] = sc;
+        t[4] = sh;
+        t[8] = mean;
+    }
+}
+// one channel quad of one pixel: v = gradient w.r.t. the ReLU'd BatchNorm output (complete); masks it and adds to the lane's partial sums
+__device__ __forceinline__ void bnb_apply(const ConvArgs& a, const float4 sc, const float4 sh, const float4 mu, int64_t eo, float4& v,
+                                          float (&s1)[4], float (&s2)[4]) {
+    const float4 y = *(const float4*)(a.bnb_y + eo);
+    float4 zz;
+    if (a.bnb_z) zz = *(const float4*)(a.bnb_z + eo);
+    else zz = make_float4(__fmaf_rn(y.x, sc.x, sh.x), __fmaf_rn(y.y, sc.y, sh.y), __fmaf_rn(y.z, sc.z, sh.z), __fmaf_rn(y.w, sc.w, sh.w));
+    v.x = zz.x > 0.f ? v.x : 0.f; v.y = zz.y > 0.f ? v.y : 0.f; v.z = zz.z > 0.f ? v.z : 0.f; v.w = zz.w > 0.f ? v.w : 0.f;
+    s1[0] += v.x; s1[1] += v.y; s1[2] += v.z; s1[3] += v.w;
+    s2[0] = fmaf(v.x, y.x - mu.x, s2[0]); s2[1] = fmaf(v.y, y.y - mu.y, s2[1]);
+    s2[2] = fmaf(v.z, y.z - mu.z, s2[2]); s2[3] = fmaf(v.w, y.w - mu.w, s2[3]);
+}
+
 // =====================================================================================================
 // conv_t_kernel: channels x pixels orientation with K-grouped operands
 // =====================================================================================================
@@ -155,7 +184,9 @@ constexpr int kMaxWgTiles = 64;                // tile descriptors a workgroup k
 __host__ __device__ constexpr int pipe_qs(int MT) { return MT == 1 ? 64 : MT == 2 ? 32 : 16; }
 __host__ __device__ constexpr int pipe_wpf(int MT) { return pipe_qs(MT) * 16 * MT / 256; }
 
-template <int MT, int NT, int PF, bool RES, bool CLS = false, bool PIPE = false>   // CLS: several output classes per tile (merged parity classes of a stride-2 data gradient)
+// BNB: instantiated with the EPI_BNB epilogue (its registers must not weigh on the other launches: the forward instantiations sit at the
+// edge of their occupancy step)
+template <int MT, int NT, int PF, bool RES, bool CLS = false, bool PIPE = false, bool BNB = false>   // CLS: several output classes per tile (merged parity classes of a stride-2 data gradient)
 __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArgs a) {   // PIPE plans run one workgroup per CU (three stage buffers): all 512 registers
     static_assert(!(PIPE && RES), "the ring is a schedule of the staged-weight path");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
@@ -169,6 +200,7 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
     float* wl = (float*)(qrow + a.Qpad);       // resident: [Qpad][COPW][4]; staged: [2][QS][COPW][4]; PIPE: [3][QS][COPW][4]
     float* patch = wl + (size_t)(RES ? a.Qpad : (PIPE ? 3 : 2) * a.QS) * COPW * 4;   // [imgs][PR][PC][CP]
     float* xft = patch + a.patch_floats;       // input transform: [groups][Cin/4][2][4] scale quads / shift quads
+    const float* bnt = xft + (a.bnb_lds > 0 ? a.bnb_lds : 0);   // EPI_BNB: [groups][Cout/4][3][4] scale, shift, mean quads of the BatchNorm being differentiated
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, g = lane >> 4;
@@ -179,7 +211,7 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
     const int t_begin = (int)(((int64_t)blockIdx.x * ntiles_all) / gridDim.x), t_end = (int)(((int64_t)(blockIdx.x + 1) * ntiles_all) / gridDim.x);
     const int nwt = t_end - t_begin;
     if (nwt <= 0) return;
-    const int flags = a.flags;
+    const int flags = BNB ? a.flags : (a.flags & ~EPI_BNB);
     int tr_n = 0;
     auto stamp = [&]() __attribute__((always_inline)) {
         if (a.trace && tid == 0 && tr_n < 64) a.trace[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 64 + tr_n++] = __builtin_amdgcn_s_memtime();
@@ -287,6 +319,7 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
         if (lead && a.xf_running_mean)
             bn_running_update(a.xf_stats, a.xf_rep_stride, a.groups, C, M, a.xf_momentum, a.xf_eps, a.xf_running_mean, a.xf_running_var, a.xf_nbt, tid, 256);
     }
+    if (BNB && (flags & EPI_BNB)) bnb_table(a, const_cast<float*>(bnt), tid, 256);
     if (tid < ntab) ctab[tid] = tab0;
     if (tid + 256 < ntab) ctab[tid + 256] = tab1;
     if (tid + 512 < ntab) ctab[tid + 512] = tab2;
@@ -461,7 +494,7 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
     for (int k = 0; k < nwt; ++k) {
         const int4 d0 = *(const int4*)(tdesc + k * 8);       // in_base, iy0, nrows, obase
         const int4 d1 = *(const int4*)(tdesc + k * 8 + 4);   // nimg, grp, p0, img0 | ly0 << 20
-        if ((flags & EPI_STATS) && d1.y != run_grp) {   // block-uniform; the tile range is in ascending group order
+        if ((flags & (EPI_STATS | EPI_BNB)) && d1.y != run_grp) {   // block-uniform; the tile range is in ascending group order
             if (run_grp >= 0) flush_stats();
             run_grp = d1.y;
         }
@@ -751,6 +784,11 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
                     const float4 o = *(const float4*)op;
                     v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
                 }
+                if (BNB && (flags & EPI_BNB)) {   // ReLU mask + the two batch sums of the BatchNorm this gradient enters (ConvArgs::bnb_*)
+                    const int64_t eo = (int64_t)ooff[nt] + ct.z + co;
+                    const float* t = bnt + (size_t)(d1.y * (a.Cout >> 2) + (co >> 2)) * 12;
+                    bnb_apply(a, *(const float4*)t, *(const float4*)(t + 4), *(const float4*)(t + 8), eo, v, s1[mt], s2[mt]);
+                }
                 if (flags & EPI_RELU) {
                     v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
                 }
@@ -760,7 +798,7 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
         }   // classes
         stamp();   // tile + 5: epilogue issued
     }
-    if ((flags & EPI_STATS) && run_grp >= 0) flush_stats();
+    if ((flags & (EPI_STATS | EPI_BNB)) && run_grp >= 0) flush_stats();
     stamp();
 }
 
@@ -782,7 +820,7 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
 // workgroups per CU kept at two by LDS and registers.  Weights are always resident (<= 14.4 KB); tables, patch staging, input transform and epilogue flags as in
 // conv_t_kernel.
 constexpr int kQBlocks = 5;   // blocks of four output channels (Cout <= 20)
-template <int NTQ, int PF, bool STATS>
+template <int NTQ, int PF, int STATS>   // 0: no sums; 1: forward batch statistics (EPI_STATS); 2: BatchNorm-backward sums (EPI_BNB)
 __global__ void __launch_bounds__(256, 2) conv_q_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     constexpr int MB = kQBlocks, COPW = 4 * MB;
@@ -793,13 +831,14 @@ __global__ void __launch_bounds__(256, 2) conv_q_kernel(const ConvArgs a) {
     float* wl = (float*)(qrow + a.Qpad);                  // [Qpad][COPW][4]
     float* patch = wl + (size_t)a.Qpad * COPW * 4;
     float* xft = patch + a.patch_floats;
+    const float* bnt = xft + (a.bnb_lds > 0 ? a.bnb_lds : 0);   // EPI_BNB table (see conv_t_kernel)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int LP = a.LH * a.LW;
     const int ntiles_all = a.groups * a.tiles_per_group;
     const int t_begin = (int)(((int64_t)blockIdx.x * ntiles_all) / gridDim.x), t_end = (int)(((int64_t)(blockIdx.x + 1) * ntiles_all) / gridDim.x);
     const int nwt = t_end - t_begin;
     if (nwt <= 0) return;
-    const int flags = STATS ? a.flags : (a.flags & ~EPI_STATS);   // (instantiated without the statistics: no partial sums in registers)
+    const int flags = STATS == 1 ? (a.flags & ~EPI_BNB) : STATS == 2 ? (a.flags & ~EPI_STATS) : (a.flags & ~(EPI_STATS | EPI_BNB));   // (instantiated without the statistics: no partial sums in registers)
     // ---- plan tables (conv_plan_tables) ----------------------------------------------------------------------------------------
     const int* __restrict__ blob = a.blob;
     // Register budget (two workgroups per CU: 256 registers, accumulators in ArchVGPRs so that the K loop carries no accvgpr copies
@@ -887,6 +926,7 @@ __global__ void __launch_bounds__(256, 2) conv_q_kernel(const ConvArgs a) {
         if (lead && a.xf_running_mean)
             bn_running_update(a.xf_stats, a.xf_rep_stride, a.groups, C, M, a.xf_momentum, a.xf_eps, a.xf_running_mean, a.xf_running_var, a.xf_nbt, tid, 256);
     }
+    if (STATS == 2 && (flags & EPI_BNB)) bnb_table(a, const_cast<float*>(bnt), tid, 256);
     if (tid < ntab) ctab[tid] = tab0;
     if (tid + 256 < ntab) ctab[tid + 256] = tab1;
     if (tid < ntd) tdesc[tid] = td0;
@@ -931,7 +971,7 @@ __global__ void __launch_bounds__(256, 2) conv_q_kernel(const ConvArgs a) {
     for (int k = 0; k < nwt; ++k) {
         const int4 d0 = *(const int4*)(tdesc + k * 8);
         const int4 d1 = *(const int4*)(tdesc + k * 8 + 4);
-        if ((flags & EPI_STATS) && d1.y != run_grp) {
+        if ((flags & (EPI_STATS | EPI_BNB)) && d1.y != run_grp) {
             if (run_grp >= 0) flush_stats();
             run_grp = d1.y;
         }
@@ -1003,7 +1043,7 @@ __global__ void __launch_bounds__(256, 2) conv_q_kernel(const ConvArgs a) {
             }
             if (q < nq) fma(0);
         }
-        if (STATS && (flags & EPI_STATS)) {   // this tile's sums over the wave's pixels -> the wave's accumulator slot
+        if (STATS == 1 && (flags & EPI_STATS)) {   // this tile's sums over the wave's pixels -> the wave's accumulator slot
             float* rw = qrows + (size_t)(wave * 4 + (lane >> 4)) * 2 * COPW;
 #pragma unroll
             for (int m = 0; m < MB; ++m)
@@ -1029,40 +1069,69 @@ __global__ void __launch_bounds__(256, 2) conv_q_kernel(const ConvArgs a) {
             }
         }
         // ---- epilogue from registers: the lane holds channels 4m .. 4m + 3 of its NTQ pixels ---------------------------------------
-#pragma unroll
-        for (int nt = 0; nt < NTQ; ++nt) {
-            const bool pv_ok = ooff[nt] >= 0;
+        // one (pixel set, channel block) of the tile: the flag-driven register epilogue
+        auto epi_one = [&](int nt, int m, float (&b1)[4], float (&b2)[4]) __attribute__((always_inline)) {
+            const int co = 4 * m;
+            if (ooff[nt] < 0 || co >= a.Cout) return;
+            float4 v = make_float4(acc[m][nt][0], acc[m][nt][1], acc[m][nt][2], acc[m][nt][3]);
+            float* op = a.out + (int64_t)ooff[nt] + co;
+            if (flags & EPI_AFFINE) {
+                const float4 sc = *(const float4*)(a.scale + co), sh = *(const float4*)(a.shift + co);
+                v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+            }
+            if (flags & EPI_RES) {
+                const float4 r = *(const float4*)(a.res + (int64_t)ooff[nt] + co);
+                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            }
+            if (flags & EPI_RESMASK) {
+                const float4 r = *(const float4*)(a.res + (int64_t)ooff[nt] + co);
+                const float4 mk = *(const float4*)(a.resmask + (int64_t)ooff[nt] + co);
+                v.x += mk.x > 0.f ? r.x : 0.f; v.y += mk.y > 0.f ? r.y : 0.f; v.z += mk.z > 0.f ? r.z : 0.f; v.w += mk.w > 0.f ? r.w : 0.f;
+            }
+            if (flags & EPI_ACCUM) {
+                const float4 o = *(const float4*)op;
+                v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+            }
+            if (STATS == 2 && (flags & EPI_BNB)) {
+                const float* t = bnt + (size_t)(d1.y * (a.Cout >> 2) + m) * 12;
+                bnb_apply(a, *(const float4*)t, *(const float4*)(t + 4), *(const float4*)(t + 8), (int64_t)ooff[nt] + co, v, b1, b2);
+            }
+            if (flags & EPI_RELU) {
+                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+            }
+            *(float4*)op = v;
+        };
+        if (STATS == 2 && (flags & EPI_BNB)) {
+            // channel block by channel block (8 sum registers at a time): the block's sums over the wave's pixels -> the wave's
+            // accumulator slot, as the forward's statistics
+            float* rw = qrows + (size_t)(wave * 4 + (lane >> 4)) * 2 * COPW;
 #pragma unroll
             for (int m = 0; m < MB; ++m) {
-                const int co = 4 * m;
-                if (!pv_ok || co >= a.Cout) continue;
-                float4 v = make_float4(acc[m][nt][0], acc[m][nt][1], acc[m][nt][2], acc[m][nt][3]);
-                float* op = a.out + (int64_t)ooff[nt] + co;
-                if (flags & EPI_AFFINE) {
-                    const float4 sc = *(const float4*)(a.scale + co), sh = *(const float4*)(a.shift + co);
-                    v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+                float b1[4] = {0.f, 0.f, 0.f, 0.f}, b2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int nt = 0; nt < NTQ; ++nt) epi_one(nt, m, b1, b2);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float r1 = row16_sum(b1[e]), r2 = row16_sum(b2[e]);
+                    if ((lane & 15) == 0) {
+                        rw[m * 4 + e] = r1;
+                        rw[COPW + m * 4 + e] = r2;
+                    }
                 }
-                if (flags & EPI_RES) {
-                    const float4 r = *(const float4*)(a.res + (int64_t)ooff[nt] + co);
-                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
-                }
-                if (flags & EPI_RESMASK) {
-                    const float4 r = *(const float4*)(a.res + (int64_t)ooff[nt] + co);
-                    const float4 mk = *(const float4*)(a.resmask + (int64_t)ooff[nt] + co);
-                    v.x += mk.x > 0.f ? r.x : 0.f; v.y += mk.y > 0.f ? r.y : 0.f; v.z += mk.z > 0.f ? r.z : 0.f; v.w += mk.w > 0.f ? r.w : 0.f;
-                }
-                if (flags & EPI_ACCUM) {
-                    const float4 o = *(const float4*)op;
-                    v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-                }
-                if (flags & EPI_RELU) {
-                    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                }
-                *(float4*)op = v;
             }
+            if (lane < 2 * COPW) {   // (same wave: the writes above are ordered before these reads)
+                const float* r0 = qrows + (size_t)(wave * 4) * 2 * COPW + lane;
+                qacc[wave * 2 * COPW + lane] += (r0[0] + r0[2 * COPW]) + (r0[4 * COPW] + r0[6 * COPW]);
+            }
+        } else {
+            float nb1[4], nb2[4];   // (unused)
+#pragma unroll
+            for (int nt = 0; nt < NTQ; ++nt)
+#pragma unroll
+                for (int m = 0; m < MB; ++m) epi_one(nt, m, nb1, nb2);
         }
     }
-    if ((flags & EPI_STATS) && run_grp >= 0) flush_stats();
+    if ((flags & (EPI_STATS | EPI_BNB)) && run_grp >= 0) flush_stats();
 }
 
 
@@ -1083,7 +1152,7 @@ __global__ void __launch_bounds__(256, 2) conv_q_kernel(const ConvArgs a) {
 // The kernel must stay free of scratch: a build with 10 spilled VGPRs was 1 - 4 us per launch slower than the one before it.
 constexpr int kDepthS = 4;    // weight rounds in flight per wave
 constexpr int kPFS = 7;       // patch units (16 bytes) per lane and staging pass: a wave stages 448 units per pass (layer 4 needs 360 - 405; 8 would spill at 96 VGPRs)
-template <int NT, bool TRACE>
+template <int NT, bool TRACE, bool BNB = false>   // BNB: instantiated with the EPI_BNB epilogue
 __global__ void __launch_bounds__(256, NT == 1 ? 5 : 4) conv_s_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     int* ctab = (int*)lds_raw;
@@ -1094,7 +1163,7 @@ __global__ void __launch_bounds__(256, NT == 1 ? 5 : 4) conv_s_kernel(const Conv
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, g = lane >> 4;
     const int n0 = blockIdx.y * 16;
-    const int flags = a.flags;
+    const int flags = BNB ? a.flags : (a.flags & ~EPI_BNB);
     const int* __restrict__ blob = a.blob;
     const int tile = blockIdx.x;
     const int c0 = wave * a.KC;                      // this wave's channel slice
@@ -1317,25 +1386,50 @@ __global__ void __launch_bounds__(256, NT == 1 ? 5 : 4) conv_s_kernel(const Conv
             atomicAdd(st_ + a.Cout + 2, (double)s2z); atomicAdd(st_ + a.Cout + 3, (double)s2w);
         }
     }
-    if (!live) return;
     float* op = a.out + (int64_t)oo + co;
-    if (flags & EPI_AFFINE) {
-        const float4 sc = *(const float4*)(a.scale + co), sh = *(const float4*)(a.shift + co);
-        v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+    if (live) {
+        if (flags & EPI_AFFINE) {
+            const float4 sc = *(const float4*)(a.scale + co), sh = *(const float4*)(a.shift + co);
+            v.x = fmaf(v.x, sc.x, sh.x); v.y = fmaf(v.y, sc.y, sh.y); v.z = fmaf(v.z, sc.z, sh.z); v.w = fmaf(v.w, sc.w, sh.w);
+        }
+        if (flags & EPI_RES) {
+            const float4 r = *(const float4*)(a.res + (int64_t)oo + co);
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
+        if (flags & EPI_RESMASK) {
+            const float4 r = *(const float4*)(a.res + (int64_t)oo + co);
+            const float4 mk = *(const float4*)(a.resmask + (int64_t)oo + co);
+            v.x += mk.x > 0.f ? r.x : 0.f; v.y += mk.y > 0.f ? r.y : 0.f; v.z += mk.z > 0.f ? r.z : 0.f; v.w += mk.w > 0.f ? r.w : 0.f;
+        }
+        if (flags & EPI_ACCUM) {
+            const float4 o = *(const float4*)op;
+            v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
+        }
     }
-    if (flags & EPI_RES) {
-        const float4 r = *(const float4*)(a.res + (int64_t)oo + co);
-        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+    if (BNB && (flags & EPI_BNB)) {   // ReLU mask + the two batch sums of the BatchNorm this gradient enters; one channel quad per lane: the
+                             // BatchNorm's parameters come straight from memory (no table), after the K loop (no registers across it)
+        float b1[4] = {0.f, 0.f, 0.f, 0.f}, b2[4] = {0.f, 0.f, 0.f, 0.f};
+        if (live) {
+            const int j = d1.y * a.Cout + co;
+            const float4 mu = *(const float4*)(a.bnb_mean + j);
+            float4 sc = make_float4(0.f, 0.f, 0.f, 0.f), sh = sc;
+            if (!a.bnb_z) {
+                const float4 is = *(const float4*)(a.bnb_invstd + j), gm = *(const float4*)(a.bnb_gamma + co), bt = *(const float4*)(a.bnb_beta + co);
+                bn_scale_shift(gm.x, bt.x, mu.x, is.x, sc.x, sh.x); bn_scale_shift(gm.y, bt.y, mu.y, is.y, sc.y, sh.y);
+                bn_scale_shift(gm.z, bt.z, mu.z, is.z, sc.z, sh.z); bn_scale_shift(gm.w, bt.w, mu.w, is.w, sc.w, sh.w);
+            }
+            bnb_apply(a, sc, sh, mu, (int64_t)oo + co, v, b1, b2);
+        }
+        const float s1x = row16_sum(b1[0]), s1y = row16_sum(b1[1]), s1z = row16_sum(b1[2]), s1w = row16_sum(b1[3]);
+        const float s2x = row16_sum(b2[0]), s2y = row16_sum(b2[1]), s2z = row16_sum(b2[2]), s2w = row16_sum(b2[3]);
+        if (r16 == 0 && co < a.Cout) {
+            double* st_ = a.stats + (int64_t)((blockIdx.x + blockIdx.y + wave) % kStatReps) * a.stat_rep_stride + ((int64_t)d1.y * 2) * a.Cout + co;
+            atomicAdd(st_ + 0, (double)s1x); atomicAdd(st_ + 1, (double)s1y); atomicAdd(st_ + 2, (double)s1z); atomicAdd(st_ + 3, (double)s1w);
+            atomicAdd(st_ + a.Cout + 0, (double)s2x); atomicAdd(st_ + a.Cout + 1, (double)s2y);
+            atomicAdd(st_ + a.Cout + 2, (double)s2z); atomicAdd(st_ + a.Cout + 3, (double)s2w);
+        }
     }
-    if (flags & EPI_RESMASK) {
-        const float4 r = *(const float4*)(a.res + (int64_t)oo + co);
-        const float4 mk = *(const float4*)(a.resmask + (int64_t)oo + co);
-        v.x += mk.x > 0.f ? r.x : 0.f; v.y += mk.y > 0.f ? r.y : 0.f; v.z += mk.z > 0.f ? r.z : 0.f; v.w += mk.w > 0.f ? r.w : 0.f;
-    }
-    if (flags & EPI_ACCUM) {
-        const float4 o = *(const float4*)op;
-        v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w;
-    }
+    if (!live) return;
     if (flags & EPI_RELU) {
         v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
     }
@@ -1344,13 +1438,36 @@ __global__ void __launch_bounds__(256, NT == 1 ? 5 : 4) conv_s_kernel(const Conv
 }
 
 typedef void (*conv_fn_t)(const ConvArgs);
-static conv_fn_t convs_fn(int nt, bool trace = false) {
+static conv_fn_t convs_fn(int nt, bool trace = false, bool bnb = false) {
+    if (bnb) return nt == 2 ? conv_s_kernel<2, false, true> : conv_s_kernel<1, false, true>;
     if (trace) return nt == 2 ? conv_s_kernel<2, true> : conv_s_kernel<1, true>;
     return nt == 2 ? conv_s_kernel<2, false> : conv_s_kernel<1, false>;
 }
 
 #define OCL_CONVT_TILINGS(X) X(1, 1) X(2, 1) X(3, 1) X(4, 1) X(5, 1) X(1, 2) X(2, 2) X(3, 2) X(4, 2) X(5, 2)
-static conv_fn_t convt_fn(int MT, int NT, int PF, int res, int cls = 0, int pipe = 0) {
+static conv_fn_t convt_fn(int MT, int NT, int PF, int res, int cls = 0, int pipe = 0, int bnb = 0) {
+    if (bnb) {   // the EPI_BNB epilogue: stride-1 data gradients only (no output classes)
+        if (cls) return nullptr;
+        if (pipe) {
+            if (res || NT != 1) return nullptr;
+#define OCL_CASE(M)                                                                                     \
+    if (MT == M) {                                                                                      \
+        if (PF == 4) return conv_t_kernel<M, 1, 4, false, false, true, true>;                           \
+        if (PF == 8) return conv_t_kernel<M, 1, 8, false, false, true, true>;                           \
+    }
+            OCL_CASE(1) OCL_CASE(2) OCL_CASE(3) OCL_CASE(4) OCL_CASE(5)
+#undef OCL_CASE
+            return nullptr;
+        }
+#define OCL_CASE(M, N)                                                                                                              \
+    if (MT == M && NT == N) {                                                                                                       \
+        if (PF == 4) return res ? conv_t_kernel<M, N, 4, true, false, false, true> : conv_t_kernel<M, N, 4, false, false, false, true>;   \
+        if (PF == 8) return res ? conv_t_kernel<M, N, 8, true, false, false, true> : conv_t_kernel<M, N, 8, false, false, false, true>;   \
+    }
+        OCL_CONVT_TILINGS(OCL_CASE)
+#undef OCL_CASE
+        return nullptr;
+    }
     if (pipe) {   // staged weights through the ring: one pixel tile per wave
         if (res || NT != 1) return nullptr;
 #define OCL_CASE(M)                                                                                                                  \
@@ -1420,7 +1537,9 @@ static size_t convt_layout(const ConvGeomDesc& g, ConvArgs& a, int MT, int NT, b
             const size_t patch_b = (size_t)round_up(std::max((size_t)a.imgs * a.PR * a.PC * a.CP * 4, (size_t)8 * COPW * 8), 16);
             a.patch_floats = (int)(patch_b / 4);
             const size_t xf_b = g.xf ? (size_t)g.groups * g.Cin * 8 : 0;   // input transform: scale / shift per (group, channel)
-            bytes = (size_t)kMaxWgTiles * 32 + 64 + (size_t)2 * a.Qpad * 4 + (a.wres ? w_all : (size_t)(a.pipe ? 3 : 2) * a.QS * COPW * 16) + patch_b + xf_b;
+            const size_t bnb_b = g.bnb ? (size_t)g.groups * g.Cout * 12 : 0;   // EPI_BNB: scale / shift / mean per (group, output channel)
+            a.bnb_lds = g.bnb ? (int)(xf_b / 4) : -1;
+            bytes = (size_t)kMaxWgTiles * 32 + 64 + (size_t)2 * a.Qpad * 4 + (a.wres ? w_all : (size_t)(a.pipe ? 3 : 2) * a.QS * COPW * 16) + patch_b + xf_b + bnb_b;
             const bool units_ok = a.imgs * a.PR * a.PC * (KC / 4) <= 256 * kConvPatchPF;
             if (units_ok && bytes <= kLdsLimit - 2048 && (bytes <= 100 * 1024 || KC <= 20)) goto found;
         }
@@ -1467,7 +1586,9 @@ static int plan_conv_q_ntq(const ConvGeomDesc& g, ConvPlan* p, const int NTQ, bo
     const int PF = (units <= 1024 && NTQ == 2) ? 4 : 12;
     const size_t patch_b = (size_t)round_up(std::max((size_t)a.imgs * a.PR * a.PC * a.CP * 4, (size_t)8 * COPW * 8), 16);
     a.patch_floats = (int)(patch_b / 4);
-    size_t lds = (size_t)kMaxWgTiles * 32 + 64 + (size_t)2 * a.Qpad * 4 + (size_t)a.Qpad * COPW * 16 + patch_b + (g.xf ? (size_t)g.groups * g.Cin * 8 : 0);
+    size_t lds = (size_t)kMaxWgTiles * 32 + 64 + (size_t)2 * a.Qpad * 4 + (size_t)a.Qpad * COPW * 16 + patch_b + (g.xf ? (size_t)g.groups * g.Cin * 8 : 0) +
+                 (g.bnb ? (size_t)g.groups * g.Cout * 12 : 0);
+    a.bnb_lds = g.bnb ? (g.xf ? g.groups * g.Cin * 2 : 0) : -1;
     a.qstat_off = (int)round_up(lds, 16);
     lds = (size_t)a.qstat_off + (size_t)(4 * 4 + 4) * 2 * COPW * 4;   // statistics scratch: row sums + per-wave accumulators
     if (lds > kLdsLimit - 2048) return OCL_ERR_ARG;
@@ -1556,6 +1677,7 @@ static int plan_conv_s_nt(const ConvGeomDesc& g, ConvPlan* p, int NT) {
     a.nstage = cdiv(units, 64 * kPFS);                  // staging passes of 64 kPFS units per wave
     if (a.nstage > 3 || a.imgs > 127 || a.PR >= 256 || a.PC >= 256 || a.KC / 4 >= 64) return OCL_ERR_ARG;
     a.patch_floats = std::max((int)round_up((int64_t)a.imgs * a.PR * a.PC * a.CP, 4), NT * 64 * 4);   // (>= the partial tiles it holds at the end)
+    a.bnb_lds = g.bnb ? 0 : -1;   // (conv_s_kernel reads the BatchNorm's parameters straight from memory: no table)
     a.tiles_per_group = cdiv(a.group_size, a.imgs) * a.tiles_per_img;
     const int ntiles = g.groups * a.tiles_per_group;
     const size_t lds = 64 + (size_t)(2 * a.Qpad + 16) * 4 + (size_t)4 * a.patch_floats * 4 + (g.xf ? (size_t)g.groups * g.Cin * 8 : 0);
@@ -1861,10 +1983,18 @@ int conv_plan_finalize(ConvPlan* p, PlanArena* arena, hipStream_t s) {
     int* d = (int*)((char*)arena->chunks.back() + arena->used);
     arena->used += bytes;
     OCL_HIP(hipMemcpyAsync(d, t->data(), t->size() * sizeof(int), hipMemcpyHostToDevice, s));
+    hipEvent_t e;
+    OCL_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    arena->events.push_back(e);
+    OCL_HIP(hipEventRecord(e, s));
+    p->ready = e;
+    p->ready_stream = s;
     p->a.blob = d;
     return OCL_OK;
 }
 void plan_arena_release(PlanArena* a) {
+    for (hipEvent_t e : a->events) (void)hipEventDestroy(e);
+    a->events.clear();
     for (void* c : a->chunks) (void)hipFree(c);
     for (auto* v : a->host_keep) delete v;
     a->chunks.clear();
@@ -1920,11 +2050,11 @@ void geom_fwd(const ConvShape& c, int N, int groups, ConvGeomDesc* g) {
     }
 }
 
-void geom_dgrad(const ConvShape& c, int N, std::vector<ConvGeomDesc>* out, bool merge_classes) {
+void geom_dgrad(const ConvShape& c, int N, std::vector<ConvGeomDesc>* out, bool merge_classes, int groups) {
     out->clear();
     ConvGeomDesc g;
     memset(&g, 0, sizeof(g));
-    g.N = N; g.groups = 1;
+    g.N = N; g.groups = groups;
     g.Hin = c.Ho; g.Win = c.Wo; g.Cin = c.Cout;
     g.Hout = c.Hin; g.Wout = c.Win; g.Cout = c.Cin;
     g.is = 1;
@@ -1995,10 +2125,11 @@ void geom_dgrad(const ConvShape& c, int N, std::vector<ConvGeomDesc>* out, bool 
     }
 }
 
-static conv_fn_t convq_fn(int ntq, int pf, int stats) {
-    if (ntq == 2 && pf == 4) return stats ? conv_q_kernel<2, 4, true> : conv_q_kernel<2, 4, false>;
-    if (ntq == 2 && pf == 12) return stats ? conv_q_kernel<2, 12, true> : conv_q_kernel<2, 12, false>;
-    if (ntq == 1 && pf == 12) return stats ? conv_q_kernel<1, 12, true> : conv_q_kernel<1, 12, false>;
+static conv_fn_t convq_fn(int ntq, int pf, int stats) {   // stats: 0 none, 1 EPI_STATS, 2 EPI_BNB
+#define OCL_CASE(N, P)                                                                                                         \
+    if (ntq == N && pf == P) return stats == 2 ? conv_q_kernel<N, P, 2> : stats == 1 ? conv_q_kernel<N, P, 1> : conv_q_kernel<N, P, 0>;
+    OCL_CASE(2, 4) OCL_CASE(2, 12) OCL_CASE(1, 12)
+#undef OCL_CASE
     return nullptr;
 }
 
@@ -2009,12 +2140,12 @@ int launch_conv(const ConvPlan& p, hipStream_t s) {
             return OCL_ERR_STATE;
         }
         ProfScope ps(PROF_CONV, s);
-        hipLaunchKernelGGL(convs_fn(p.NT, p.a.trace != nullptr), dim3(p.grid_x, p.grid_y), dim3(256), p.lds_bytes, s, p.a);
+        hipLaunchKernelGGL(convs_fn(p.NT, p.a.trace != nullptr, (p.a.flags & EPI_BNB) != 0), dim3(p.grid_x, p.grid_y), dim3(256), p.lds_bytes, s, p.a);
         OCL_LAUNCH_CHECK();
         return OCL_OK;
     }
     if (p.q4) {
-        conv_fn_t fq = convq_fn(p.q4, (p.a.off_loc - p.a.off_pu) / (3 * 256), (p.a.flags & EPI_STATS) ? 1 : 0);
+        conv_fn_t fq = convq_fn(p.q4, (p.a.off_loc - p.a.off_pu) / (3 * 256), (p.a.flags & EPI_BNB) ? 2 : (p.a.flags & EPI_STATS) ? 1 : 0);
         if (!fq || !p.a.blob) {
             set_error("launch_conv: no conv_q_kernel for q4=%d / plan without device tables", p.q4);
             return OCL_ERR_STATE;
@@ -2024,7 +2155,8 @@ int launch_conv(const ConvPlan& p, hipStream_t s) {
         OCL_LAUNCH_CHECK();
         return OCL_OK;
     }
-    conv_fn_t fn = convt_fn(p.MT, p.NT, convt_pf_for(p.a.imgs * p.a.PR * p.a.PC * (p.a.KC / 4)), p.a.wres, (p.a.cls_pack & 15) > 1, p.a.pipe);
+    conv_fn_t fn = convt_fn(p.MT, p.NT, convt_pf_for(p.a.imgs * p.a.PR * p.a.PC * (p.a.KC / 4)), p.a.wres, (p.a.cls_pack & 15) > 1, p.a.pipe,
+                            (p.a.flags & EPI_BNB) ? 1 : 0);
     if (!fn) {
         set_error("launch_conv: no kernel for MT=%d NT=%d", p.MT, p.NT);
         return OCL_ERR_STATE;
@@ -2540,6 +2672,34 @@ int launch_nchw3_to_nhwc4(const float* x, float* out, int N, int H, int W, hipSt
     const int64_t total = (int64_t)N * H * W;
     ProfScope ps(PROF_BN, s);
     hipLaunchKernelGGL(nchw3_to_nhwc4_kernel, dim3((unsigned)std::min<int64_t>(2048, (total + 255) / 256)), dim3(256), 0, s, x,
+                       (float4*)out, H * W, total);
+    OCL_LAUNCH_CHECK();
+    return OCL_OK;
+}
+// the same from up to kMaxInputSegments separate [n_i, 3, H, W] tensors that together form the batch (memory rows + stream batch +
+// augmented views: the reference's torch.cat((mem_x, batch_x)) and the per-view forward calls, without materialising the concatenation)
+__global__ void __launch_bounds__(256) nchw3_to_nhwc4_seg_kernel(const InputSegments sg, float4* __restrict__ out, int HW, int64_t total) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int n = (int)(i / HW);
+        const int p = (int)(i - (int64_t)n * HW);
+        int k = 0;
+#pragma unroll
+        for (int j = 1; j < kMaxInputSegments; ++j) k = (j < sg.n && n >= sg.first[j]) ? j : k;
+        const float* xs = sg.x[0];
+#pragma unroll
+        for (int j = 1; j < kMaxInputSegments; ++j) xs = k == j ? sg.x[j] : xs;
+        int f = sg.first[0];
+#pragma unroll
+        for (int j = 1; j < kMaxInputSegments; ++j) f = k == j ? sg.first[j] : f;
+        const float* b = xs + (int64_t)(n - f) * 3 * HW + p;
+        out[i] = make_float4(b[0], b[HW], b[2 * (int64_t)HW], 0.f);
+    }
+}
+int launch_nchw3_to_nhwc4_segments(const InputSegments& sg, float* out, int N, int H, int W, hipStream_t s) {
+    if (sg.n == 1) return launch_nchw3_to_nhwc4(sg.x[0], out, N, H, W, s);
+    const int64_t total = (int64_t)N * H * W;
+    ProfScope ps(PROF_BN, s);
+    hipLaunchKernelGGL(nchw3_to_nhwc4_seg_kernel, dim3((unsigned)std::min<int64_t>(2048, (total + 255) / 256)), dim3(256), 0, s, sg,
                        (float4*)out, H * W, total);
     OCL_LAUNCH_CHECK();
     return OCL_OK;
@@ -3076,6 +3236,80 @@ int launch_bn_bwd(const BnBwdArgs& a, hipStream_t s) {
     return OCL_OK;
 }
 
+// ---- apply half of a BatchNorm backward whose two batch sums came out of the producing data gradient's epilogue (EPI_BNB) ------------
+// d is the ReLU-masked gradient; per (group, channel): k1 = sum(d) / M, k2 = invstd * sum(d * (y - mean)) / M (= mean of d * xhat);
+// dy = gamma * invstd * (d - k1 - xhat * k2), the statement of bn_bwd_apply_kernel.  The replicas are summed in a fixed order.
+__global__ void __launch_bounds__(256) bn_bwd_apply_e_kernel(const BnApplyEArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // k1[C], k2[C], scale[C], mean[C], invstd[C]
+    const int g = blockIdx.y, tid = threadIdx.x;
+    const double Md = (double)a.m_per_group;
+    for (int c = tid; c < a.C; c += 256) {
+        const float istd = a.invstd[(int64_t)g * a.C + c];
+        double s1 = 0.0, s2 = 0.0;
+        for (int r = 0; r < kStatReps; ++r) {
+            s1 += a.esums[r * a.esums_rep_stride + ((int64_t)g * 2 + 0) * a.C + c];
+            s2 += a.esums[r * a.esums_rep_stride + ((int64_t)g * 2 + 1) * a.C + c];
+        }
+        sm[c] = (float)(s1 / Md);
+        sm[a.C + c] = (float)(s2 * (double)istd / Md);
+        sm[2 * a.C + c] = a.gamma[c] * istd;
+        sm[3 * a.C + c] = a.mean[(int64_t)g * a.C + c];
+        sm[4 * a.C + c] = istd;
+        if (blockIdx.x == 0 && g == 0) {   // dgamma = sum over the groups of sum(d * xhat), dbeta = sum(d)
+            double dg = 0.0, db = 0.0;
+            for (int gg = 0; gg < a.G; ++gg) {
+                double t1 = 0.0, t2 = 0.0;
+                for (int r = 0; r < kStatReps; ++r) {
+                    t1 += a.esums[r * a.esums_rep_stride + ((int64_t)gg * 2 + 0) * a.C + c];
+                    t2 += a.esums[r * a.esums_rep_stride + ((int64_t)gg * 2 + 1) * a.C + c];
+                }
+                db += t1;
+                dg += t2 * (double)a.invstd[(int64_t)gg * a.C + c];
+            }
+            if (a.accumulate) {
+                a.dgamma[c] += (float)dg;
+                a.dbeta[c] += (float)db;
+            } else {
+                a.dgamma[c] = (float)dg;
+                a.dbeta[c] = (float)db;
+            }
+        }
+    }
+    __syncthreads();
+    const int C4 = a.C >> 2;
+    const int64_t units = a.m_per_group * C4;
+    const float4* d4 = (const float4*)a.d + (int64_t)g * units;
+    const float4* y4 = (const float4*)a.y + (int64_t)g * units;
+    float4* o4 = (float4*)a.dy + (int64_t)g * units;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    auto one = [&](int64_t u, const float4 d, const float4 y) __attribute__((always_inline)) {
+        const int c = (int)(u % C4) * 4;
+        float4 o;
+        o.x = sm[2 * a.C + c] * (d.x - sm[c] - (y.x - sm[3 * a.C + c]) * sm[4 * a.C + c] * sm[a.C + c]);
+        o.y = sm[2 * a.C + c + 1] * (d.y - sm[c + 1] - (y.y - sm[3 * a.C + c + 1]) * sm[4 * a.C + c + 1] * sm[a.C + c + 1]);
+        o.z = sm[2 * a.C + c + 2] * (d.z - sm[c + 2] - (y.z - sm[3 * a.C + c + 2]) * sm[4 * a.C + c + 2] * sm[a.C + c + 2]);
+        o.w = sm[2 * a.C + c + 3] * (d.w - sm[c + 3] - (y.w - sm[3 * a.C + c + 3]) * sm[4 * a.C + c + 3] * sm[a.C + c + 3]);
+        o4[u] = o;
+    };
+    int64_t u = (int64_t)blockIdx.x * 256 + tid;
+    for (; u + 3 * stride < units; u += 4 * stride) {   // four units in flight per thread
+        const float4 d0 = d4[u], d1 = d4[u + stride], d2 = d4[u + 2 * stride], d3 = d4[u + 3 * stride];
+        const float4 y0 = y4[u], y1 = y4[u + stride], y2 = y4[u + 2 * stride], y3 = y4[u + 3 * stride];
+        one(u, d0, y0); one(u + stride, d1, y1); one(u + 2 * stride, d2, y2); one(u + 3 * stride, d3, y3);
+    }
+    for (; u < units; u += stride) one(u, d4[u], y4[u]);
+}
+
+int launch_bn_apply_e(const BnApplyEArgs& a, hipStream_t s) {
+    OCL_REQUIRE(a.C % 4 == 0 && a.G >= 1 && a.m_per_group > 0, "bn_apply_e: C=%d G=%d", a.C, a.G);
+    const int64_t units = a.m_per_group * (a.C / 4);
+    const int bx = (int)std::max<int64_t>(1, std::min<int64_t>(1024 / a.G, (units + 1023) / 1024));
+    ProfScope ps(PROF_BN, s);
+    hipLaunchKernelGGL(bn_bwd_apply_e_kernel, dim3(bx, a.G), dim3(256), (size_t)5 * a.C * 4, s, a);
+    OCL_LAUNCH_CHECK();
+    return OCL_OK;
+}
+
 // =====================================================================================================
 // avg_pool2d(4) + flatten (C,ph,pw order), l2-normalise, misc
 // =====================================================================================================
@@ -3228,7 +3462,17 @@ int conv_kernels_init() {
     for (int nt = 1; nt <= 2; ++nt)
         for (int tr = 0; tr < 2; ++tr)
             OCL_HIP(hipFuncSetAttribute((const void*)convs_fn(nt, tr != 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
-    for (int st = 0; st < 2; ++st) {
+    // the EPI_BNB instantiations
+    for (int m = 1; m <= 5; ++m)
+        for (int pf = 4; pf <= 8; pf += 4) {
+            for (int n = 1; n <= 2; ++n)
+                for (int res = 0; res < 2; ++res)
+                    OCL_HIP(hipFuncSetAttribute((const void*)convt_fn(m, n, pf, res, 0, 0, 1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+            OCL_HIP(hipFuncSetAttribute((const void*)convt_fn(m, 1, pf, 0, 0, 1, 1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+        }
+    for (int nt = 1; nt <= 2; ++nt)
+        OCL_HIP(hipFuncSetAttribute((const void*)convs_fn(nt, false, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+    for (int st = 0; st < 3; ++st) {
         OCL_HIP(hipFuncSetAttribute((const void*)convq_fn(2, 4, st), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
         OCL_HIP(hipFuncSetAttribute((const void*)convq_fn(2, 12, st), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
         OCL_HIP(hipFuncSetAttribute((const void*)convq_fn(1, 12, st), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));

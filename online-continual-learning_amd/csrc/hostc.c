@@ -109,21 +109,23 @@ static PyObject* py_randperm_check(PyObject* self, PyObject* args) {
 typedef struct {
     long long token, version;
     Py_ssize_t n;
-    uint64_t content;   /* order-independent checksum of the set's elements (set_checksum) when the order was recorded */
+    uint64_t content;   /* checksum of the set's (element, table slot) pairs (set_checksum) when the order was recorded */
     int64_t* members;
 } ClassMemo;
 static ClassMemo g_memo[MEMO_LABELS];
 
 /* The memo is keyed on (dict token, per-label version, set size); versions are bumped only by update_cache.  Any other in-place
- * mutation of a class set (a test, a future plugin, a remove + add of equal size) is caught by comparing an order-independent
- * checksum of the live set's element hashes (one pass over the hash table: no set copy, no PyLong conversion). */
+ * mutation of a class set (a test, a future plugin, a remove + add of equal size) is caught by comparing a checksum of the live
+ * set's (element hash, hash-table slot) pairs (one pass over the hash table: no set copy, no PyLong conversion): it changes when
+ * the contents change AND when the same elements sit in other slots of the table, i.e. whenever the iteration order -- which is
+ * what the memo stores -- can differ. */
 static uint64_t set_checksum(PyObject* set) {
     Py_ssize_t pos = 0;
     PyObject* item;
     Py_hash_t h;
     uint64_t acc = 0;
     while (_PySet_NextEntry(set, &pos, &item, &h)) {
-        uint64_t x = (uint64_t)h * 0x9E3779B97F4A7C15ull;
+        uint64_t x = (uint64_t)h * 0x9E3779B97F4A7C15ull + (uint64_t)pos * 0xD6E8FEB86659FD93ull;   /* pos: one past the entry's slot */
         x ^= x >> 29;
         acc += x * 0xBF58476D1CE4E5B9ull;
     }

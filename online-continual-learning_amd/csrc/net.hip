@@ -50,6 +50,7 @@ struct PlanSet {
     std::vector<WgradPlan> wgrad;
     std::vector<int64_t> partial_off;           // per conv: its own slab region (batched reduction), floats
     bool batched_reduce = false;                // every layer's slabs fit the workspace side by side
+    std::vector<char> dgrad_bnb;                // per conv: its data-gradient plan follows the BatchNorm groups and has room for the EPI_BNB table
 };
 
 }  // namespace
@@ -350,6 +351,10 @@ static int get_plans(ocl_net* n, int N, int groups, PlanSet** out) {
     ps.fwd.resize(n->convs.size());
     ps.dgrad.resize(n->convs.size());
     ps.wgrad.resize(n->convs.size());
+    ps.dgrad_bnb.assign(n->convs.size(), 0);
+    // BatchNorm backward of bn1: its two batch sums in the epilogue of conv2's data gradient (EPI_BNB) + a streaming apply kernel instead
+    // of the one-pass kernel with its grid-wide arrival (OCL_BNB_EPI=0: the one-pass kernel).  The replicated arena holds <= 2 groups.
+    static const bool env_bnb = [] { const char* e = getenv("OCL_BNB_EPI"); return !(e && e[0] == '0'); }();
     for (size_t i = 0; i < n->convs.size(); ++i) {
         const ConvInfo& c = n->convs[i];
         ConvGeomDesc g;
@@ -362,7 +367,12 @@ static int get_plans(ocl_net* n, int N, int groups, PlanSet** out) {
             // stride-2 3x3: the four parity classes as one launch where conv_t_kernel can take them (OCL_DGRAD_MERGE=0: four launches)
             static const bool merge = [] { const char* e = getenv("OCL_DGRAD_MERGE"); return !(e && e[0] == '0'); }();
             std::vector<ConvGeomDesc> dg;
-            geom_dgrad(c, N, &dg, merge);
+            const bool bnb = env_bnb && c.xf_src >= 0 && c.stride == 1 && groups <= 2;   // conv2 of a block: its data gradient enters bn1's backward
+            geom_dgrad(c, N, &dg, merge, bnb ? groups : 1);
+            if (bnb && dg.size() == 1) {
+                dg[0].bnb = 1;
+                ps.dgrad_bnb[i] = 1;
+            }
             if (dg.size() == 1 && dg[0].ncls > 1) {
                 ConvPlan p;
                 if (plan_conv(dg[0], &p) != OCL_OK) geom_dgrad(c, N, &dg, false);
@@ -434,6 +444,13 @@ static const BnFoldDesc* fold_descs(const ocl_net* n) {
     return (const BnFoldDesc*)(n->ws + n->off_descs + align_up((int64_t)(n->convs.size() * sizeof(PackDesc)), 64));
 }
 
+// the BatchNorm whose backward starts in a data gradient's epilogue (ConvArgs::bnb_*, EPI_BNB)
+struct BnbEpi {
+    const float *y, *z, *mean, *invstd, *gamma, *beta;
+    double* sums;            // [kStatReps][G][2][C], replica stride rep_stride doubles, zeroed
+    int64_t rep_stride;
+};
+
 // the producer-side BatchNorm a convolution applies to its own input (ConvArgs::xf)
 struct XfBn {
     const double* stats;
@@ -444,11 +461,15 @@ struct XfBn {
 };
 
 static int run_conv(ocl_net* n, ConvPlan& cached, const float* in, const float* wT, float* out, int flags, double* stats,
-                    const float* scale, const float* shift, const float* res, const float* resmask, hipStream_t s, const XfBn* xf = nullptr) {
+                    const float* scale, const float* shift, const float* res, const float* resmask, hipStream_t s, const XfBn* xf = nullptr,
+                    const BnbEpi* be = nullptr) {
     if (!cached.a.blob) {   // first launch of this plan: its tables go to the device, on this stream, in front of the launch
         int rc = conv_plan_finalize(&cached, &n->plan_arena, s);
         if (rc != OCL_OK) return rc;
     }
+    // the tables were uploaded asynchronously on the stream of the plan's first launch: any other stream (the side stream's projection
+    // shortcuts, a different caller stream) orders itself behind that copy
+    if (cached.ready && s != cached.ready_stream) OCL_HIP(hipStreamWaitEvent(s, cached.ready, 0));
     ConvPlan p = cached;
     if (xf) {
         p.a.xf = 1;
@@ -470,6 +491,17 @@ static int run_conv(ocl_net* n, ConvPlan& cached, const float* in, const float* 
     p.a.shift = shift;
     p.a.res = res;
     p.a.resmask = resmask;
+    if (be) {
+        if (p.a.bnb_lds < 0) {
+            set_error("run_conv: plan has no room for the BatchNorm-backward epilogue");
+            return OCL_ERR_STATE;
+        }
+        p.a.flags |= EPI_BNB;
+        p.a.stats = be->sums;
+        p.a.stat_rep_stride = be->rep_stride;
+        p.a.bnb_y = be->y; p.a.bnb_z = be->z;
+        p.a.bnb_mean = be->mean; p.a.bnb_invstd = be->invstd; p.a.bnb_gamma = be->gamma; p.a.bnb_beta = be->beta;
+    }
     return launch_conv(p, s);
 }
 
@@ -726,9 +758,28 @@ extern "C" {
 
 int ocl_net_forward(ocl_net* n, const float* x, int N, int groups, uint32_t flags, const float* params_override, float* feat_out,
                     float* out, int slot, void* stream) {
+    OCL_REQUIRE(x, "net_forward: null input");
+    const float* xs[1] = {x};
+    const int32_t ns[1] = {N};
+    return ocl_net_forward_segments(n, xs, ns, 1, groups, flags, params_override, feat_out, out, slot, stream);
+}
+
+int ocl_net_forward_segments(ocl_net* n, const float* const* xs, const int32_t* ns, int nseg, int groups, uint32_t flags,
+                             const float* params_override, float* feat_out, float* out, int slot, void* stream) {
     OCL_REQUIRE(n && n->bound, "net_forward: net not bound");
     if (int arc = check_async_error("net_forward")) return arc;
-    OCL_REQUIRE(x && N > 0 && N <= n->d.max_batch, "net_forward: n=%d (max_batch %d)", N, n->d.max_batch);
+    OCL_REQUIRE(xs && ns && nseg >= 1 && nseg <= kMaxInputSegments, "net_forward: %d input segments (1 .. %d)", nseg, kMaxInputSegments);
+    InputSegments sg;
+    memset(&sg, 0, sizeof(sg));
+    int N = 0;
+    for (int i = 0; i < nseg; ++i) {
+        OCL_REQUIRE(xs[i] && ns[i] > 0, "net_forward: segment %d is empty", i);
+        sg.x[i] = xs[i];
+        sg.first[i] = N;
+        N += ns[i];
+    }
+    sg.n = nseg;
+    OCL_REQUIRE(N > 0 && N <= n->d.max_batch, "net_forward: n=%d (max_batch %d)", N, n->d.max_batch);
     OCL_REQUIRE(groups >= 1 && groups <= kGmax && N % groups == 0, "net_forward: groups=%d must divide n=%d (<= %d)", groups, N, kGmax);
     OCL_REQUIRE(slot >= 0 && slot < n->d.n_slots, "net_forward: slot %d", slot);
     hipStream_t s = (hipStream_t)stream;
@@ -746,7 +797,8 @@ int ocl_net_forward(ocl_net* n, const float* x, int N, int groups, uint32_t flag
     // Eval-mode passes have no cross-image terms (folded BatchNorm): their plans are made for the batch rounded up to 16 images (the
     // extra images are whatever the activation buffers hold; nothing reads their outputs), so the evaluation sets of the ASER update,
     // whose size changes from step to step, share a handful of plan sets instead of planning a new one almost every step.
-    const int Nplan = train ? N : std::min(n->d.max_batch, (N + 15) / 16 * 16);
+    // (buckets of 4 up to 16 images: a 1 - 4 image pass is not padded to 16x its work)
+    const int Nplan = train ? N : std::min(n->d.max_batch, N <= 16 ? (N + 3) / 4 * 4 : (N + 15) / 16 * 16);
     int rc = get_plans(n, Nplan, train ? groups : 1, &ps);
     if (rc != OCL_OK) return rc;
     float* pack = (float*)(n->ws + n->off_pack);
@@ -765,7 +817,7 @@ int ocl_net_forward(ocl_net* n, const float* x, int N, int groups, uint32_t flag
 
     float* S = n->slotf(slot);
     float* x4 = S + n->x4_off;
-    rc = launch_nchw3_to_nhwc4(x, x4, N, n->d.in_h, n->d.in_w, s);
+    rc = launch_nchw3_to_nhwc4_segments(sg, x4, N, n->d.in_h, n->d.in_w, s);
     if (rc != OCL_OK) return rc;
     n->slot_valid[slot] = false;
 
@@ -951,14 +1003,48 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
         }
         return launch_wgrad_reduce(wp, GT(n->convs[conv_i].w_t), accumulate, sw);
     };
-    auto dgrad = [&](int conv_i, const float* dy, float* dx, const float* res, const float* resmask, int extra_flags) -> int {
+    auto dgrad = [&](int conv_i, const float* dy, float* dx, const float* res, const float* resmask, int extra_flags,
+                     const BnbEpi* be = nullptr) -> int {
         const ConvInfo& c = n->convs[conv_i];
         for (auto& p : ps->dgrad[conv_i]) {
             int fl = extra_flags | (res ? (resmask ? EPI_RESMASK : EPI_RES) : 0);
-            int r = run_conv(n, p, dy, pack + c.td_off, dx, fl, nullptr, nullptr, nullptr, res, resmask, s);
+            int r = run_conv(n, p, dy, pack + c.td_off, dx, fl, nullptr, nullptr, nullptr, res, resmask, s, nullptr, be);
             if (r) return r;
         }
         return OCL_OK;
+    };
+    // BatchNorm `bn_conv`'s backward with the reduction half in the epilogue of the data gradient that produces d (EPI_BNB): the
+    // descriptor for that launch, and the apply launch that follows it
+    auto bnb_desc = [&](int bn_conv, const float* zmask) -> BnbEpi {
+        const ConvInfo& c = n->convs[bn_conv];
+        const BnInfo& b = n->bns[c.bn];
+        BnbEpi e;
+        e.y = at(c.y_off, c);
+        e.z = zmask;
+        e.mean = S + b.save_off;
+        e.invstd = S + b.save_off + (int64_t)kGmax * b.C;
+        e.gamma = T(b.gamma_t);
+        e.beta = T(b.beta_t);
+        e.sums = bsums + b.fused_off;
+        e.rep_stride = (int64_t)G * 2 * b.C;
+        return e;
+    };
+    auto bn_apply_e = [&](int bn_conv, const float* d, float* dy) -> int {
+        const ConvInfo& c = n->convs[bn_conv];
+        const BnInfo& b = n->bns[c.bn];
+        BnApplyEArgs a;
+        memset(&a, 0, sizeof(a));
+        a.d = d; a.y = at(c.y_off, c); a.dy = dy;
+        a.mean = S + b.save_off;
+        a.invstd = S + b.save_off + (int64_t)kGmax * b.C;
+        a.gamma = T(b.gamma_t);
+        a.dgamma = GT(b.gamma_t);
+        a.dbeta = GT(b.beta_t);
+        a.esums = bsums + b.fused_off;
+        a.esums_rep_stride = (int64_t)G * 2 * b.C;
+        a.m_per_group = (int64_t)(Nc / G) * c.Ho * c.Wo;
+        a.G = G; a.C = b.C; a.accumulate = accumulate;
+        return launch_bn_apply_e(a, s);
     };
 
     auto stop_here = [&](int bi, int step) -> bool {
@@ -988,11 +1074,18 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
         }
         if ((rc = fused ? wgrad(b.conv2, at(c1.y_off, c1), gB, b.conv1) : wgrad(b.conv2, a1, gB))) return rc;
         if ((rc = release(rB))) return rc;
-        if ((rc = dgrad(b.conv2, gB, gD, nullptr, nullptr, 0))) return rc;   // gD = dL/da1 (pre-mask)
+        // bn1's backward: its batch sums come out of conv2's data gradient (gD = the MASKED dL/da1), a streaming kernel applies them;
+        // otherwise (plan without the epilogue table, eval-mode tape, > 2 groups) the one-pass kernel on the unmasked gD
+        const bool epi1 = ps->dgrad_bnb[b.conv2] && !frozen && G <= 2 && n->dbg_stop < 0;
+        BnbEpi be1;
+        if (epi1) be1 = bnb_desc(b.conv1, fused ? nullptr : a1);
+        if ((rc = dgrad(b.conv2, gB, gD, nullptr, nullptr, 0, epi1 ? &be1 : nullptr))) return rc;   // gD = dL/da1 (pre-mask; masked with EPI_BNB)
         if (stop_here(bi, 2)) return OCL_OK;
         int rB1;
         float* gB1 = take_dy(&rB1);
-        if ((rc = bn_bwd(gD, fused ? nullptr : a1, b.conv1, gB1, -1, nullptr, fused))) return rc;     // gB1 = dL/dy1
+        if (epi1) {
+            if ((rc = bn_apply_e(b.conv1, gD, gB1))) return rc;                                       // gB1 = dL/dy1
+        } else if ((rc = bn_bwd(gD, fused ? nullptr : a1, b.conv1, gB1, -1, nullptr, fused))) return rc;
         gB = gB1;
         if (stop_here(bi, 3)) return OCL_OK;
         if ((rc = publish())) return rc;
@@ -1023,6 +1116,10 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
         wp.a.dy = gS;
         wp.a.partial = partial + (int64_t)(16ll << 20) / 4;
         if ((int64_t)(16ll << 20) / 4 + (int64_t)wp.partial_floats > n->partial_floats) wp.a.partial = nullptr;   // (workspace too small: after the join)
+        // the side stream's slabs start at `partial`: the stem's region is only free beside them while every other layer's slabs end
+        // below it (plan_wgrad caps a split at 12 MB, but a single slab of a wider net may exceed that)
+        for (size_t i = 1; i < ps->wgrad.size(); ++i)
+            if ((int64_t)ps->wgrad[i].partial_floats * 4 > (16ll << 20)) wp.a.partial = nullptr;
         if (wp.a.partial) {
             if ((rc = launch_wgrad(wp, s))) return rc;
             if ((rc = launch_wgrad_reduce(wp, GT(n->convs[0].w_t), accumulate, s))) return rc;

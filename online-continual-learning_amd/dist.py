@@ -26,6 +26,9 @@ def init_from_env(backend=None):
         if backend is None:
             backend = os.environ.get("OCL_DIST_BACKEND") or ("nccl" if n_dev > 0 and not shared else "gloo")
         if backend == "nccl":
+            if shared:
+                raise RuntimeError("backend nccl (RCCL) needs one GPU per local rank: %d local ranks on %d device(s); use gloo "
+                                   "(the default when ranks share a GPU)" % (local_world, n_dev))
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, init_method="env://", rank=rank, world_size=world)
     return rank, world, (local % n_dev if shared else local)

@@ -67,6 +67,7 @@ SIGNATURES = {
     "ocl_net_workspace_bytes": (i64, [vp]),
     "ocl_net_bind": (C.c_int, [vp, vp, vp, vp, vp, vp, i64]),
     "ocl_net_forward": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_uint32, vp, vp, vp, C.c_int, vp]),
+    "ocl_net_forward_segments": (C.c_int, [vp, C.POINTER(vp), C.POINTER(i32), C.c_int, C.c_int, C.c_uint32, vp, vp, vp, C.c_int, vp]),
     "ocl_net_backward": (C.c_int, [vp, C.c_int, vp, C.c_int, vp]),
     "ocl_net_debug_stop": (C.c_int, [vp, C.c_int]),
     "ocl_net_debug_copy": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, i64, C.POINTER(i64), vp]),

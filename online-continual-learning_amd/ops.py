@@ -283,14 +283,18 @@ def scr_augment(x, params):
     return out
 
 
-def scr_augment_uniform(x, u, cfg12, want_params=False):
-    """Augmented view from raw uniform draws u [n, AUG_NUNIFORM] (device): parameter arithmetic and the image kernel in one call."""
+def scr_augment_uniform(x, u, cfg12, want_params=False, out=None):
+    """Augmented view from raw uniform draws u [n, AUG_NUNIFORM] (device): parameter arithmetic and the image kernel in one call.
+    out: a contiguous [n,3,h,w] tensor (or row slice of one) to write into."""
     ffi.init()
     x, u = _f32(x), _f32(u)
     n, c, h, w = x.shape
     if c != 3 or u.shape != (n, AUG_NUNIFORM) or len(cfg12) != 12:
         raise RuntimeError("scr_augment_uniform: x must be [n,3,h,w], u [n,%d], cfg 12 floats" % AUG_NUNIFORM)
-    out = torch.empty_like(x)
+    if out is None:
+        out = torch.empty_like(x)
+    elif out.shape != x.shape or out.dtype != torch.float32 or not out.is_contiguous():
+        raise RuntimeError("scr_augment_uniform: out must be a contiguous float32 tensor of x's shape")
     params = torch.empty((n, AUG_NPARAM), dtype=torch.float32, device=x.device)
     cfg = (ffi.C.c_double * 12)(*[float(v) for v in cfg12])
     ffi.check(ffi.lib().ocl_scr_augment_uniform(ffi.ptr(x), ffi.ptr(out), n, h, w, ffi.ptr(u), cfg, ffi.ptr(params), ffi.stream()),

@@ -67,7 +67,7 @@ class ASER_update(object):
         n_mem, n_cur = mem_x.size(0), cur_x.size(0)
 
         trace = debug.on()
-        values = compute_knn_sv(buffer.model, torch.cat((eval_x, minor_x)), torch.cat((eval_y, minor_y)), torch.cat((mem_x, cur_x)),
+        values = compute_knn_sv(buffer.model, (eval_x, minor_x), torch.cat((eval_y, minor_y)), (mem_x, cur_x),
                                 torch.cat((mem_y, cur_y)), self.k, device=self.device, want_order=trace)
         knn_order = None
         if trace:

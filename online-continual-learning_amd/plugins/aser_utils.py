@@ -10,13 +10,16 @@ from .buffer_utils import ClassBalancedRandomSampling, _host_labels
 
 def deep_features(model, eval_x, n_eval, cand_x, n_cand):
     """aser_utils.py:64-91."""
+    # eval_x / cand_x may each be a tensor or a sequence of tensors (the pieces of the reference's torch.cat calls, e.g. class-balanced
+    # memory samples + minority batch items): the engine reads the pieces where they are, nothing is concatenated
+    def pieces(t):
+        return [maybe_cuda(p) for p in (t if isinstance(t, (list, tuple)) else (t,))]
     if cand_x is None:
         num = n_eval
-        total_x = eval_x
+        total_x = pieces(eval_x)
     else:
         num = n_eval + n_cand
-        total_x = torch.cat((eval_x, cand_x), 0)
-    total_x = maybe_cuda(total_x)
+        total_x = pieces(eval_x) + pieces(cand_x)
     deep_features_ = mini_batch_deep_features(model, total_x, num)
     eval_df = deep_features_[0:n_eval]
     cand_df = deep_features_[n_eval:]
@@ -26,8 +29,10 @@ def deep_features(model, eval_x, n_eval, cand_x, n_cand):
 def compute_knn_sv(model, eval_x, eval_y, cand_x, cand_y, k, device="cpu", want_order=False):
     """aser_utils.py:7-61: KNN Shapley value matrix [n_eval, n_cand] of candidates w.r.t. evaluation data.
     want_order (parity tests): also return the per-row ascending-distance candidate order the kernel used."""
-    n_eval = eval_x.size(0)
-    n_cand = cand_x.size(0)
+    def rows(t):
+        return sum(p.size(0) for p in t) if isinstance(t, (list, tuple)) else t.size(0)
+    n_eval = rows(eval_x)
+    n_cand = rows(cand_x)
     eval_df, cand_df = deep_features(model, eval_x, n_eval, cand_x, n_cand)
     return ops.knn_sv(eval_df.contiguous(), eval_y, cand_df.contiguous(), cand_y, k, want_order=want_order)
 
@@ -37,8 +42,7 @@ def compute_knn_sv_pair(model, eval_a_x, eval_a_y, eval_b_x, eval_b_y, cand_x, c
     with ONE eval-mode feature pass over eval_a + eval_b + candidates: eval-mode features are per-sample, so the candidates'
     features (computed twice by the reference) are the same in both calls."""
     na, nb, nc = eval_a_x.size(0), eval_b_x.size(0), cand_x.size(0)
-    total_x = maybe_cuda(torch.cat((eval_a_x, eval_b_x, cand_x), 0))
-    f = mini_batch_deep_features(model, total_x, na + nb + nc)
+    f = mini_batch_deep_features(model, [maybe_cuda(eval_a_x), maybe_cuda(eval_b_x), maybe_cuda(cand_x)], na + nb + nc)
     fa, fb, fc = f[0:na].contiguous(), f[na:na + nb].contiguous(), f[na + nb:].contiguous()
     return (ops.knn_sv(fa, eval_a_y, fc, cand_y, k, want_order=want_order),
             ops.knn_sv(fb, eval_b_y, fc, cand_y, k, want_order=want_order))

@@ -175,7 +175,8 @@ class ClassBalancedRandomSampling:
     @classmethod
     def invalidate(cls):
         """Forget the C helper's memoised iteration orders (call after mutating a class set other than through update_cache; the
-        helper also compares a checksum of every set's elements, so this is belt and braces)."""
+        helper also compares a checksum of every set's (element, hash-table slot) pairs -- contents and layout, hence iteration
+        order -- so this is belt and braces)."""
         cls._tracked = None
 
     @classmethod

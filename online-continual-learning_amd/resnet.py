@@ -204,9 +204,21 @@ class _EngineMixin:
             raise RuntimeError("expected a float32 [n,3,H,W] tensor on the GPU, got %s %s on %s" % (x.dtype, tuple(x.shape), x.device))
         if x.shape[2] != self._desc.in_h or x.shape[3] != self._desc.in_w:
             raise RuntimeError("engine built for %dx%d inputs, got %dx%d" % (self._desc.in_h, self._desc.in_w, x.shape[2], x.shape[3]))
-        if x.shape[0] > self._desc.max_batch:
-            raise RuntimeError("batch %d exceeds the engine's max_batch %d" % (x.shape[0], self._desc.max_batch))
         return x.contiguous()
+
+    def _segments(self, x):
+        """x: one [n,3,H,W] tensor or a sequence of them (the pieces of a batch the reference would torch.cat: memory rows, stream batch,
+        augmented views).  Returns (tensors kept alive, total n, pointer array, size array) for ocl_net_forward_segments: the engine's
+        layout conversion reads the pieces where they are, no concatenated copy is made."""
+        parts = [self._check_input(t) for t in (x if isinstance(x, (list, tuple)) else (x,)) if t.shape[0] > 0]
+        if not parts or len(parts) > 8:
+            raise RuntimeError("forward: 1 .. 8 non-empty input tensors, got %d" % len(parts))
+        n = sum(t.shape[0] for t in parts)
+        if n > self._desc.max_batch:
+            raise RuntimeError("batch %d exceeds the engine's max_batch %d" % (n, self._desc.max_batch))
+        ptrs = (ffi.vp * len(parts))(*[t.data_ptr() for t in parts])
+        sizes = (ffi.i32 * len(parts))(*[t.shape[0] for t in parts])
+        return parts, n, ptrs, sizes
 
     def _tape_slot(self):
         """Next activation tape (round robin over the model's n_slots); a generation counter detects overwritten tapes."""
@@ -218,30 +230,30 @@ class _EngineMixin:
 
     def _engine_train_forward(self, x, groups, save, params_override=None, update_running=True, want_feat=False, frozen=False):
         self._ensure_bound()
-        x = self._check_input(x)
-        n = x.shape[0]
+        parts, n, ptrs, sizes = self._segments(x)
+        dev = parts[0].device
         # forwards that keep no tape (MIR's scoring passes, the KD teacher, no_grad passes) run in a scratch slot of their own, so
         # that any number of them may sit between a taped forward and its backward
         slot, gen = self._tape_slot() if save else (self._n_tapes, 0)
-        out = torch.empty((n, self.out_dim), dtype=torch.float32, device=x.device)
-        feat = torch.empty((n, self.feature_dim), dtype=torch.float32, device=x.device) if want_feat else None
+        out = torch.empty((n, self.out_dim), dtype=torch.float32, device=dev)
+        feat = torch.empty((n, self.feature_dim), dtype=torch.float32, device=dev) if want_feat else None
         flags = ffi.FWD_TRAIN | (ffi.FWD_SAVE_TAPE if save else 0) | (ffi.FWD_UPDATE_RUNNING if update_running else 0)
         if frozen:   # model.eval() under autograd: running statistics, activations kept for backward
             flags = ffi.FWD_SAVE_TAPE | ffi.FWD_FROZEN_BN
-        ffi.check(ffi.lib().ocl_net_forward(self._net, ffi.ptr(x), n, groups, flags, ffi.ptr(params_override), ffi.ptr(feat),
-                                            ffi.ptr(out), slot, ffi.stream()), "net_forward(train)")
+        ffi.check(ffi.lib().ocl_net_forward_segments(self._net, ptrs, sizes, len(parts), groups, flags, ffi.ptr(params_override), ffi.ptr(feat),
+                                                     ffi.ptr(out), slot, ffi.stream()), "net_forward(train)")
         if want_feat:
             return out, feat
         return out, slot, gen
 
     def _engine_eval_forward(self, x, want_out=True, want_feat=False, params_override=None):
         self._ensure_bound()
-        x = self._check_input(x)
-        n = x.shape[0]
-        out = torch.empty((n, self.out_dim), dtype=torch.float32, device=x.device) if want_out else None
-        feat = torch.empty((n, self.feature_dim), dtype=torch.float32, device=x.device) if want_feat else None
-        ffi.check(ffi.lib().ocl_net_forward(self._net, ffi.ptr(x), n, 1, 0, ffi.ptr(params_override), ffi.ptr(feat), ffi.ptr(out),
-                                            self._n_tapes, ffi.stream()), "net_forward(eval)")
+        parts, n, ptrs, sizes = self._segments(x)
+        dev = parts[0].device
+        out = torch.empty((n, self.out_dim), dtype=torch.float32, device=dev) if want_out else None
+        feat = torch.empty((n, self.feature_dim), dtype=torch.float32, device=dev) if want_feat else None
+        ffi.check(ffi.lib().ocl_net_forward_segments(self._net, ptrs, sizes, len(parts), 1, 0, ffi.ptr(params_override), ffi.ptr(feat),
+                                                     ffi.ptr(out), self._n_tapes, ffi.stream()), "net_forward(eval)")
         return out, feat
 
     def _engine_backward(self, slot, gen, dout):
@@ -273,9 +285,16 @@ class _EngineMixin:
     def forward_views(self, views):
         """SCR: the reference calls model.forward once per view (agents/scr.py:55), i.e. BatchNorm statistics are
         per view.  Here all views run as ONE batched pass with per-group statistics; returns [n_views*bsz, out]
-        view-major."""
-        x = torch.cat(list(views), dim=0)
-        return self._forward_out(x, groups=len(views))
+        view-major.  A view may itself be a sequence of tensors (memory rows, stream batch): the pieces are read where they are
+        (ocl_net_forward_segments), nothing is concatenated."""
+        parts, sizes = [], []
+        for v in views:
+            vs = list(v) if isinstance(v, (list, tuple)) else [v]
+            parts += vs
+            sizes.append(sum(t.shape[0] for t in vs))
+        if len(set(sizes)) != 1:
+            raise RuntimeError("forward_views: the views must hold the same number of images, got %s" % sizes)
+        return self._forward_out(tuple(parts), groups=len(views))
 
     def forward_with_params(self, x, flat_params):
         """no-grad forward of a virtual model (MIR's theta - lr*grad, mir_retrieve.py:21,25) in the current mode,
@@ -300,9 +319,15 @@ class _EngineMixin:
 
     def features_batched(self, x, chunk=None):
         """features() over an arbitrarily large batch in engine-sized chunks (eval-mode BN is per-sample, so
-        chunking does not change results: mini_batch_deep_features uses 64, evaluate() uses 1)."""
+        chunking does not change results: mini_batch_deep_features uses 64, evaluate() uses 1).  x may be a sequence of tensors
+        (the pieces of the reference's torch.cat((eval_x, cand_x)), utils/buffer/aser_utils.py:73) when they fit one pass."""
         self._ensure_bound()
         chunk = chunk or self._desc.max_batch
+        if isinstance(x, (list, tuple)):
+            x = [t for t in x if t.shape[0] > 0]
+            if sum(t.shape[0] for t in x) <= chunk and 1 <= len(x) <= 8:
+                return self._features(tuple(x))
+            x = torch.cat(list(x), 0)
         outs = [self._features(x[i:i + chunk]) for i in range(0, x.shape[0], chunk)]
         return outs[0] if len(outs) == 1 else torch.cat(outs, 0)
 

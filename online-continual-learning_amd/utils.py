@@ -52,7 +52,9 @@ def mini_batch_deep_features(model, total_x, num):
         is_train = True
         model.eval()
     with torch.no_grad():
-        feats = model.features_batched(total_x[:num]).reshape((num, -1))
+        # total_x: a tensor, or the pieces the reference concatenates (read where they are: ocl_net_forward_segments)
+        src = total_x if isinstance(total_x, (list, tuple)) else total_x[:num]
+        feats = model.features_batched(src).reshape((num, -1))
     if is_train:
         model.train()
     return feats

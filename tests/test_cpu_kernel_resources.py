@@ -14,12 +14,14 @@ SRC = ROOT + "/online-continual-learning_amd/csrc/conv.hip"
 
 # the kernels a training / eval step launches (templates: the instantiations the planner picks at the BASELINE sizes)
 HOT = [
-    r"conv_s_kernel<1, false>", r"conv_s_kernel<2, false>",
-    r"conv_q_kernel<2, 4, (true|false)>", r"conv_q_kernel<2, 12, (true|false)>", r"conv_q_kernel<1, 12, (true|false)>",
-    r"conv_t_kernel<3, 1, 8, true, false, false>", r"conv_t_kernel<5, 1, 8, false, false, true>", r"conv_t_kernel<3, 1, 8, false, false, true>",
-    r"conv_t_kernel<1, 1, 8, (true|false), (true|false), (true|false)>", r"conv_t_kernel<2, 1, 4, true, (true|false), false>",
+    r"conv_s_kernel<1, false, (true|false)>", r"conv_s_kernel<2, false, (true|false)>",
+    r"conv_q_kernel<2, 4, [012]>", r"conv_q_kernel<2, 12, [012]>", r"conv_q_kernel<1, 12, [012]>",
+    r"conv_t_kernel<3, 1, 8, true, false, false, (true|false)>", r"conv_t_kernel<5, 1, 8, false, false, true, (true|false)>",
+    r"conv_t_kernel<3, 1, 8, false, false, true, (true|false)>",
+    r"conv_t_kernel<1, 1, 8, (true|false), (true|false), (true|false), false>", r"conv_t_kernel<2, 1, 4, true, (true|false), false, false>",
+    r"conv_t_kernel<1, 1, 8, true, false, false, true>", r"conv_t_kernel<2, 1, 4, true, false, false, true>",   # the EPI_BNB data gradients of a replay-sized pass
     r"conv_wgrad_kernel<2, 3, 8>", r"conv_wgrad_kernel<3, 2, 8>", r"conv_wgrad_kernel<1, 3, 8>", r"conv_wgrad_kernel<1, 2, 8>", r"conv_wgrad_kernel<1, 2, 4>",
-    r"bn_fwd_kernel", r"bn_bwd_fused_kernel<\d+, \d>", r"wgrad_reduce_kernel", r"wgrad_reduce_multi_kernel",
+    r"bn_fwd_kernel", r"bn_bwd_fused_kernel<\d+, \d>", r"bn_bwd_apply_e_kernel", r"wgrad_reduce_kernel", r"wgrad_reduce_multi_kernel",
 ]
 
 

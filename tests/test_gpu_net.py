@@ -268,6 +268,28 @@ def test_eval_forward_one_large_batch_with_rounded_plans(cuda):
     assert np.array_equal(f2, f[:146])
 
 
+def test_eval_padding_images_do_not_leak_into_the_real_rows(cuda):
+    """Eval-mode plans are made for the batch rounded up (4 images up to 16, 16 above: net.hip): the padding images are computed from
+    whatever the activation buffers hold.  Seed those buffers with NaN (a 16-image pass of NaN inputs), then run 1, 3, 5, 10 and 17
+    images: every feature of the real rows must be finite and equal, bit for bit, to the same rows out of an engine that never saw a
+    NaN -- no cross-image term may reach from the padding into a real image."""
+    rng = np.random.default_rng(8)
+    x = rng.random((17, 3, 32, 32)).astype(np.float32)
+    clean, _ = build("ER", "cifar100", "mlp", cuda=cuda, max_batch=64)
+    dirty, _ = build("ER", "cifar100", "mlp", cuda=cuda, max_batch=64)
+    clean.eval(); dirty.eval()
+    xd = torch.from_numpy(x).to(cuda)
+    nan16 = torch.full((16, 3, 32, 32), float("nan"), device=cuda)
+    nan32 = torch.full((32, 3, 32, 32), float("nan"), device=cuda)
+    with torch.no_grad():
+        for n in (1, 3, 5, 10, 17):
+            dirty.features_batched(nan32 if n > 16 else nan16)
+            got = dirty.features_batched(xd[:n]).cpu().numpy()
+            ref = clean.features_batched(xd[:n]).cpu().numpy()
+            assert np.isfinite(got).all(), n
+            assert np.array_equal(got, ref), n
+
+
 def test_virtual_params_forward_does_not_touch_model(cuda):
     """MIR's theta - lr*grad forward (mir_retrieve.py:21,25) through params_override."""
     m, sd = build("ER", "cifar100", cuda=cuda)

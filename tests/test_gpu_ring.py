@@ -128,3 +128,17 @@ def test_conv_s_kernel_matches_conv_t_kernel_on_the_whole_network(tmp_path):
         assert max(fwd.values()) < 2e-4, max(fwd.items(), key=lambda kv: kv[1])
         # (a flip also reaches every tensor upstream of it: one flipped case = up to 60 tensors)
         assert med < 1e-5 and n_off <= 0.25 * len(grad) and worst[1] < 0.1, worst
+
+
+def test_bn_backward_sums_in_the_dgrad_epilogue_match_the_one_pass_kernel(tmp_path):
+    """EPI_BNB: bn1's backward as [batch sums in the epilogue of conv2's data gradient] + [streaming apply kernel] against
+    the one-pass kernel (OCL_BNB_EPI=0) on the whole network.  The forward is the same code on both sides (same activation pattern), so
+    every gradient must agree to fp32 round-off: only the summation order of the two batch sums differs."""
+    import numpy as np
+    ref = _run_s(tmp_path, "bnb0", OCL_BNB_EPI="0")
+    got = _run_s(tmp_path, "bnb1", OCL_BNB_EPI="1")
+    assert got.keys() == ref.keys() and len(ref) > 100
+    errs = {k: float(np.abs(got[k] - ref[k]).max() / (1e-12 + np.abs(ref[k]).max())) for k in ref}
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    print("bnb epilogue vs one-pass kernel: worst", worst, "median %.2e" % float(np.median(list(errs.values()))))
+    assert worst[1] < 2e-5, worst
