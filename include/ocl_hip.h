@@ -249,7 +249,9 @@ int ocl_net_debug_copy(ocl_net* net, int slot, int what, int index, float* dst, 
 /* ---- kernel-level entry points (single layers; tests and micro-benchmarks) ------------------------------
  * BatchNorm2d backward (train mode) fused with the ReLU mask that follows it: dpre = dz * (zmask > 0) (zmask NULL =
  * no ReLU); dy = gamma*invstd*(dpre - mean(dpre) - xhat*mean(dpre*xhat)); dgamma = sum(dpre*xhat), dbeta = sum(dpre).
- * Tensors are NHWC [groups*m_per_group, c]; mean/invstd are [groups, c]. scratch: groups*2*c doubles. */
+ * Tensors are NHWC [groups*m_per_group, c]; mean/invstd are [groups, c]. scratch: groups*2*c accumulator cells of 16 bytes
+ * (= groups*4*c doubles, 16-byte aligned): the batch sums are accumulated as integers, independent of the order in which the
+ * workgroups finish. */
 int ocl_bn_bwd_nhwc(const float* dz, const float* zmask, const float* y, const float* mean, const float* invstd,
                     const float* gamma, int64_t m_per_group, int groups, int c, float* dy, float* dgamma,
                     float* dbeta, int accumulate, double* scratch, void* stream);

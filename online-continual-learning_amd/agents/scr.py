@@ -111,6 +111,8 @@ class ScrAugment(object):
         return out
 
     def __call__(self, x):
+        if isinstance(x, (tuple, list)):   # the pieces of a batch: one draw, one output tensor, no concatenated input
+            return self.apply_parts(x)
         # the draws on the host generator (one call, as before); everything derived from them on the device: the ~40 small CPU
         # tensor ops of params_from_uniform cost 0.25 ms of host time per step
         u = ops.upload(self.draw(x.shape[0]), x.device)
@@ -180,17 +182,18 @@ class SupContrastReplay(ContinualLearner):
                             combined_labels = torch.cat((mem_y, batch_y))
                             if isinstance(self.transform, ScrAugment) and not debug.on():
                                 # torch.cat((mem_x, batch_x)) is not materialised: the augmentation and the engine's layout conversion
-                                # read the two pieces where they are
+                                # read the two pieces where they are (ScrAugment takes the pieces as a tuple)
                                 first_view = (mem_x, batch_x)
-                                combined_batch_aug = self.transform.apply_parts(first_view)
+                                aug = self.transform(first_view)
                             else:
                                 first_view = (torch.cat((mem_x, batch_x)),)
-                                combined_batch_aug = self.transform(first_view[0])
+                                aug = self.transform(first_view[0])
+                            second_view = tuple(aug) if isinstance(aug, (tuple, list)) else (aug,)
                         if overlap:
                             main.wait_stream(ds)
-                            for t in first_view + (combined_batch_aug, combined_labels):
+                            for t in first_view + second_view + (combined_labels,):
                                 t.record_stream(main)   # allocated on the data stream, consumed on the main one
-                        features = self.model.forward_views([first_view, combined_batch_aug])
+                        features = self.model.forward_views([first_view, second_view])
                         loss = self.criterion_views(features, combined_labels, 2)
                         if self.verbose:
                             losses.update(loss, batch_y.size(0))

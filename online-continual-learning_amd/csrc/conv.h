@@ -9,6 +9,17 @@ namespace ocl {
 
 constexpr int kStatReps = 8;   // replicas of the BatchNorm statistic accumulators (atomics contention)
 
+// One batch-sum accumulator.  Workgroups add their partial sums with atomics in whatever order they finish; a floating-point
+// accumulator would make the sum -- and with it the normalised activations, the gradients and the stepped weights -- depend on that
+// order in the last bit.  The partial sums are therefore converted to 2^-40 fixed point and added as INTEGERS (two 64-bit words: the
+// low 32 bits of the fixed-point value and the rest), which is associative: the totals, and everything downstream, are bit-identical
+// from run to run (tests/test_gpu_parity2.py::test_training_steps_are_bit_reproducible).  Resolution 2^-40 (9e-13) absolute per
+// partial sum, range |sum| < 2^47; a non-finite partial sum poisons the cell (reads back as NaN).
+struct StatCell {
+    unsigned long long lo;   // sum of the low 32 bits of the addends' fixed-point values
+    long long hi;            // sum of the remaining bits (floor(v * 2^8))
+};
+
 enum ConvEpi : int {
     EPI_STORE = 0,       // out = acc
     EPI_STATS = 1,       // + per-(group,channel) sum / sum-of-squares into `stats` (fp64 atomics)
@@ -27,7 +38,7 @@ struct ConvArgs {
     const float* shift;
     const float* res;
     const float* resmask;
-    double* stats;        // [kStatReps][groups][2][Cout], replica stride stat_rep_stride doubles
+    StatCell* stats;      // [kStatReps][groups][2][Cout], replica stride stat_rep_stride cells
     int64_t stat_rep_stride;
     int N, Hin, Win, Cin;
     int Hout, Wout, Cout;
@@ -64,7 +75,7 @@ struct ConvArgs {
     int xf;
     int patch_floats;           // LDS floats of the patch area (the transform table follows it)
     int qstat_off;              // conv_q_kernel: byte offset of its statistics scratch in LDS ([4 waves][4 rows + 1][2 * 20] floats)
-    const double* xf_stats;     // producer's statistics [kStatReps][groups][2][Cin], replica stride xf_rep_stride doubles
+    const StatCell* xf_stats;   // producer's statistics [kStatReps][groups][2][Cin], replica stride xf_rep_stride cells
     int64_t xf_rep_stride;
     int64_t xf_m_per_group;     // pixels per BatchNorm group of the producer's output
     const float* xf_gamma;
@@ -225,9 +236,9 @@ struct PackDesc {
     int Cout, Cin, ntaps, CinP, CoutP, CiP;
 };
 enum { PACK_TF = 1, PACK_TD = 2, PACK_ALL = 3 };   // which packs a launch writes
-// zero_a / zero_b: two arrays of doubles cleared by the same launch (the BatchNorm statistics arenas of the pass), may be null / 0
+// zero_a / zero_b: two arrays of accumulator cells cleared by the same launch (the BatchNorm statistics arenas of the pass), may be null / 0
 int launch_pack_weights(const float* params, float* arena, const PackDesc* descs_dev, int n_layers, int max_elems,
-                        hipStream_t s, int mask = PACK_ALL, double* zero_a = nullptr, int64_t zero_a_n = 0, double* zero_b = nullptr,
+                        hipStream_t s, int mask = PACK_ALL, StatCell* zero_a = nullptr, int64_t zero_a_n = 0, StatCell* zero_b = nullptr,
                         int64_t zero_b_n = 0);
 
 // ---- layout / elementwise ------------------------------------------------------------------------------
@@ -244,7 +255,7 @@ struct BnFwdArgs {
     const float* y;       // raw conv output [M,C]
     float* z;             // output
     const float* res;     // optional residual (already normalised), same shape
-    const double* stats;  // [kStatReps][G][2][C] (replica stride stat_rep_stride doubles), summed here
+    const StatCell* stats;  // [kStatReps][G][2][C] (replica stride stat_rep_stride cells), summed here
     int64_t stat_rep_stride;
     const float* gamma;
     const float* beta;
@@ -285,10 +296,10 @@ struct BnBwdArgs {
     float* dy[2];         // grad wrt raw conv output
     float* dgamma[2];
     float* dbeta[2];
-    double* sums;         // scratch [nsets][G][2][C], zeroed by the caller
+    StatCell* sums;       // scratch [nsets][G][2][C], zeroed by the caller
     unsigned* barrier;    // zeroed by the caller, or null: arrival counter of the one-pass kernel (nsets == 1, G <= 2, see launch_bn_bwd)
-    double* fsums;        // one-pass kernel: zeroed accumulators [8 replicas][G][2][C]
-    double* fsums_b;      // the same for the second BatchNorm (nsets == 2), null: two-kernel path for two sets
+    StatCell* fsums;      // one-pass kernel: zeroed accumulators [8 replicas][G][2][C]
+    StatCell* fsums_b;    // the same for the second BatchNorm (nsets == 2), null: two-kernel path for two sets
     int accumulate;       // dgamma/dbeta += (1) or = (0)
     unsigned* err;        // host-mapped asynchronous error word (one-pass kernel: arrival time-out), may be null
     int frozen;           // 1: the forward normalised with constant (running) statistics: dy = gamma*invstd*dpre, no mean terms
@@ -299,7 +310,7 @@ struct BnBwdArgs {
 };
 int launch_bn_bwd(const BnBwdArgs& a, hipStream_t s);
 // Apply half of a BatchNorm backward whose reduction ran in the producing data gradient's epilogue (EPI_BNB): d is the masked gradient,
-// esums the replicated sums [kStatReps][G][2][C] (replica stride esums_rep_stride doubles) of d and d * (y - mean);
+// esums the replicated sums [kStatReps][G][2][C] (replica stride esums_rep_stride cells) of d and d * (y - mean);
 // dy = gamma * invstd * (d - mean(d) - xhat * mean(d * xhat)); block 0 writes dgamma / dbeta.  Pure streaming: no atomics, no arrival.
 struct BnApplyEArgs {
     const float* d;
@@ -310,7 +321,7 @@ struct BnApplyEArgs {
     float* dy;
     float* dgamma;
     float* dbeta;
-    const double* esums;
+    const StatCell* esums;
     int64_t esums_rep_stride;
     int64_t m_per_group;
     int G, C, accumulate;

@@ -69,21 +69,109 @@ __device__ __forceinline__ void bn_scale_shift(float gamma, float beta, float me
     sc = gamma * invstd;
     sh = __fmaf_rn(-mean, sc, beta);
 }
-// mean / invstd of (group g, channel c) from the replicated fp64 sums (biased variance, nn.BatchNorm2d's normalisation)
-__device__ __forceinline__ void bn_batch_moments(const double* __restrict__ stats, int64_t rep_stride, int g, int c, int C, double M, float eps,
-                                                 double& mean, double& var) {
-    double s1 = 0.0, s2 = 0.0;
-    for (int r = 0; r < kStatReps; ++r) {   // fixed order: the replica sums are combined deterministically
-        s1 += stats[r * rep_stride + ((int64_t)g * 2 + 0) * C + c];
-        s2 += stats[r * rep_stride + ((int64_t)g * 2 + 1) * C + c];
+// ---- order-independent batch sums (StatCell, conv.h) ---------------------------------------------------------------------
+// (OCL_FP64_SUMS: measurement build -- the cell's first word holds a double and takes fp64 atomics, the scheme of rounds 1 - 3, whose
+// totals depend on the arrival order in the last bit; `make fp64` builds it as libocl_hip_fp64.so for A/B runs, OCL_LIB selects it)
+#ifndef OCL_FP64_SUMS
+#define OCL_FP64_SUMS 0
+#endif
+__device__ __forceinline__ void fx_add(StatCell* cell, double v) {
+#if OCL_FP64_SUMS
+    atomicAdd((double*)&cell->lo, v);
+    return;
+#endif
+    long long hi;
+    unsigned long long lo;
+    if (fabs(v) < 7.0e13) {                                   // (false for NaN / Inf as well)
+        const double q = v * 1099511627776.0;                 // v * 2^40: exact
+        const double h = floor(q * (1.0 / 4294967296.0));     // floor(q / 2^32)
+        hi = (long long)h;
+        lo = (unsigned long long)(q - h * 4294967296.0);      // [0, 2^32): truncating it to an integer is the only rounding (< 2^-40)
+    } else {
+        hi = 1ll << 56;                                       // poison: fx_value reports NaN
+        lo = 0ull;
     }
+    atomicAdd(&cell->lo, lo);
+    atomicAdd((unsigned long long*)&cell->hi, (unsigned long long)hi);
+}
+__device__ __forceinline__ double fx_decode(long long hi, unsigned long long lo) {
+#if OCL_FP64_SUMS
+    return __longlong_as_double((long long)lo);
+#endif
+    if (hi >= (1ll << 55) || hi <= -(1ll << 55)) return __builtin_nan("");
+    return (double)hi * (1.0 / 256.0) + (double)lo * (1.0 / 1099511627776.0);
+}
+// the total of a cell's kStatReps replicas: integer sums, exact in any order
+__device__ __forceinline__ double fx_total(const StatCell* __restrict__ cells, int64_t rep_stride, int64_t idx) {
+#if OCL_FP64_SUMS
+    double t = 0.0;
+    for (int r = 0; r < kStatReps; ++r) t += __longlong_as_double((long long)cells[r * rep_stride + idx].lo);
+    return t;
+#endif
+    long long hi = 0;
+    unsigned long long lo = 0;
+    bool bad = false;
+    for (int r = 0; r < kStatReps; ++r) {
+        const StatCell c = cells[r * rep_stride + idx];
+        bad |= c.hi >= (1ll << 55) || c.hi <= -(1ll << 55);
+        hi += c.hi;
+        lo += c.lo;
+    }
+    return bad ? __builtin_nan("") : fx_decode(hi, lo);
+}
+
+// the same with returning device-scope atomics / device-scope atomic loads (bn_bwd_fused_kernel: the adds must have executed at the
+// coherence point before the wave signals its arrival; the totals are read while other workgroups may still be spinning)
+__device__ __forceinline__ unsigned long long fx_fetch_add(StatCell* cell, double v) {
+#if OCL_FP64_SUMS
+    return (unsigned long long)__double_as_longlong(__hip_atomic_fetch_add((double*)&cell->lo, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#endif
+    long long hi;
+    unsigned long long lo;
+    if (fabs(v) < 7.0e13) {
+        const double q = v * 1099511627776.0;
+        const double h = floor(q * (1.0 / 4294967296.0));
+        hi = (long long)h;
+        lo = (unsigned long long)(q - h * 4294967296.0);
+    } else {
+        hi = 1ll << 56;
+        lo = 0ull;
+    }
+    return __hip_atomic_fetch_add(&cell->lo, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
+           __hip_atomic_fetch_add((unsigned long long*)&cell->hi, (unsigned long long)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double fx_total_atomic(const StatCell* cells, int64_t rep_stride, int64_t idx) {
+#if OCL_FP64_SUMS
+    double t = 0.0;
+    for (int r = 0; r < kStatReps; ++r)
+        t += __hip_atomic_load((const double*)&cells[r * rep_stride + idx].lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return t;
+#endif
+    long long hi = 0;
+    unsigned long long lo = 0;
+    bool bad = false;
+    for (int r = 0; r < kStatReps; ++r) {
+        const StatCell* c = cells + r * rep_stride + idx;
+        const long long h = (long long)__hip_atomic_load((const unsigned long long*)&c->hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bad |= h >= (1ll << 55) || h <= -(1ll << 55);
+        hi += h;
+        lo += __hip_atomic_load(&c->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return bad ? __builtin_nan("") : fx_decode(hi, lo);
+}
+
+// mean / invstd of (group g, channel c) from the replicated batch sums (biased variance, nn.BatchNorm2d's normalisation)
+__device__ __forceinline__ void bn_batch_moments(const StatCell* __restrict__ stats, int64_t rep_stride, int g, int c, int C, double M, float eps,
+                                                 double& mean, double& var) {
+    const double s1 = fx_total(stats, rep_stride, ((int64_t)g * 2 + 0) * C + c);
+    const double s2 = fx_total(stats, rep_stride, ((int64_t)g * 2 + 1) * C + c);
     mean = s1 / M;
     var = s2 / M - mean * mean;
     if (var < 0.0) var = 0.0;
     (void)eps;
 }
 // running statistics: one update per group, in order (= the reference's separate forward calls), unbiased variance, momentum
-__device__ __forceinline__ void bn_running_update(const double* __restrict__ stats, int64_t rep_stride, int G, int C, double M, float momentum,
+__device__ __forceinline__ void bn_running_update(const StatCell* __restrict__ stats, int64_t rep_stride, int G, int C, double M, float momentum,
                                                   float eps, float* __restrict__ running_mean, float* __restrict__ running_var,
                                                   int64_t* __restrict__ nbt, int tid, int nthreads) {
     for (int c = tid; c < C; c += nthreads) {
@@ -472,8 +560,8 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
             if (co < a.Cout) {
                 const double v = (red[(0 * 2 + which) * COPW + c] + red[(1 * 2 + which) * COPW + c]) +
                                  (red[(2 * 2 + which) * COPW + c] + red[(3 * 2 + which) * COPW + c]);
-                double* st_ = a.stats + (int64_t)(blockIdx.x % kStatReps) * a.stat_rep_stride;
-                atomicAdd(&st_[((int64_t)run_grp * 2 + which) * a.Cout + co], v);
+                StatCell* st_ = a.stats + (int64_t)(blockIdx.x % kStatReps) * a.stat_rep_stride;
+                fx_add(&st_[((int64_t)run_grp * 2 + which) * a.Cout + co], v);
             }
         }
         __syncthreads();
@@ -958,8 +1046,8 @@ __global__ void __launch_bounds__(256, 2) conv_q_kernel(const ConvArgs a) {
             if (c < a.Cout) {
                 const double v = ((double)qacc[0 * 2 * COPW + tid] + (double)qacc[1 * 2 * COPW + tid]) +
                                  ((double)qacc[2 * 2 * COPW + tid] + (double)qacc[3 * 2 * COPW + tid]);
-                double* st_ = a.stats + (int64_t)(blockIdx.x % kStatReps) * a.stat_rep_stride;
-                atomicAdd(&st_[((int64_t)run_grp * 2 + which) * a.Cout + c], v);
+                StatCell* st_ = a.stats + (int64_t)(blockIdx.x % kStatReps) * a.stat_rep_stride;
+                fx_add(&st_[((int64_t)run_grp * 2 + which) * a.Cout + c], v);
             }
         }
         __syncthreads();
@@ -1380,10 +1468,10 @@ __global__ void __launch_bounds__(256, NT == 1 ? 5 : 4) conv_s_kernel(const Conv
         const float s1x = row16_sum(z.x), s1y = row16_sum(z.y), s1z = row16_sum(z.z), s1w = row16_sum(z.w);
         const float s2x = row16_sum(z.x * z.x), s2y = row16_sum(z.y * z.y), s2z = row16_sum(z.z * z.z), s2w = row16_sum(z.w * z.w);
         if (r16 == 0 && co < a.Cout) {
-            double* st_ = a.stats + (int64_t)((blockIdx.x + blockIdx.y + wave) % kStatReps) * a.stat_rep_stride + ((int64_t)d1.y * 2) * a.Cout + co;
-            atomicAdd(st_ + 0, (double)s1x); atomicAdd(st_ + 1, (double)s1y); atomicAdd(st_ + 2, (double)s1z); atomicAdd(st_ + 3, (double)s1w);
-            atomicAdd(st_ + a.Cout + 0, (double)s2x); atomicAdd(st_ + a.Cout + 1, (double)s2y);
-            atomicAdd(st_ + a.Cout + 2, (double)s2z); atomicAdd(st_ + a.Cout + 3, (double)s2w);
+            StatCell* st_ = a.stats + (int64_t)((blockIdx.x + blockIdx.y + wave) % kStatReps) * a.stat_rep_stride + ((int64_t)d1.y * 2) * a.Cout + co;
+            fx_add(st_ + 0, (double)s1x); fx_add(st_ + 1, (double)s1y); fx_add(st_ + 2, (double)s1z); fx_add(st_ + 3, (double)s1w);
+            fx_add(st_ + a.Cout + 0, (double)s2x); fx_add(st_ + a.Cout + 1, (double)s2y);
+            fx_add(st_ + a.Cout + 2, (double)s2z); fx_add(st_ + a.Cout + 3, (double)s2w);
         }
     }
     float* op = a.out + (int64_t)oo + co;
@@ -1423,10 +1511,10 @@ __global__ void __launch_bounds__(256, NT == 1 ? 5 : 4) conv_s_kernel(const Conv
         const float s1x = row16_sum(b1[0]), s1y = row16_sum(b1[1]), s1z = row16_sum(b1[2]), s1w = row16_sum(b1[3]);
         const float s2x = row16_sum(b2[0]), s2y = row16_sum(b2[1]), s2z = row16_sum(b2[2]), s2w = row16_sum(b2[3]);
         if (r16 == 0 && co < a.Cout) {
-            double* st_ = a.stats + (int64_t)((blockIdx.x + blockIdx.y + wave) % kStatReps) * a.stat_rep_stride + ((int64_t)d1.y * 2) * a.Cout + co;
-            atomicAdd(st_ + 0, (double)s1x); atomicAdd(st_ + 1, (double)s1y); atomicAdd(st_ + 2, (double)s1z); atomicAdd(st_ + 3, (double)s1w);
-            atomicAdd(st_ + a.Cout + 0, (double)s2x); atomicAdd(st_ + a.Cout + 1, (double)s2y);
-            atomicAdd(st_ + a.Cout + 2, (double)s2z); atomicAdd(st_ + a.Cout + 3, (double)s2w);
+            StatCell* st_ = a.stats + (int64_t)((blockIdx.x + blockIdx.y + wave) % kStatReps) * a.stat_rep_stride + ((int64_t)d1.y * 2) * a.Cout + co;
+            fx_add(st_ + 0, (double)s1x); fx_add(st_ + 1, (double)s1y); fx_add(st_ + 2, (double)s1z); fx_add(st_ + 3, (double)s1w);
+            fx_add(st_ + a.Cout + 0, (double)s2x); fx_add(st_ + a.Cout + 1, (double)s2y);
+            fx_add(st_ + a.Cout + 2, (double)s2z); fx_add(st_ + a.Cout + 3, (double)s2w);
         }
     }
     if (!live) return;
@@ -2622,12 +2710,14 @@ int launch_wgrad_reduce_multi(WgradReduceMulti m, hipStream_t s) {
 // weight packing (all conv layers in one launch)
 // =====================================================================================================
 __global__ void __launch_bounds__(256) pack_weights_kernel(const float* __restrict__ params, float* __restrict__ arena,
-                                                           const PackDesc* __restrict__ descs, int mask, int n_layers, double* __restrict__ zero_a,
-                                                           int64_t zero_a_n, double* __restrict__ zero_b, int64_t zero_b_n) {
+                                                           const PackDesc* __restrict__ descs, int mask, int n_layers, StatCell* __restrict__ zero_a,
+                                                           int64_t zero_a_n, StatCell* __restrict__ zero_b, int64_t zero_b_n) {
     if ((int)blockIdx.y >= n_layers) {   // the last grid row clears the statistics arenas of the pass (saves two memset launches)
         for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < zero_a_n + zero_b_n; i += (int64_t)gridDim.x * blockDim.x) {
-            if (i < zero_a_n) zero_a[i] = 0.0;
-            else zero_b[i - zero_a_n] = 0.0;
+            StatCell z;
+            z.lo = 0ull; z.hi = 0ll;
+            if (i < zero_a_n) zero_a[i] = z;
+            else zero_b[i - zero_a_n] = z;
         }
         return;
     }
@@ -2647,7 +2737,7 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const float* __restri
 }
 
 int launch_pack_weights(const float* params, float* arena, const PackDesc* descs_dev, int n_layers, int max_elems, hipStream_t s,
-                        int mask, double* zero_a, int64_t zero_a_n, double* zero_b, int64_t zero_b_n) {
+                        int mask, StatCell* zero_a, int64_t zero_a_n, StatCell* zero_b, int64_t zero_b_n) {
     ProfScope ps(PROF_BN, s);
     const int extra = (zero_a_n + zero_b_n) > 0 ? 1 : 0;
     hipLaunchKernelGGL(pack_weights_kernel, dim3(std::min(64, cdiv(max_elems, 256)), n_layers + extra), dim3(256), 0, s, params, arena,
@@ -2904,7 +2994,7 @@ __global__ void __launch_bounds__(256) bn_bwd_reduce_kernel(const BnBwdArgs a) {
         double t = 0.0;
         for (int r = 0; r < PT; ++r) t += (double)base[((size_t)kk * PT + r) * a.C + c];
         const int k = kk >> 1, which = kk & 1;
-        atomicAdd(&a.sums[(((int64_t)k * a.G + g) * 2 + which) * a.C + c], t);
+        fx_add(&a.sums[(((int64_t)k * a.G + g) * 2 + which) * a.C + c], t);
     }
 }
 
@@ -2915,8 +3005,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const BnBwdArgs a) {
     const double Md = (double)a.m_per_group;
     for (int j = tid; j < a.nsets * a.C; j += 256) {
         const int c = j % a.C, k = j / a.C;
-        const double sdy = a.sums[(((int64_t)k * a.G + g) * 2 + 0) * a.C + c];
-        const double sdx = a.sums[(((int64_t)k * a.G + g) * 2 + 1) * a.C + c];
+        const StatCell cdy = a.sums[(((int64_t)k * a.G + g) * 2 + 0) * a.C + c], cdx = a.sums[(((int64_t)k * a.G + g) * 2 + 1) * a.C + c];
+        const double sdy = fx_decode(cdy.hi, cdy.lo), sdx = fx_decode(cdx.hi, cdx.lo);
         float* s = sm + (size_t)k * 6 * a.C;
         const float istd = a.invstd[k][(int64_t)g * a.C + c];
         s[c] = a.frozen ? 0.f : (float)(sdy / Md);
@@ -2932,8 +3022,9 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const BnBwdArgs a) {
         if (blockIdx.x == 0 && g == 0) {
             double dg = 0.0, db = 0.0;
             for (int gg = 0; gg < a.G; ++gg) {
-                db += a.sums[(((int64_t)k * a.G + gg) * 2 + 0) * a.C + c];
-                dg += a.sums[(((int64_t)k * a.G + gg) * 2 + 1) * a.C + c];
+                const StatCell cb = a.sums[(((int64_t)k * a.G + gg) * 2 + 0) * a.C + c], cg = a.sums[(((int64_t)k * a.G + gg) * 2 + 1) * a.C + c];
+                db += fx_decode(cb.hi, cb.lo);
+                dg += fx_decode(cg.hi, cg.lo);
             }
             if (a.accumulate) {
                 a.dgamma[k][c] += (float)dg;
@@ -3068,19 +3159,16 @@ __global__ void __launch_bounds__(kBnFusedThreads) bn_bwd_fused_kernel(const BnB
             const float4 v = red[which][t];
             t0 += (double)v.x; t1 += (double)v.y; t2 += (double)v.z; t3 += (double)v.w;
         }
-        double r = 0.0;
+        unsigned long long r = 0ull;
         // returning atomics: the wave waits for them to have executed (at the device-wide coherence point) before the barrier below
 #pragma unroll
         for (int k = 0; k < NS; ++k) {
             if (which != 0 && which != 1 + k) continue;   // the sum of d goes to both arenas, the sum of d * xhat_k to its own
-            double* arena = k == 0 ? a.fsums : a.fsums_b;
-            double* dst = arena + ((int64_t)(blockIdx.x % kBnFusedReps) * a.G * 2 + (int64_t)g * 2 + (which ? 1 : 0)) * a.C + q * 4;
-            r += __hip_atomic_fetch_add(dst + 0, t0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            r += __hip_atomic_fetch_add(dst + 1, t1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            r += __hip_atomic_fetch_add(dst + 2, t2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            r += __hip_atomic_fetch_add(dst + 3, t3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            StatCell* arena = k == 0 ? a.fsums : a.fsums_b;
+            StatCell* dst = arena + ((int64_t)(blockIdx.x % kBnFusedReps) * a.G * 2 + (int64_t)g * 2 + (which ? 1 : 0)) * a.C + q * 4;
+            r += fx_fetch_add(dst + 0, t0) + fx_fetch_add(dst + 1, t1) + fx_fetch_add(dst + 2, t2) + fx_fetch_add(dst + 3, t3);
         }
-        if (r == 1.2345e300) red[0][0].x = 0.f;   // keeps the returns (never true)
+        if (r == 0x123456789abcdef1ull) red[0][0].x = 0.f;   // keeps the returns (practically never true)
     }
     // ---- grid-wide arrival ---------------------------------------------------------------------------
     // Relaxed device-scope atomics only: they execute at the coherence point and bypass the per-XCD L2, so no release / acquire
@@ -3104,21 +3192,18 @@ __global__ void __launch_bounds__(kBnFusedThreads) bn_bwd_fused_kernel(const BnB
     const double Md = (double)M;
     if (g < a.G && tid < (1 + NS) * a.C) {
         const int which = tid / a.C, c = tid - which * a.C;
-        const double* arena = which <= 1 ? a.fsums : a.fsums_b;
-        double v = 0.0;
-        for (int r = 0; r < kBnFusedReps; ++r)
-            v += __hip_atomic_load(arena + ((int64_t)r * a.G * 2 + (int64_t)g * 2 + (which ? 1 : 0)) * a.C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const StatCell* arena = which <= 1 ? a.fsums : a.fsums_b;
+        const double v = fx_total_atomic(arena, (int64_t)a.G * 2 * a.C, ((int64_t)g * 2 + (which ? 1 : 0)) * a.C + c);
         kk[which][c] = timed_out ? __builtin_nanf("") : (float)(v / Md);
     }
     if (blockIdx.x == 0 && tid < NS * a.C) {   // dgamma / dbeta over all groups
         const int k = tid / a.C, c = tid - k * a.C;
-        const double* arena = k == 0 ? a.fsums : a.fsums_b;
+        const StatCell* arena = k == 0 ? a.fsums : a.fsums_b;
         double db = 0.0, dg = 0.0;
-        for (int gg = 0; gg < a.G; ++gg)
-            for (int r = 0; r < kBnFusedReps; ++r) {
-                db += __hip_atomic_load(arena + ((int64_t)r * a.G * 2 + (int64_t)gg * 2 + 0) * a.C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                dg += __hip_atomic_load(arena + ((int64_t)r * a.G * 2 + (int64_t)gg * 2 + 1) * a.C + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+        for (int gg = 0; gg < a.G; ++gg) {   // (each group's total is exact; the groups are added in order)
+            db += fx_total_atomic(arena, (int64_t)a.G * 2 * a.C, ((int64_t)gg * 2 + 0) * a.C + c);
+            dg += fx_total_atomic(arena, (int64_t)a.G * 2 * a.C, ((int64_t)gg * 2 + 1) * a.C + c);
+        }
         if (a.accumulate) {
             a.dgamma[k][c] += (float)dg;
             a.dbeta[k][c] += (float)db;
@@ -3245,11 +3330,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_e_kernel(const BnApplyEArgs 
     const double Md = (double)a.m_per_group;
     for (int c = tid; c < a.C; c += 256) {
         const float istd = a.invstd[(int64_t)g * a.C + c];
-        double s1 = 0.0, s2 = 0.0;
-        for (int r = 0; r < kStatReps; ++r) {
-            s1 += a.esums[r * a.esums_rep_stride + ((int64_t)g * 2 + 0) * a.C + c];
-            s2 += a.esums[r * a.esums_rep_stride + ((int64_t)g * 2 + 1) * a.C + c];
-        }
+        const double s1 = fx_total(a.esums, a.esums_rep_stride, ((int64_t)g * 2 + 0) * a.C + c);
+        const double s2 = fx_total(a.esums, a.esums_rep_stride, ((int64_t)g * 2 + 1) * a.C + c);
         sm[c] = (float)(s1 / Md);
         sm[a.C + c] = (float)(s2 * (double)istd / Md);
         sm[2 * a.C + c] = a.gamma[c] * istd;
@@ -3258,11 +3340,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_e_kernel(const BnApplyEArgs 
         if (blockIdx.x == 0 && g == 0) {   // dgamma = sum over the groups of sum(d * xhat), dbeta = sum(d)
             double dg = 0.0, db = 0.0;
             for (int gg = 0; gg < a.G; ++gg) {
-                double t1 = 0.0, t2 = 0.0;
-                for (int r = 0; r < kStatReps; ++r) {
-                    t1 += a.esums[r * a.esums_rep_stride + ((int64_t)gg * 2 + 0) * a.C + c];
-                    t2 += a.esums[r * a.esums_rep_stride + ((int64_t)gg * 2 + 1) * a.C + c];
-                }
+                const double t1 = fx_total(a.esums, a.esums_rep_stride, ((int64_t)gg * 2 + 0) * a.C + c);
+                const double t2 = fx_total(a.esums, a.esums_rep_stride, ((int64_t)gg * 2 + 1) * a.C + c);
                 db += t1;
                 dg += t2 * (double)a.invstd[(int64_t)gg * a.C + c];
             }

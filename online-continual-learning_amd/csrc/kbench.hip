@@ -173,7 +173,7 @@ __global__ void wgrad_ref_kernel(const float* __restrict__ x, const float* __res
 }
 
 static void bench_geom(const char* lname, const char* kind, ConvGeomDesc g, const float* in, const float* w, float* out,
-                       float* out_ref, double* stats, int flags, double flops, size_t out_elems, bool sweep) {
+                       float* out_ref, StatCell* stats, int flags, double flops, size_t out_elems, bool sweep) {
     float* wT = make_packT(w, g.Cin, g.WPT);
     auto run = [&](ConvPlan p, float* o) {
         p.a.in = in; p.a.wT = wT; p.a.out = o; p.a.flags = flags; p.a.stats = stats; p.a.stat_rep_stride = 8 * 2 * 1024;
@@ -199,8 +199,8 @@ static void bench_geom(const char* lname, const char* kind, ConvGeomDesc g, cons
     }
     printf("%-20s %-7s M=%7d N=%3d K=%4d\n", lname, kind, g.N * g.LH * g.LW, g.Cout, g.ntaps * g.Cin);
     {   // conv_t_kernel: planner's choice and (sweep) every admissible (MT, NT)
-        double* stats2;
-        CK(hipMalloc(&stats2, kStatReps * 8 * 2 * 1024 * 8));
+        StatCell* stats2;
+        CK(hipMalloc(&stats2, kStatReps * 8 * 2 * 1024 * sizeof(StatCell)));
         for (int mt = 0; mt <= (sweep ? 5 : 0); ++mt)
             for (int nt = (mt ? 1 : 0); nt <= (mt ? 2 : 0); ++nt)
             for (int pipe = 0; pipe < 3; ++pipe) {   // staged-weight plans: the two-buffer schedule, then the three-buffer ring; 2: conv_t_kernel where the planner takes conv_q_kernel
@@ -221,23 +221,26 @@ static void bench_geom(const char* lname, const char* kind, ConvGeomDesc g, cons
                 }
                 OK(conv_plan_finalize(&pt));   // (kbench leaks the plans' device tables: a measurement tool that exits right after)
                 CK(hipMemset(out, 0, out_elems * 4));
-                CK(hipMemset(stats2, 0, kStatReps * 8 * 2 * 1024 * 8));
-                double* keep = stats;
+                CK(hipMemset(stats2, 0, kStatReps * 8 * 2 * 1024 * sizeof(StatCell)));
+                StatCell* keep = stats;
                 stats = stats2;
                 run(pt, out);
                 stats = keep;
                 const double d = max_diff(out, out_ref, out_elems);
                 double ds = 0.0;
                 if (flags & EPI_STATS) {   // statistics: the kernel's replicas summed, against the fp64 sums of the reference output
-                    std::vector<double> b(kStatReps * 8 * 2 * 1024);
-                    CK(hipMemcpy(b.data(), stats2, b.size() * 8, hipMemcpyDeviceToHost));
+                    std::vector<StatCell> b(kStatReps * 8 * 2 * 1024);
+                    CK(hipMemcpy(b.data(), stats2, b.size() * sizeof(StatCell), hipMemcpyDeviceToHost));
                     for (int i = 0; i < g.groups * 2 * g.Cout; ++i) {
-                        double y = 0;
-                        for (int r = 0; r < kStatReps; ++r) y += b[(size_t)r * 8 * 2 * 1024 + i];
+                        double y = 0;   // (2^-40 fixed point in two integer words: conv.h StatCell)
+                        for (int r = 0; r < kStatReps; ++r) {
+                            const StatCell& cell = b[(size_t)r * 8 * 2 * 1024 + i];
+                            y += (double)cell.hi / 256.0 + (double)cell.lo / 1099511627776.0;
+                        }
                         ds = fmax(ds, fabs(ref_stats[i] - y) / (1.0 + fabs(ref_stats[i])));
                     }
                 }
-                double* keep2 = stats;
+                StatCell* keep2 = stats;
                 stats = stats2;
                 const double t = time_us([&] { run(pt, out); });
                 stats = keep2;
@@ -817,9 +820,9 @@ int main(int argc, char** argv) {
     float* bufC = dev_rand(max_act, 3);
     float* bufD = dev_rand(max_act, 4);
     float* w = dev_rand(max_w + 4096, 5, 0.2f);
-    double* stats;
-    CK(hipMalloc(&stats, kStatReps * 8 * 2 * 1024 * 8));
-    CK(hipMemset(stats, 0, kStatReps * 8 * 2 * 1024 * 8));
+    StatCell* stats;
+    CK(hipMalloc(&stats, kStatReps * 8 * 2 * 1024 * sizeof(StatCell)));
+    CK(hipMemset(stats, 0, kStatReps * 8 * 2 * 1024 * sizeof(StatCell)));
     printf("# kbench N=%d groups=%d hw=%d\n", N, groups, hw);
     if (mode == "launch") { launch_probe(); return 0; }
     if (mode == "peak4") {
@@ -958,8 +961,8 @@ int main(int argc, char** argv) {
     if (mode == "all" || mode == "bn") {
         int lastC = -1, lastH = -1;
         float* small = dev_rand(64 * 1024, 9);
-        double* sums;
-        CK(hipMalloc(&sums, 8 * 4 * 1024 * 8 + (size_t)2048 * 4 * 1024 * 8));
+        StatCell* sums;
+        CK(hipMalloc(&sums, (8 * 4 * 1024 + (size_t)2048 * 4 * 1024) * sizeof(StatCell)));
         for (auto& l : layers) {
             const ConvShape& c = l.s;
             if (c.Cout == lastC && c.Ho == lastH) continue;
@@ -977,13 +980,13 @@ int main(int argc, char** argv) {
             b.y[0] = bufC; b.mean[0] = small + 4096; b.invstd[0] = small + 8192; b.gamma[0] = small; b.dy[0] = bufD;
             b.dgamma[0] = small + 12288; b.dbeta[0] = small + 13312; b.sums = sums;
             const double tb = time_us([&] {
-                CK(hipMemsetAsync(sums, 0, 8 * 4 * 1024 * 8, 0));
+                CK(hipMemsetAsync(sums, 0, 8 * 4 * 1024 * sizeof(StatCell), 0));
                 OK(launch_bn_bwd(b, 0));
             });
             b.barrier = (unsigned*)(sums + 4096);
             b.fsums = sums + 8192;
             const double tfz = time_us([&] {
-                CK(hipMemsetAsync(sums, 0, 8 * 4 * 1024 * 8, 0));
+                CK(hipMemsetAsync(sums, 0, 8 * 4 * 1024 * sizeof(StatCell), 0));
                 OK(launch_bn_bwd(b, 0));
             });
             b.barrier = nullptr;

@@ -107,8 +107,8 @@ struct ocl_net {
     float* gbuf(int i) const { return (float*)(ws + off_g[i]); }
     float* dybuf(int i) const { return (float*)(ws + off_dy[i]); }
     float* partialbuf() const { return (float*)(ws + off_partial); }
-    double* statsbuf() const { return (double*)(ws + off_stats); }
-    double* bsumsbuf() const { return (double*)(ws + off_bsums); }
+    StatCell* statsbuf() const { return (StatCell*)(ws + off_stats); }
+    StatCell* bsumsbuf() const { return (StatCell*)(ws + off_bsums); }
 
     // second stream for the weight gradients + events (created on first backward)
     hipStream_t s2 = nullptr;
@@ -119,6 +119,20 @@ struct ocl_net {
     int dy_next = 0;
     size_t ev_next = 0;
 
+    // launch-sequence replay (OCL_GRAPH=1): the kernel sequence of a forward / backward with given shapes, slot and flags is captured
+    // once into a hipGraph and replayed, so that the host pays one graph launch instead of 60 - 100 kernel launches + events
+    struct GraphKey {
+        int kind, N, G, slot, a, b, c;
+        uint64_t p;
+        bool operator<(const GraphKey& o) const { return memcmp(this, &o, sizeof(GraphKey)) < 0; }
+    };
+    struct GraphSlot {
+        hipGraphExec_t exec = nullptr;
+        int seen = 0;
+        bool failed = false;
+    };
+    std::map<GraphKey, GraphSlot> graphs;
+    bool capturing = false;
 };
 
 // -----------------------------------------------------------------------------------------------------
@@ -313,7 +327,7 @@ static int build_layout(ocl_net* n) {
     }
     n->stats_doubles = so * kStatReps;   // kStatReps replicas of the whole arena, replica stride `so`
     n->stats_rep_stride = so;
-    n->off_stats = takeb(n->stats_doubles * 8);
+    n->off_stats = takeb(n->stats_doubles * (int64_t)sizeof(StatCell));   // (counts are in accumulator cells)
     // backward: [G][2][C] per BN as well, followed by the one-pass kernel's arenas (8 replicas x 2 groups x 2 x C + counter per BN)
     int64_t fo = so;
     for (auto& b : n->bns) {
@@ -321,12 +335,12 @@ static int build_layout(ocl_net* n) {
         fo += (int64_t)8 * 2 * 2 * b.C + 8;   // + 9 arrival counters (unsigned)
     }
     n->bsums_doubles = fo;
-    n->off_bsums = takeb(fo * 8);
+    n->off_bsums = takeb(fo * (int64_t)sizeof(StatCell));
     n->off_pack = takeb(n->pack_floats * 4);
     n->fold_floats = n->n_stats;  // scale[C], shift[C] per BN, same layout as running stats
     n->off_fold = takeb(n->fold_floats * 4);
     n->off_descs = takeb((int64_t)(n->convs.size() * sizeof(PackDesc) + n->bns.size() * sizeof(BnFoldDesc) + 256));
-    n->head_floats = N * ((int64_t)n->feat_dim * 3 + n->out_dim * 2 + 64);
+    n->head_floats = N * ((int64_t)n->feat_dim * 3 + n->out_dim * 3 + 64);   // dfeat, dh1, dh2 (<= max(feat_dim, out_dim) each), staged dout
     n->off_head = takeb(n->head_floats * 4);
     n->slot_base = w;
     n->slot_bytes = align_up(n->slot_floats * 4, 256);
@@ -447,20 +461,20 @@ static const BnFoldDesc* fold_descs(const ocl_net* n) {
 // the BatchNorm whose backward starts in a data gradient's epilogue (ConvArgs::bnb_*, EPI_BNB)
 struct BnbEpi {
     const float *y, *z, *mean, *invstd, *gamma, *beta;
-    double* sums;            // [kStatReps][G][2][C], replica stride rep_stride doubles, zeroed
+    StatCell* sums;          // [kStatReps][G][2][C], replica stride rep_stride cells, zeroed
     int64_t rep_stride;
 };
 
 // the producer-side BatchNorm a convolution applies to its own input (ConvArgs::xf)
 struct XfBn {
-    const double* stats;
+    const StatCell* stats;
     const float *gamma, *beta;
     float *save_mean, *save_invstd, *running_mean, *running_var;
     int64_t* nbt;
     int64_t m_per_group;
 };
 
-static int run_conv(ocl_net* n, ConvPlan& cached, const float* in, const float* wT, float* out, int flags, double* stats,
+static int run_conv(ocl_net* n, ConvPlan& cached, const float* in, const float* wT, float* out, int flags, StatCell* stats,
                     const float* scale, const float* shift, const float* res, const float* resmask, hipStream_t s, const XfBn* xf = nullptr,
                     const BnbEpi* be = nullptr) {
     if (!cached.a.blob) {   // first launch of this plan: its tables go to the device, on this stream, in front of the launch
@@ -469,7 +483,7 @@ static int run_conv(ocl_net* n, ConvPlan& cached, const float* in, const float* 
     }
     // the tables were uploaded asynchronously on the stream of the plan's first launch: any other stream (the side stream's projection
     // shortcuts, a different caller stream) orders itself behind that copy
-    if (cached.ready && s != cached.ready_stream) OCL_HIP(hipStreamWaitEvent(s, cached.ready, 0));
+    if (cached.ready && s != cached.ready_stream && !n->capturing) OCL_HIP(hipStreamWaitEvent(s, cached.ready, 0));
     ConvPlan p = cached;
     if (xf) {
         p.a.xf = 1;
@@ -574,6 +588,54 @@ static int side_join(ocl_net* n, hipStream_t s) {
     return OCL_OK;
 }
 
+// -----------------------------------------------------------------------------------------------------
+// Launch-sequence replay.  `body` issues launches that depend only on `key` (every pointer it uses lies in the workspace or the bound
+// parameter / gradient / statistics arrays) and touches no host state.  First sight of a key: ordinary launches (plans get their
+// device tables, one-time queries run).  Second sight: the same launches under stream capture -> hipGraph -> instantiate -> launch.
+// From then on: one hipGraphLaunch.  Any failure falls back to ordinary launches for that key.  Off unless OCL_GRAPH=1; never
+// while profiling (per-kernel events) or under a debug stop.
+// -----------------------------------------------------------------------------------------------------
+static bool graph_enabled(const ocl_net* n) {
+    static const bool env_graph = [] { const char* e = getenv("OCL_GRAPH"); return e && e[0] == '1'; }();
+    return env_graph && !prof_on() && n->dbg_stop < 0;
+}
+template <class F>
+static int run_replayed(ocl_net* n, ocl_net::GraphKey key, hipStream_t s, F&& body) {
+    if (!graph_enabled(n)) return body();
+    ocl_net::GraphSlot& g = n->graphs[key];
+    if (g.exec) {
+        OCL_HIP(hipGraphLaunch(g.exec, s));
+        return OCL_OK;
+    }
+    if (g.failed || g.seen++ < 1) return body();
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) {
+        (void)hipGetLastError();
+        g.failed = true;
+        return body();
+    }
+    n->capturing = true;
+    const int rc = body();
+    n->capturing = false;
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(s, &graph);
+    if (rc != OCL_OK || e != hipSuccess || !graph) {
+        if (graph) (void)hipGraphDestroy(graph);
+        (void)hipGetLastError();
+        g.failed = true;
+        return rc != OCL_OK ? rc : body();
+    }
+    const hipError_t ei = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess) {
+        (void)hipGetLastError();
+        g.exec = nullptr;
+        g.failed = true;
+        return body();
+    }
+    OCL_HIP(hipGraphLaunch(g.exec, s));
+    return OCL_OK;
+}
+
 // =====================================================================================================
 // C ABI
 // =====================================================================================================
@@ -598,6 +660,8 @@ int ocl_net_create(const ocl_net_desc* desc, ocl_net** out) {
 
 void ocl_net_destroy(ocl_net* net) {
     if (!net) return;
+    for (auto& kv : net->graphs)
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
     for (auto e : net->ev_ready) (void)hipEventDestroy(e);
     for (int i = 0; i < ocl_net::kDyRing; ++i)
         if (net->ev_done[i]) (void)hipEventDestroy(net->ev_done[i]);
@@ -670,7 +734,7 @@ static int trunk_forward_train(ocl_net* n, PlanSet* ps, const float* P, float* S
                                bool side = false, bool frozen = false, bool fuse = false) {
     const int img0 = 0, g0 = 0;
     float* pack = (float*)(n->ws + n->off_pack);
-    double* stats = n->statsbuf();
+    StatCell* stats = n->statsbuf();
     int rc = OCL_OK;
     // (cleared by the forward's weight-pack launch)
     auto at = [&](int64_t off, const ConvInfo& c) { return S + off + (int64_t)img0 * c.Ho * c.Wo * c.Cout; };
@@ -807,72 +871,89 @@ int ocl_net_forward_segments(ocl_net* n, const float* const* xs, const int32_t* 
     // every forward packs (the caller may have stepped the weights), but only the layouts the pass reads: the forward packs, and the
     // data-gradient packs when a backward will follow this tape
     const int pack_mask = n->pack_need_fwd | ((flags & OCL_FWD_SAVE_TAPE) ? n->pack_need_bwd : 0);
-    // (the same launch clears the statistics arenas: the forward's, and the backward's for the backward that follows a taped pass)
-    rc = launch_pack_weights(P, pack, pack_descs(n), (int)n->convs.size(), max_elems, s, pack_mask, n->statsbuf(), n->stats_doubles,
-                             n->bsumsbuf(), n->bsums_doubles);
-    n->bsums_clean = true;
-    if (rc != OCL_OK) return rc;
-    n->pack_have = n->pack_src == P ? (n->pack_have | pack_mask) : pack_mask;   // (older packs of the same array stay as they were)
-    n->pack_src = P;
 
     float* S = n->slotf(slot);
     float* x4 = S + n->x4_off;
+    // (the only launch that reads caller memory: in front of the replayable sequence)
     rc = launch_nchw3_to_nhwc4_segments(sg, x4, N, n->d.in_h, n->d.in_w, s);
     if (rc != OCL_OK) return rc;
     n->slot_valid[slot] = false;
 
-    const bool feat_direct = feat_out && !out && !(flags & OCL_FWD_SAVE_TAPE);   // features only (ASER scoring, NCM): no copy
+    const bool replay = graph_enabled(n);
+    // features only (ASER scoring, NCM): straight into the caller's array, no copy (a replayed sequence writes the slot's own array)
+    const bool feat_direct = feat_out && !out && !(flags & OCL_FWD_SAVE_TAPE) && !replay;
     float* feat = feat_direct ? feat_out : S + n->feat_off;
     const bool upd = (flags & OCL_FWD_UPDATE_RUNNING) != 0;
-    bool fused = false;
+    static const bool env_single = [] { const char* e = getenv("OCL_SINGLE_STREAM"); return e && e[0] == '1'; }();
+    static const bool env_noextra = [] { const char* e = getenv("OCL_SIDE_EXTRA"); return e && e[0] == '0'; }();
+    static const bool env_nofuse = [] { const char* e = getenv("OCL_BN1_FUSE"); return e && e[0] == '0'; }();
+    const bool side = train && n->dbg_stop < 0 && N >= kSideExtraMinBatch && !prof_on() && !env_single && !env_noextra;
+    if (side && (rc = ensure_side_stream(n))) return rc;
+    const bool fused = train && !frozen && !env_nofuse;
+    const bool want_head = out || (flags & OCL_FWD_SAVE_TAPE);
+    float* head_out2 = replay ? nullptr : out;   // the head's last kernel writes the caller's array as well (not when replayed)
+    bool wrote = false;
+
+    // ---- the launch sequence (everything below depends only on the key: shapes, slot, flags, parameter array) -----------------------
+    auto body = [&]() -> int {
+        int rc = launch_pack_weights(P, pack, pack_descs(n), (int)n->convs.size(), max_elems, s, pack_mask, n->statsbuf(), n->stats_doubles,
+                                     n->bsumsbuf(), n->bsums_doubles);   // (also clears the statistics arenas of the pass and of its backward)
+        if (rc != OCL_OK) return rc;
+        if (train) {
+            if ((rc = trunk_forward_train(n, ps, P, S, N, groups, upd && !frozen, feat, s, side, frozen, fused))) return rc;
+        } else {
+            float* fold = (float*)(n->ws + n->off_fold);
+            if ((rc = launch_bn_fold(P, n->running, fold, fold_descs(n), (int)n->bns.size(), 1e-5f, s))) return rc;
+            auto conv_eval = [&](int conv_i, const float* in, float* o, const float* res, int relu) -> int {
+                const ConvInfo& c = n->convs[conv_i];
+                const BnInfo& b = n->bns[c.bn];
+                int fl = EPI_AFFINE | (res ? EPI_RES : 0) | (relu ? EPI_RELU : 0);
+                return run_conv(n, ps->fwd[conv_i], in, pack + c.tf_off, o, fl, nullptr, fold + b.stat_off, fold + b.stat_off + b.C, res,
+                                nullptr, s);
+            };
+            float* bufs[4] = {n->gbuf(0), n->gbuf(1), n->gbuf(2), n->gbuf(3)};
+            float* cur = bufs[0];
+            if ((rc = conv_eval(0, x4, cur, nullptr, 1))) return rc;
+            int ci = 0;
+            for (auto& b : n->blocks) {
+                float* a1 = bufs[(ci + 1) & 3];
+                float* sc = bufs[(ci + 2) & 3];
+                float* z = bufs[(ci + 3) & 3];
+                if ((rc = conv_eval(b.conv1, cur, a1, nullptr, 1))) return rc;
+                const float* res = cur;
+                if (b.convs >= 0) {
+                    if ((rc = conv_eval(b.convs, cur, sc, nullptr, 0))) return rc;
+                    res = sc;
+                }
+                if ((rc = conv_eval(b.conv2, a1, z, res, 1))) return rc;
+                cur = z;
+                ci = (ci + 3) & 3;
+            }
+            if ((rc = launch_avgpool_fwd(cur, feat, N, n->Hf, n->Wf, n->convs[n->blocks.back().conv2].Cout, s))) return rc;
+        }
+        if (want_head && (rc = head_forward(n, P, feat, S + n->h1_off, S + n->h2_off, S + n->norms_off, S + n->out_off, N, s, head_out2, &wrote)))
+            return rc;
+        return OCL_OK;
+    };
+    ocl_net::GraphKey key;
+    memset(&key, 0, sizeof(key));
+    key.kind = 0; key.N = N; key.G = groups; key.slot = slot; key.a = (int)flags; key.b = pack_mask;
+    key.c = (want_head ? 1 : 0) | (feat == S + n->feat_off ? 2 : 0);
+    key.p = (uint64_t)(uintptr_t)P;
+    rc = run_replayed(n, key, s, body);
+    // host state of the pass (also when the launches were replayed)
+    n->bsums_clean = true;
+    n->pack_have = n->pack_src == P ? (n->pack_have | pack_mask) : pack_mask;   // (older packs of the same array stay as they were)
+    n->pack_src = P;
+    if (rc != OCL_OK) return rc;
     if (train) {
-        static const bool env_single = [] { const char* e = getenv("OCL_SINGLE_STREAM"); return e && e[0] == '1'; }();
-        static const bool env_noextra = [] { const char* e = getenv("OCL_SIDE_EXTRA"); return e && e[0] == '0'; }();
-        const bool side = n->dbg_stop < 0 && N >= kSideExtraMinBatch && !prof_on() && !env_single && !env_noextra;
-        if (side && (rc = ensure_side_stream(n))) return rc;
-        static const bool env_nofuse = [] { const char* e = getenv("OCL_BN1_FUSE"); return e && e[0] == '0'; }();
-        fused = !frozen && !env_nofuse;
-        if ((rc = trunk_forward_train(n, ps, P, S, N, groups, upd && !frozen, feat, s, side, frozen, fused))) return rc;
         n->slot_fused[slot] = fused;
         n->slot_n[slot] = N;
         n->slot_groups[slot] = groups;
-    } else {
-        float* fold = (float*)(n->ws + n->off_fold);
-        if ((rc = launch_bn_fold(P, n->running, fold, fold_descs(n), (int)n->bns.size(), 1e-5f, s))) return rc;
-        auto conv_eval = [&](int conv_i, const float* in, float* o, const float* res, int relu) -> int {
-            const ConvInfo& c = n->convs[conv_i];
-            const BnInfo& b = n->bns[c.bn];
-            int fl = EPI_AFFINE | (res ? EPI_RES : 0) | (relu ? EPI_RELU : 0);
-            return run_conv(n, ps->fwd[conv_i], in, pack + c.tf_off, o, fl, nullptr, fold + b.stat_off, fold + b.stat_off + b.C, res,
-                            nullptr, s);
-        };
-        float* bufs[4] = {n->gbuf(0), n->gbuf(1), n->gbuf(2), n->gbuf(3)};
-        float* cur = bufs[0];
-        if ((rc = conv_eval(0, x4, cur, nullptr, 1))) return rc;
-        int ci = 0;
-        for (auto& b : n->blocks) {
-            float* a1 = bufs[(ci + 1) & 3];
-            float* sc = bufs[(ci + 2) & 3];
-            float* z = bufs[(ci + 3) & 3];
-            if ((rc = conv_eval(b.conv1, cur, a1, nullptr, 1))) return rc;
-            const float* res = cur;
-            if (b.convs >= 0) {
-                if ((rc = conv_eval(b.convs, cur, sc, nullptr, 0))) return rc;
-                res = sc;
-            }
-            if ((rc = conv_eval(b.conv2, a1, z, res, 1))) return rc;
-            cur = z;
-            ci = (ci + 3) & 3;
-        }
-        if ((rc = launch_avgpool_fwd(cur, feat, N, n->Hf, n->Wf, n->convs[n->blocks.back().conv2].Cout, s))) return rc;
     }
     if (feat_out && !feat_direct) OCL_HIP(hipMemcpyAsync(feat_out, feat, (size_t)N * n->feat_dim * 4, hipMemcpyDeviceToDevice, s));
-    if (out || (flags & OCL_FWD_SAVE_TAPE)) {
-        float* o = S + n->out_off;
-        bool wrote = false;
-        if ((rc = head_forward(n, P, feat, S + n->h1_off, S + n->h2_off, S + n->norms_off, o, N, s, out, &wrote))) return rc;
-        if (out && !wrote) OCL_HIP(hipMemcpyAsync(out, o, (size_t)N * n->out_dim * 4, hipMemcpyDeviceToDevice, s));
-    }
+    if (out && want_head && !(wrote && head_out2))
+        OCL_HIP(hipMemcpyAsync(out, S + n->out_off, (size_t)N * n->out_dim * 4, hipMemcpyDeviceToDevice, s));
     if (train && (flags & OCL_FWD_SAVE_TAPE) && !params_override) {
         n->slot_valid[slot] = true;
         n->slot_frozen[slot] = frozen;
@@ -893,10 +974,10 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
     const int img0 = 0, g0 = 0;
     float* pack = (float*)(n->ws + n->off_pack);
     float* partial = n->partialbuf();
-    double* bsums = n->bsumsbuf();
+    StatCell* bsums = n->bsumsbuf();
     int rc = OCL_OK;
     const bool two_streams_arg = side != nullptr;
-    if (!n->bsums_clean) OCL_HIP(hipMemsetAsync(bsums, 0, n->bsums_doubles * 8, s));   // a second backward since the last forward
+    if (!n->bsums_clean) OCL_HIP(hipMemsetAsync(bsums, 0, n->bsums_doubles * sizeof(StatCell), s));   // a second backward since the last forward
     n->bsums_clean = false;
     auto T = [&](int t) { return P + n->tensors[t].off; };
     auto GT = [&](int t) { return Gr + n->tensors[t].off; };
@@ -976,7 +1057,10 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
     // one stream (replay-sized batches: bound by the number of dependent launches): every layer writes its slabs into its own region
     // and ONE launch at the end of the backward reduces them all
     static const bool env_noreduce = [] { const char* e = getenv("OCL_BATCHED_REDUCE"); return e && e[0] == '0'; }();
-    const bool batched = !two_streams_arg && Nc < kTwoStreamMinBatch && ps->batched_reduce && !env_noreduce && n->dbg_stop < 0;
+    // (with a side stream too: the small launches of a replay-sized backward leave most of the machine idle, so the weight gradients
+    // run BESIDE the dependent chain there, each layer into its own slab region, and one launch at the end reduces them all)
+    const bool batched = Nc < kTwoStreamMinBatch && ps->batched_reduce && !env_noreduce && n->dbg_stop < 0;
+    (void)two_streams_arg;
     WgradReduceMulti rm;
     rm.partial = partial; rm.grads = Gr; rm.accumulate = accumulate; rm.n = 0;
     // xf_conv >= 0: xin is the RAW output of that convolution; its BatchNorm + ReLU is applied while the kernel stages its patches
@@ -1110,6 +1194,15 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
     // still running there when the chain ends -- with its own slab region (the slabs of one layer stay under 12 MB; the stem's start
     // 16 MB into the buffer), and the join follows it.
     (void)rS;
+    if (two_streams && batched) {   // replay-sized pass: the stem's weight gradient and the one reduction of all layers on the side stream, then the join
+        if ((rc = publish())) return rc;
+        if ((rc = wgrad(0, S + n->x4_off + (int64_t)img0 * n->d.in_h * n->d.in_w * 4, gS))) return rc;
+        if (rm.n > 0 && (rc = launch_wgrad_reduce_multi(rm, sw))) return rc;
+        OCL_HIP(hipEventRecord(n->ev_join, sw));
+        OCL_HIP(hipStreamWaitEvent(s, n->ev_join, 0));
+        for (int i = 0; i < ocl_net::kDyRing; ++i) n->ev_done_pending[i] = false;   // covered by the join
+        return OCL_OK;
+    }
     if (two_streams) {
         WgradPlan wp = ps->wgrad[0];
         wp.a.x = S + n->x4_off + (int64_t)img0 * n->d.in_h * n->d.in_w * 4;
@@ -1154,15 +1247,11 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
     const float* P = n->params;
     float* Gr = n->grads;
     float* pack = (float*)(n->ws + n->off_pack);
-    if (n->pack_src != P || (n->pack_have & n->pack_need_bwd) != n->pack_need_bwd) {
-        // the arena was rewritten by a forward of MIR's virtual model since the taped forward (or plans made since need another layout)
-        int max_elems = 0;
-        for (auto& c : n->convs) max_elems = std::max(max_elems, c.Cout * c.Cin * c.k * c.k);
-        const int m = n->pack_need_fwd | n->pack_need_bwd;
-        if ((rc = launch_pack_weights(P, pack, pack_descs(n), (int)n->convs.size(), max_elems, s, m))) return rc;
-        n->pack_src = P;
-        n->pack_have = m;
-    }
+    // the arena was rewritten by a forward of MIR's virtual model since the taped forward (or plans made since need another layout)
+    const bool repack = n->pack_src != P || (n->pack_have & n->pack_need_bwd) != n->pack_need_bwd;
+    const int repack_mask = n->pack_need_fwd | n->pack_need_bwd;
+    const bool bsums_dirty = !n->bsums_clean;   // a second backward since the last forward: trunk_backward clears the arena itself
+    const bool replay = graph_enabled(n);
     auto T = [&](int t) { return P + n->tensors[t].off; };
     auto GT = [&](int t) { return Gr + n->tensors[t].off; };
     const int FD = n->feat_dim, OD = n->out_dim;
@@ -1170,6 +1259,11 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
     float* dfeat = hb;
     float* dh1 = hb + (int64_t)N * FD;
     float* dh2 = dh1 + (int64_t)N * FD;
+    if (replay) {   // the only read of caller memory: dout is staged inside the workspace, in front of the replayable sequence
+        float* stage = hb + (int64_t)N * (3 * FD + 2 * OD);
+        OCL_HIP(hipMemcpyAsync(stage, dout, (size_t)N * OD * 4, hipMemcpyDeviceToDevice, s));
+        dout = stage;
+    }
     float* feat = S + n->feat_off;
     float* h1 = S + n->h1_off;
     float* o = S + n->out_off;
@@ -1183,7 +1277,9 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
     // 10-20 images are latency-bound: the event traffic costs more than the overlap returns there.  Debug stops and measurement
     // runs (ocl_prof_enable, OCL_SINGLE_STREAM=1: per-kernel durations of the kernel alone) stay on one stream as well.
     static const bool env_single = [] { const char* e = getenv("OCL_SINGLE_STREAM"); return e && e[0] == '1'; }();
-    const bool two_streams = n->dbg_stop < 0 && N >= kTwoStreamMinBatch && !prof_on() && !env_single;
+    // OCL_TWO_STREAM_MIN_PIX: smallest pass (images x input pixels) whose weight gradients leave the caller's stream
+    static const int64_t env_min_pix = [] { const char* e = getenv("OCL_TWO_STREAM_MIN_PIX"); return e ? (int64_t)atoll(e) : (int64_t)kTwoStreamMinBatch * 1024; }();
+    const bool two_streams = n->dbg_stop < 0 && (int64_t)N * n->d.in_h * n->d.in_w >= env_min_pix && !prof_on() && !env_single;
     if (two_streams && (rc = ensure_side_stream(n))) return rc;
     auto lin_bwd = [&](const float* dy, int ncol, const float* xin, int kin, int tw, int tb, float* dx) -> int {
         // y = x W^T + b, W [ncol, kin]
@@ -1197,27 +1293,51 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
         if (dx) r = ocl_gemm_small(dy, ncol, 1, T(tw), kin, 1, dx, kin, N, kin, ncol, nullptr, 0, 0, s);  // dx = dy W
         return r;
     };
-    if (n->d.head == 0) {
-        if ((rc = lin_bwd(dout, OD, feat, FD, n->t_linear_w, n->t_linear_b, dfeat))) return rc;
-    } else {
-        if (!accumulate) {  // encoder.linear takes no part in SupConResNet.forward: its gradient is zero
-            if ((rc = launch_fill(GT(n->t_linear_w), n->tensors[n->t_linear_w].numel, 0.f, s))) return rc;
-            if ((rc = launch_fill(GT(n->t_linear_b), n->tensors[n->t_linear_b].numel, 0.f, s))) return rc;
+    const bool fused_tape = n->slot_fused[slot];
+    auto body = [&]() -> int {
+        int rc = OCL_OK;
+        if (repack) {
+            int max_elems = 0;
+            for (auto& c : n->convs) max_elems = std::max(max_elems, c.Cout * c.Cin * c.k * c.k);
+            if ((rc = launch_pack_weights(P, pack, pack_descs(n), (int)n->convs.size(), max_elems, s, repack_mask))) return rc;
         }
-        if (n->d.head == 1) {
-            if ((rc = launch_l2norm_bwd(o, norms, dout, dh2, N, OD, s))) return rc;
-            if ((rc = lin_bwd(dh2, OD, h1, FD, n->t_h2_w, n->t_h2_b, dh1))) return rc;
-            if ((rc = launch_relu_bwd(dh1, h1, dh1, (int64_t)N * FD, s))) return rc;
-            if ((rc = lin_bwd(dh1, FD, feat, FD, n->t_h0_w, n->t_h0_b, dfeat))) return rc;
-        } else if (n->d.head == 2) {
-            if ((rc = launch_l2norm_bwd(o, norms, dout, dh2, N, OD, s))) return rc;
-            if ((rc = lin_bwd(dh2, OD, feat, FD, n->t_h2_w, n->t_h2_b, dfeat))) return rc;
+        if (n->d.head == 0) {
+            if ((rc = lin_bwd(dout, OD, feat, FD, n->t_linear_w, n->t_linear_b, dfeat))) return rc;
         } else {
-            if ((rc = launch_l2norm_bwd(o, norms, dout, dfeat, N, FD, s))) return rc;
+            if (!accumulate) {  // encoder.linear takes no part in SupConResNet.forward: its gradient is zero
+                if ((rc = launch_fill(GT(n->t_linear_w), n->tensors[n->t_linear_w].numel, 0.f, s))) return rc;
+                if ((rc = launch_fill(GT(n->t_linear_b), n->tensors[n->t_linear_b].numel, 0.f, s))) return rc;
+            }
+            if (n->d.head == 1) {
+                if ((rc = launch_l2norm_bwd(o, norms, dout, dh2, N, OD, s))) return rc;
+                if ((rc = lin_bwd(dh2, OD, h1, FD, n->t_h2_w, n->t_h2_b, dh1))) return rc;
+                if ((rc = launch_relu_bwd(dh1, h1, dh1, (int64_t)N * FD, s))) return rc;
+                if ((rc = lin_bwd(dh1, FD, feat, FD, n->t_h0_w, n->t_h0_b, dfeat))) return rc;
+            } else if (n->d.head == 2) {
+                if ((rc = launch_l2norm_bwd(o, norms, dout, dh2, N, OD, s))) return rc;
+                if ((rc = lin_bwd(dh2, OD, feat, FD, n->t_h2_w, n->t_h2_b, dfeat))) return rc;
+            } else {
+                if ((rc = launch_l2norm_bwd(o, norms, dout, dfeat, N, FD, s))) return rc;
+            }
         }
+        // ---- trunk ------------------------------------------------------------------------------------
+        n->bsums_clean = !bsums_dirty;   // (trunk_backward reads the flag: the same decision whenever the sequence is issued)
+        return trunk_backward(n, ps, P, Gr, S, N, G, accumulate, dfeat, s, two_streams ? n->s2 : nullptr, frozen, fused_tape);
+    };
+    ocl_net::GraphKey key;
+    memset(&key, 0, sizeof(key));
+    key.kind = 1; key.N = N; key.G = G; key.slot = slot;
+    key.a = (accumulate ? 1 : 0) | (frozen ? 2 : 0) | (fused_tape ? 4 : 0) | (two_streams ? 8 : 0);
+    key.b = (repack ? 1 : 0) | (bsums_dirty ? 2 : 0);
+    key.c = repack_mask;
+    key.p = (uint64_t)(uintptr_t)P;
+    rc = run_replayed(n, key, s, body);
+    if (repack) {
+        n->pack_src = P;
+        n->pack_have = repack_mask;
     }
-    // ---- trunk ------------------------------------------------------------------------------------
-    return trunk_backward(n, ps, P, Gr, S, N, G, accumulate, dfeat, s, two_streams ? n->s2 : nullptr, frozen, n->slot_fused[slot]);
+    n->bsums_clean = false;
+    return rc;
 }
 
 int ocl_net_debug_stop(ocl_net* n, int stage) {

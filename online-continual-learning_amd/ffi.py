@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libocl_hip.so")
+LIB_PATH = os.environ.get("OCL_LIB") or os.path.join(_HERE, "libocl_hip.so")   # (OCL_LIB: a measurement build of the same library)
 _lib = None
 
 i64 = C.c_int64

@@ -602,3 +602,36 @@ def test_bench_gpus_2_launches_its_own_ranks(cuda):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and len(d["per_rank_images_per_s"]) == 2
     assert d["value"] > 0 and abs(d["value"] - 2 * 20 * 10 / (d["ms_per_step"] * 20 * 1e-3)) < 1e-6 * d["value"]   # whole-job rate = all ranks' images / max-over-ranks time
     assert "cpu_baseline" not in d and "accuracy" not in d                                                       # single-GPU record only
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# run-to-run reproducibility
+# ---------------------------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("workload", ["scr", "er"])
+def test_training_steps_are_bit_reproducible(cuda, workload):
+    """The BatchNorm batch sums (forward statistics, backward reductions) are accumulated as fixed-point integers (csrc/conv.h StatCell),
+    the weight-gradient slabs are reduced in a fixed order: nothing in a step depends on the order in which workgroups finish, whatever
+    the two engine streams and the data stream do.  Two fresh agents, same seeds, same stream: after 12 steps at BASELINE size (SCR:
+    110 + 110 views through the two-stream backward; ER: the merged 20-image pass) every weight, BatchNorm buffer and memory row is
+    BIT-IDENTICAL.  (The reference's CPU path has this property at a fixed thread count.)"""
+    import random
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    def run():
+        params, model, agent, hw, ncls = bench.build_agent(workload, 3, cuda)
+        x, y = bench.synth_u8(12 * params.batch, hw, ncls, 17)
+        np.random.seed(5); random.seed(5); torch.manual_seed(5)
+        agent.train_learner(torch.from_numpy(x).to(cuda), y)
+        torch.cuda.synchronize()
+        sd = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
+        return sd, agent.buffer.buffer_img.detach().cpu().numpy().copy(), agent.buffer.buffer_label.detach().cpu().numpy().copy()
+
+    a, b = run(), run()
+    assert a[0].keys() == b[0].keys()
+    diff = [k for k in a[0] if not np.array_equal(a[0][k], b[0][k])]
+    assert not diff, "tensors differ between two identical runs: %s" % diff[:5]
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
