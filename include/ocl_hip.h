@@ -256,6 +256,13 @@ int ocl_bn_bwd_nhwc(const float* dz, const float* zmask, const float* y, const f
                     const float* gamma, int64_t m_per_group, int groups, int c, float* dy, float* dgamma,
                     float* dbeta, int accumulate, double* scratch, void* stream);
 
+/* Run-to-run reproducibility.  The BatchNorm batch sums (forward statistics, backward reductions) are the only accumulations of a
+ * step whose order depends on scheduling.  on = 1: they are accumulated as fixed-point integers (associative): every weight is
+ * bit-identical from run to run, as the reference's CPU path is at a fixed thread count; costs ~12 % per step (two atomics per
+ * partial sum).  on = 0 (default; OCL_DETERMINISTIC=1 in the environment starts with 1): fp64 atomics.  Synchronises the device;
+ * call it between steps, not inside one. */
+int ocl_set_deterministic(int on);
+
 /* ---- measurement helpers --------------------------------------------------------------------------
  * HIP-event timing on the caller's stream (bench.py's roofline leg: torch.cuda.Event only sees
  * torch's current stream).  Kernel-class accumulators are filled when profiling is enabled. */

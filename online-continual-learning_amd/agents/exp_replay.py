@@ -8,12 +8,14 @@ sequence of model / RNG / buffer effects and chooses a cheaper schedule where th
 * ASER mode (`_two_pass_step`): the gradients of the first two passes are thrown away by the reference's zero_grad(), so their
   backward is not run (MIR retrieval still gets the batch pass's gradient vector).
 """
+import contextlib
 import os
 
 import numpy as np
 import torch
 
 from .. import debug
+from .. import ops
 from ..buffer import Buffer
 from ..data import DeviceLoader
 from ..utils import maybe_cuda, AverageMeter
@@ -128,9 +130,31 @@ class ExperienceReplay(ContinualLearner):
                     and not trick['kd_trick'] and not trick['kd_trick_star'] and hasattr(upd, "update_begin")
                     and os.environ.get("OCL_ASER_PIPELINE", "1") != "0")
 
+        # Random retrieval + reservoir update never touch the model: like agents/scr.py, the data path (loader gather, retrieve gather,
+        # reservoir scatter: ~20 tiny launches, 5 % of a 1 ms step) goes to its own stream, so that step i+1's data work runs next to
+        # step i's backward instead of in front of step i+1's forward.  Same statements, same order, same RNG draws (OCL_DATA_STREAM=0:
+        # everything on the main stream; tests/test_gpu_steps.py::test_er_data_stream_overlap_is_schedule_only: bit-identical end state).
+        overlap = (merge and self.cuda and self.params.update == 'random' and not debug.on()
+                   and os.environ.get("OCL_DATA_STREAM", "1") != "0")
+        main = torch.cuda.current_stream() if self.cuda else None
+        ds = ops.data_stream(x_train.device if torch.is_tensor(x_train) and x_train.is_cuda else torch.cuda.current_device()) if overlap else None
+        if overlap:
+            ds.wait_stream(main)
+
+        def on_data():
+            return torch.cuda.stream(ds) if overlap else contextlib.nullcontext()
+
         for ep in range(self.epoch):
             pending = None
-            for i, (batch_x, batch_y) in enumerate(train_loader):
+            loader_it = iter(train_loader)
+            i = -1
+            while True:
+                with on_data():
+                    batch_data = next(loader_it, None)
+                if batch_data is None:
+                    break
+                i += 1
+                batch_x, batch_y = batch_data
                 batch_y_host = train_loader.last_y_host
                 pre = None
                 if pipeline:
@@ -140,17 +164,23 @@ class ExperienceReplay(ContinualLearner):
                 for j in range(self.mem_iters):
                     retrieved = None
                     if merge:
-                        retrieved = self.buffer.retrieve(x=batch_x, y=batch_y)
+                        with on_data():
+                            retrieved = self.buffer.retrieve(x=batch_x, y=batch_y)
+                            retrieved = (maybe_cuda(retrieved[0], self.cuda), maybe_cuda(retrieved[1], self.cuda))
+                        if overlap:
+                            main.wait_stream(ds)
+                            for t in (batch_x, batch_y) + retrieved:
+                                t.record_stream(main)   # allocated on the data stream, consumed on the main one
                         if retrieved[0].size(0) == batch_x.size(0):
-                            self._merged_step(batch_x, batch_y, maybe_cuda(retrieved[0], self.cuda), maybe_cuda(retrieved[1], self.cuda),
-                                              meters)
+                            self._merged_step(batch_x, batch_y, retrieved[0], retrieved[1], meters)
                             continue
                     self._two_pass_step(batch_x, batch_y, batch_y_host, meters, aser, retrieved, logits=pre if j == 0 else None)
 
                 if pipeline:
                     pending = upd.update_begin(self.buffer, batch_x, batch_y, y_host=batch_y_host)
                 else:
-                    self.buffer.update(batch_x, batch_y, y_host=batch_y_host)
+                    with on_data():
+                        self.buffer.update(batch_x, batch_y, y_host=batch_y_host)
 
                 if i % 100 == 1 and self.verbose:
                     for tag, (loss_meter, acc_meter) in zip(("", "mem "), meters):
@@ -158,4 +188,6 @@ class ExperienceReplay(ContinualLearner):
                                                                                              acc_meter.avg()))
             if pipeline:
                 upd.update_finish(self.buffer, pending)
+        if overlap:
+            main.wait_stream(ds)
         self.after_train()

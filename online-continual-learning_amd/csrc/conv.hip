@@ -69,84 +69,118 @@ __device__ __forceinline__ void bn_scale_shift(float gamma, float beta, float me
     sc = gamma * invstd;
     sh = __fmaf_rn(-mean, sc, beta);
 }
-// ---- order-independent batch sums (StatCell, conv.h) ---------------------------------------------------------------------
-// (OCL_FP64_SUMS: measurement build -- the cell's first word holds a double and takes fp64 atomics, the scheme of rounds 1 - 3, whose
-// totals depend on the arrival order in the last bit; `make fp64` builds it as libocl_hip_fp64.so for A/B runs, OCL_LIB selects it)
-#ifndef OCL_FP64_SUMS
-#define OCL_FP64_SUMS 0
-#endif
-__device__ __forceinline__ void fx_add(StatCell* cell, double v) {
-#if OCL_FP64_SUMS
-    atomicAdd((double*)&cell->lo, v);
-    return;
-#endif
-    long long hi;
-    unsigned long long lo;
+// ---- batch sums (StatCell, conv.h) ---------------------------------------------------------------------------------------------
+// Two ways to accumulate a cell, chosen at run time (ocl_set_deterministic / OCL_DETERMINISTIC=1, a __constant__ flag):
+//  * default: the cell's first word holds a double and takes fp64 atomics (rounds 1 - 3): totals depend on the workgroups' arrival
+//    order in the last bit;
+//  * deterministic: 2^-40 fixed point added as two 64-bit INTEGERS (associative): bit-identical totals whatever the order.  Costs
+//    two atomics per partial sum instead of one: +12 % on the SCR step, +13 % on ER (profiles/r4_batch_sums_ab.txt) -- which is why
+//    it is a mode and not the default.
+__constant__ int g_det_sums = 0;
+
+__device__ __forceinline__ void fx_split(double v, long long& hi, unsigned long long& lo) {
     if (fabs(v) < 7.0e13) {                                   // (false for NaN / Inf as well)
         const double q = v * 1099511627776.0;                 // v * 2^40: exact
         const double h = floor(q * (1.0 / 4294967296.0));     // floor(q / 2^32)
         hi = (long long)h;
         lo = (unsigned long long)(q - h * 4294967296.0);      // [0, 2^32): truncating it to an integer is the only rounding (< 2^-40)
     } else {
-        hi = 1ll << 56;                                       // poison: fx_value reports NaN
+        hi = 1ll << 56;                                       // poison: reads back as NaN
         lo = 0ull;
     }
+}
+__device__ __forceinline__ void fx_add(StatCell* cell, double v) {
+    if (!g_det_sums) {
+        atomicAdd((double*)&cell->lo, v);
+        return;
+    }
+    long long hi;
+    unsigned long long lo;
+    fx_split(v, hi, lo);
     atomicAdd(&cell->lo, lo);
     atomicAdd((unsigned long long*)&cell->hi, (unsigned long long)hi);
 }
 __device__ __forceinline__ double fx_decode(long long hi, unsigned long long lo) {
-#if OCL_FP64_SUMS
-    return __longlong_as_double((long long)lo);
-#endif
+    if (!g_det_sums) return __longlong_as_double((long long)lo);
     if (hi >= (1ll << 55) || hi <= -(1ll << 55)) return __builtin_nan("");
     return (double)hi * (1.0 / 256.0) + (double)lo * (1.0 / 1099511627776.0);
 }
-// the total of a cell's kStatReps replicas: integer sums, exact in any order
+typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+// the total of a cell's kStatReps replicas (deterministic mode: integer sums, exact in any order; default: the replicas in a fixed
+// order).  All replicas are requested before any is consumed: left to itself the compiler waited for each 16-byte load before issuing
+// the next -- eight dependent L2 round trips in the prologue of every kernel that reads a statistic.
 __device__ __forceinline__ double fx_total(const StatCell* __restrict__ cells, int64_t rep_stride, int64_t idx) {
-#if OCL_FP64_SUMS
-    double t = 0.0;
-    for (int r = 0; r < kStatReps; ++r) t += __longlong_as_double((long long)cells[r * rep_stride + idx].lo);
-    return t;
-#endif
+    u64x2_t c[kStatReps];
+#pragma unroll
+    for (int r = 0; r < kStatReps; ++r) c[r] = *(const u64x2_t*)(cells + r * rep_stride + idx);
+    if (!g_det_sums) {
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < kStatReps; ++r) t += __longlong_as_double((long long)c[r].x);
+        return t;
+    }
     long long hi = 0;
     unsigned long long lo = 0;
     bool bad = false;
+#pragma unroll
     for (int r = 0; r < kStatReps; ++r) {
-        const StatCell c = cells[r * rep_stride + idx];
-        bad |= c.hi >= (1ll << 55) || c.hi <= -(1ll << 55);
-        hi += c.hi;
-        lo += c.lo;
+        const long long h = (long long)c[r].y;
+        bad |= h >= (1ll << 55) || h <= -(1ll << 55);
+        hi += h;
+        lo += c[r].x;
     }
     return bad ? __builtin_nan("") : fx_decode(hi, lo);
 }
-
+// two totals at once: all 2 * kStatReps loads in flight together
+__device__ __forceinline__ void fx_total2(const StatCell* __restrict__ cells, int64_t rep_stride, int64_t idx1, int64_t idx2, double& t1, double& t2) {
+    u64x2_t a[kStatReps], b[kStatReps];
+#pragma unroll
+    for (int r = 0; r < kStatReps; ++r) {
+        a[r] = *(const u64x2_t*)(cells + r * rep_stride + idx1);
+        b[r] = *(const u64x2_t*)(cells + r * rep_stride + idx2);
+    }
+    if (!g_det_sums) {
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int r = 0; r < kStatReps; ++r) {
+            s1 += __longlong_as_double((long long)a[r].x);
+            s2 += __longlong_as_double((long long)b[r].x);
+        }
+        t1 = s1; t2 = s2;
+        return;
+    }
+    long long h1 = 0, h2 = 0;
+    unsigned long long l1 = 0, l2 = 0;
+    bool bad1 = false, bad2 = false;
+#pragma unroll
+    for (int r = 0; r < kStatReps; ++r) {
+        const long long x = (long long)a[r].y, y = (long long)b[r].y;
+        bad1 |= x >= (1ll << 55) || x <= -(1ll << 55);
+        bad2 |= y >= (1ll << 55) || y <= -(1ll << 55);
+        h1 += x; l1 += a[r].x;
+        h2 += y; l2 += b[r].x;
+    }
+    t1 = bad1 ? __builtin_nan("") : fx_decode(h1, l1);
+    t2 = bad2 ? __builtin_nan("") : fx_decode(h2, l2);
+}
 // the same with returning device-scope atomics / device-scope atomic loads (bn_bwd_fused_kernel: the adds must have executed at the
 // coherence point before the wave signals its arrival; the totals are read while other workgroups may still be spinning)
 __device__ __forceinline__ unsigned long long fx_fetch_add(StatCell* cell, double v) {
-#if OCL_FP64_SUMS
-    return (unsigned long long)__double_as_longlong(__hip_atomic_fetch_add((double*)&cell->lo, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-#endif
+    if (!g_det_sums)
+        return (unsigned long long)__double_as_longlong(__hip_atomic_fetch_add((double*)&cell->lo, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     long long hi;
     unsigned long long lo;
-    if (fabs(v) < 7.0e13) {
-        const double q = v * 1099511627776.0;
-        const double h = floor(q * (1.0 / 4294967296.0));
-        hi = (long long)h;
-        lo = (unsigned long long)(q - h * 4294967296.0);
-    } else {
-        hi = 1ll << 56;
-        lo = 0ull;
-    }
+    fx_split(v, hi, lo);
     return __hip_atomic_fetch_add(&cell->lo, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
            __hip_atomic_fetch_add((unsigned long long*)&cell->hi, (unsigned long long)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ double fx_total_atomic(const StatCell* cells, int64_t rep_stride, int64_t idx) {
-#if OCL_FP64_SUMS
-    double t = 0.0;
-    for (int r = 0; r < kStatReps; ++r)
-        t += __hip_atomic_load((const double*)&cells[r * rep_stride + idx].lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return t;
-#endif
+    if (!g_det_sums) {
+        double t = 0.0;
+        for (int r = 0; r < kStatReps; ++r)
+            t += __hip_atomic_load((const double*)&cells[r * rep_stride + idx].lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return t;
+    }
     long long hi = 0;
     unsigned long long lo = 0;
     bool bad = false;
@@ -159,12 +193,18 @@ __device__ __forceinline__ double fx_total_atomic(const StatCell* cells, int64_t
     }
     return bad ? __builtin_nan("") : fx_decode(hi, lo);
 }
+int set_deterministic_sums(int on) {
+    const int v = on ? 1 : 0;
+    OCL_HIP(hipDeviceSynchronize());   // (no launch may straddle the switch: the cells are interpreted by the flag)
+    OCL_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_det_sums), &v, sizeof(int)));
+    return OCL_OK;
+}
 
 // mean / invstd of (group g, channel c) from the replicated batch sums (biased variance, nn.BatchNorm2d's normalisation)
 __device__ __forceinline__ void bn_batch_moments(const StatCell* __restrict__ stats, int64_t rep_stride, int g, int c, int C, double M, float eps,
                                                  double& mean, double& var) {
-    const double s1 = fx_total(stats, rep_stride, ((int64_t)g * 2 + 0) * C + c);
-    const double s2 = fx_total(stats, rep_stride, ((int64_t)g * 2 + 1) * C + c);
+    double s1, s2;
+    fx_total2(stats, rep_stride, ((int64_t)g * 2 + 0) * C + c, ((int64_t)g * 2 + 1) * C + c, s1, s2);
     mean = s1 / M;
     var = s2 / M - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -3330,8 +3370,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_e_kernel(const BnApplyEArgs 
     const double Md = (double)a.m_per_group;
     for (int c = tid; c < a.C; c += 256) {
         const float istd = a.invstd[(int64_t)g * a.C + c];
-        const double s1 = fx_total(a.esums, a.esums_rep_stride, ((int64_t)g * 2 + 0) * a.C + c);
-        const double s2 = fx_total(a.esums, a.esums_rep_stride, ((int64_t)g * 2 + 1) * a.C + c);
+        double s1, s2;
+        fx_total2(a.esums, a.esums_rep_stride, ((int64_t)g * 2 + 0) * a.C + c, ((int64_t)g * 2 + 1) * a.C + c, s1, s2);
         sm[c] = (float)(s1 / Md);
         sm[a.C + c] = (float)(s2 * (double)istd / Md);
         sm[2 * a.C + c] = a.gamma[c] * istd;
@@ -3340,8 +3380,8 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_e_kernel(const BnApplyEArgs 
         if (blockIdx.x == 0 && g == 0) {   // dgamma = sum over the groups of sum(d * xhat), dbeta = sum(d)
             double dg = 0.0, db = 0.0;
             for (int gg = 0; gg < a.G; ++gg) {
-                const double t1 = fx_total(a.esums, a.esums_rep_stride, ((int64_t)gg * 2 + 0) * a.C + c);
-                const double t2 = fx_total(a.esums, a.esums_rep_stride, ((int64_t)gg * 2 + 1) * a.C + c);
+                double t1, t2;
+                fx_total2(a.esums, a.esums_rep_stride, ((int64_t)gg * 2 + 0) * a.C + c, ((int64_t)gg * 2 + 1) * a.C + c, t1, t2);
                 db += t1;
                 dg += t2 * (double)a.invstd[(int64_t)gg * a.C + c];
             }
@@ -3521,6 +3561,13 @@ int launch_fill(float* p, int64_t n, float v, hipStream_t s) {
 int conv_kernels_init() {
     static bool done = false;
     if (done) return OCL_OK;
+    {
+        const char* e = getenv("OCL_DETERMINISTIC");
+        if (e && e[0] == '1') {
+            int rc = set_deterministic_sums(1);
+            if (rc != OCL_OK) return rc;
+        }
+    }
     for (int m = 1; m <= 4; ++m)
         for (int n = 1; n <= 5; ++n)
             for (int pf = 4; pf <= 8; pf += 4)

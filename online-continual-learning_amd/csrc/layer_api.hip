@@ -22,4 +22,6 @@ int ocl_bn_bwd_nhwc(const float* dz, const float* zmask, const float* y, const f
     return launch_bn_bwd(a, s);
 }
 
+int ocl_set_deterministic(int on) { return set_deterministic_sums(on); }
+
 }  // extern "C"

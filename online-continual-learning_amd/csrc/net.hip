@@ -602,6 +602,7 @@ static bool graph_enabled(const ocl_net* n) {
 template <class F>
 static int run_replayed(ocl_net* n, ocl_net::GraphKey key, hipStream_t s, F&& body) {
     if (!graph_enabled(n)) return body();
+    static const bool verbose = [] { const char* e = getenv("OCL_GRAPH_VERBOSE"); return e && e[0] == '1'; }();
     ocl_net::GraphSlot& g = n->graphs[key];
     if (g.exec) {
         OCL_HIP(hipGraphLaunch(g.exec, s));
@@ -609,6 +610,7 @@ static int run_replayed(ocl_net* n, ocl_net::GraphKey key, hipStream_t s, F&& bo
     }
     if (g.failed || g.seen++ < 1) return body();
     if (hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed) != hipSuccess) {
+        if (verbose) fprintf(stderr, "ocl graph: begin-capture failed (kind %d N %d)\n", key.kind, key.N);
         (void)hipGetLastError();
         g.failed = true;
         return body();
@@ -619,19 +621,24 @@ static int run_replayed(ocl_net* n, ocl_net::GraphKey key, hipStream_t s, F&& bo
     hipGraph_t graph = nullptr;
     const hipError_t e = hipStreamEndCapture(s, &graph);
     if (rc != OCL_OK || e != hipSuccess || !graph) {
+        if (verbose) fprintf(stderr, "ocl graph: capture failed (kind %d N %d): body rc %d, end-capture %d (%s)\n", key.kind, key.N, rc, (int)e, hipGetErrorString(e));
         if (graph) (void)hipGraphDestroy(graph);
         (void)hipGetLastError();
         g.failed = true;
         return rc != OCL_OK ? rc : body();
     }
+    size_t n_nodes = 0;
+    (void)hipGraphGetNodes(graph, nullptr, &n_nodes);
     const hipError_t ei = hipGraphInstantiate(&g.exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     if (ei != hipSuccess) {
+        if (verbose) fprintf(stderr, "ocl graph: instantiate failed (kind %d N %d): %s\n", key.kind, key.N, hipGetErrorString(ei));
         (void)hipGetLastError();
         g.exec = nullptr;
         g.failed = true;
         return body();
     }
+    if (verbose) fprintf(stderr, "ocl graph: captured kind %d N %d G %d slot %d: %zu nodes\n", key.kind, key.N, key.G, key.slot, n_nodes);
     OCL_HIP(hipGraphLaunch(g.exec, s));
     return OCL_OK;
 }
@@ -940,7 +947,9 @@ int ocl_net_forward_segments(ocl_net* n, const float* const* xs, const int32_t* 
     key.kind = 0; key.N = N; key.G = groups; key.slot = slot; key.a = (int)flags; key.b = pack_mask;
     key.c = (want_head ? 1 : 0) | (feat == S + n->feat_off ? 2 : 0);
     key.p = (uint64_t)(uintptr_t)P;
-    rc = run_replayed(n, key, s, body);
+    // (sequences that fork to the side stream are not replayed: as a graph the SCR pass ran at 4.2 ms per step against 2.35 with
+    // stream launches -- profiles/r4_graph_replay.txt -- while a single-stream ER pass keeps its GPU time and halves the host's)
+    rc = side ? body() : run_replayed(n, key, s, body);
     // host state of the pass (also when the launches were replayed)
     n->bsums_clean = true;
     n->pack_have = n->pack_src == P ? (n->pack_have | pack_mask) : pack_mask;   // (older packs of the same array stay as they were)
@@ -1331,7 +1340,7 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
     key.b = (repack ? 1 : 0) | (bsums_dirty ? 2 : 0);
     key.c = repack_mask;
     key.p = (uint64_t)(uintptr_t)P;
-    rc = run_replayed(n, key, s, body);
+    rc = two_streams ? body() : run_replayed(n, key, s, body);   // (single-stream sequences only: see ocl_net_forward_segments)
     if (repack) {
         n->pack_src = P;
         n->pack_have = repack_mask;

@@ -72,6 +72,7 @@ SIGNATURES = {
     "ocl_net_debug_stop": (C.c_int, [vp, C.c_int]),
     "ocl_net_debug_copy": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, vp, i64, C.POINTER(i64), vp]),
     "ocl_bn_bwd_nhwc": (C.c_int, [vp, vp, vp, vp, vp, vp, i64, C.c_int, C.c_int, vp, vp, vp, C.c_int, vp, vp]),
+    "ocl_set_deterministic": (C.c_int, [C.c_int]),
     "ocl_prof_enable": (C.c_int, [C.c_int]),
     "ocl_prof_reset": (C.c_int, []),
     "ocl_prof_query": (C.c_int, [C.c_int, C.POINTER(C.c_double), C.POINTER(i64)]),

@@ -340,3 +340,9 @@ def mfma_calibrate(iters=20000):
     tf, us = C.c_double(0), C.c_double(0)
     ffi.check(ffi.lib().ocl_mfma_calibrate(int(iters), ffi.ptr(scratch), C.byref(tf), C.byref(us), ffi.stream()), "mfma_calibrate")
     return tf.value, us.value
+
+
+def set_deterministic(on):
+    """Order-independent (integer) BatchNorm batch sums: bit-reproducible training steps at ~12 % per step (include/ocl_hip.h)."""
+    ffi.init()
+    ffi.check(ffi.lib().ocl_set_deterministic(int(bool(on))), "set_deterministic")

@@ -81,4 +81,8 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if os.environ.get("OCL_PROBE_STREAM") == "1":   # (hipGraph capture, OCL_GRAPH=1, needs a non-default stream)
+        with torch.cuda.stream(torch.cuda.Stream()):
+            main()
+    else:
+        main()

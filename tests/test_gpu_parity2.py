@@ -610,8 +610,9 @@ def test_bench_gpus_2_launches_its_own_ranks(cuda):
 
 @pytest.mark.parametrize("workload", ["scr", "er"])
 def test_training_steps_are_bit_reproducible(cuda, workload):
-    """The BatchNorm batch sums (forward statistics, backward reductions) are accumulated as fixed-point integers (csrc/conv.h StatCell),
-    the weight-gradient slabs are reduced in a fixed order: nothing in a step depends on the order in which workgroups finish, whatever
+    """Deterministic mode (ocl_set_deterministic): the BatchNorm batch sums (forward statistics, backward reductions) are accumulated as
+    fixed-point integers (csrc/conv.h StatCell), the weight-gradient slabs are reduced in a fixed order: nothing in a step depends on
+    the order in which workgroups finish, whatever
     the two engine streams and the data stream do.  Two fresh agents, same seeds, same stream: after 12 steps at BASELINE size (SCR:
     110 + 110 views through the two-stream backward; ER: the merged 20-image pass) every weight, BatchNorm buffer and memory row is
     BIT-IDENTICAL.  (The reference's CPU path has this property at a fixed thread count.)"""
@@ -630,7 +631,12 @@ def test_training_steps_are_bit_reproducible(cuda, workload):
         sd = {k: v.detach().cpu().numpy().copy() for k, v in model.state_dict().items()}
         return sd, agent.buffer.buffer_img.detach().cpu().numpy().copy(), agent.buffer.buffer_label.detach().cpu().numpy().copy()
 
-    a, b = run(), run()
+    from ocl_amd import ops
+    ops.set_deterministic(True)
+    try:
+        a, b = run(), run()
+    finally:
+        ops.set_deterministic(False)
     assert a[0].keys() == b[0].keys()
     diff = [k for k in a[0] if not np.array_equal(a[0][k], b[0][k])]
     assert not diff, "tensors differ between two identical runs: %s" % diff[:5]

@@ -142,3 +142,51 @@ def test_bn_backward_sums_in_the_dgrad_epilogue_match_the_one_pass_kernel(tmp_pa
     worst = max(errs.items(), key=lambda kv: kv[1])
     print("bnb epilogue vs one-pass kernel: worst", worst, "median %.2e" % float(np.median(list(errs.values()))))
     assert worst[1] < 2e-5, worst
+
+
+# ---- launch-sequence replay (OCL_GRAPH=1, csrc/net.hip run_replayed) ------------------------------------------------------------------------
+_SCRIPT_G = r"""
+import hashlib, json, os, random, sys
+import importlib.util
+import numpy as np
+import torch
+sys.path.insert(0, %(root)r)
+spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(%(root)r, "bench.py"))
+bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+out = {}
+side = torch.cuda.Stream()          # stream capture needs a non-default stream
+with torch.cuda.stream(side):
+    for wl in ("er", "scr"):
+        params, model, agent, hw, ncls = bench.build_agent(wl, 3, dev)
+        x, y = bench.synth_u8(14 * params.batch, hw, ncls, 17)
+        np.random.seed(5); random.seed(5); torch.manual_seed(5)
+        agent.train_learner(torch.from_numpy(x).to(dev), y)
+        torch.cuda.synchronize()
+        h = hashlib.sha256()
+        for k, v in model.state_dict().items():
+            h.update(v.detach().cpu().numpy().tobytes())
+        h.update(agent.buffer.buffer_img.detach().cpu().numpy().tobytes())
+        out[wl] = h.hexdigest()
+print("DIGEST " + json.dumps(out))
+"""
+
+
+def test_launch_sequence_replay_is_schedule_only():
+    """OCL_GRAPH=1: the forward / backward launch sequences are captured into hipGraphs at their second occurrence and replayed from
+    then on.  Same kernels, same arguments, order-independent batch sums: 14 ER and 14 SCR steps at BASELINE size end in bit-identical
+    weights, BatchNorm buffers and replay memory with and without the replay; the verbose log must show that sequences WERE captured
+    (on the default stream hipStreamBeginCapture is refused and the engine falls back to ordinary launches)."""
+    res = {}
+    for flag in ("0", "1"):
+        env = dict(os.environ, OCL_GRAPH=flag, OCL_GRAPH_VERBOSE="1", OCL_DETERMINISTIC="1", PYTHONDONTWRITEBYTECODE="1")
+        r = subprocess.run([sys.executable, "-c", _SCRIPT_G % {"root": ROOT}], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("DIGEST ")][-1]
+        res[flag] = (json.loads(line[len("DIGEST "):]), r.stderr)
+    assert res["0"][0] == res["1"][0], "weights differ with OCL_GRAPH=1"
+    captured = [l for l in res["1"][1].splitlines() if l.startswith("ocl graph: captured")]
+    failed = [l for l in res["1"][1].splitlines() if l.startswith("ocl graph:") and "failed" in l]
+    print("\n".join(captured[:8]))
+    assert len(captured) >= 4 and not failed, (captured[:4], failed[:4])

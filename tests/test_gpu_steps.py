@@ -471,6 +471,30 @@ def test_scr_data_stream_overlap_is_schedule_only(cuda, monkeypatch):
     assert np.abs(w1 - w0).max() < 1e-4 * max(1.0, np.abs(w0).max())
 
 
+def test_er_data_stream_overlap_is_schedule_only(cuda, monkeypatch):
+    """agents/exp_replay.py (random retrieve / reservoir update, merged two-group pass) issues its data path on the data stream as
+    agents/scr.py does.  Same statements, same RNG draws, and the batch sums are order-independent: 60 free-running ER steps (memory
+    filling up and being overwritten) with and without the overlap end in the same replay memory AND the same weights, bit for bit."""
+    from ocl_amd import ops
+    ops.set_deterministic(True)   # (bit-identical weights need the order-independent batch sums; restored below)
+    cfg = dict(STEP_CASES["er_c10"], mem_size=200)
+    rng = np.random.default_rng(79)
+    x = rng.integers(0, 256, (600, 32, 32, 3), dtype=np.uint8)
+    y = rng.integers(0, 10, 600).astype(np.int64)
+    finals = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("OCL_DATA_STREAM", flag)
+        params, model, agent = build_agent(cfg)
+        agent.train_learner(torch.from_numpy(x).to(cuda), y)
+        torch.cuda.synchronize()
+        finals.append((model.flat_params().cpu().numpy().copy(), agent.buffer.buffer_img.cpu().numpy().copy(),
+                       agent.buffer.buffer_label.cpu().numpy().copy(), agent.buffer.n_seen_so_far))
+    ops.set_deterministic(False)
+    (w1, b1, l1, n1), (w0, b0, l0, n0) = finals
+    assert n1 == n0 == 600 and np.array_equal(l1, l0) and np.array_equal(b1, b0)
+    assert np.array_equal(w1, w0)
+
+
 def test_aser_pipelined_loop_is_schedule_only(cuda, monkeypatch):
     """agents/exp_replay.py issues the batch-pass forward of iteration i+1 before the host half of iteration i's ASER update (wait
     for the ranking, class table, row moves).  Same kernels on the same data, same RNG draws: 40 free-running ER + ASER steps
