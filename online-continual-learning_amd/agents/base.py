@@ -55,6 +55,31 @@ class ContinualLearner(torch.nn.Module, metaclass=abc.ABCMeta):
     def train_learner(self, x_train, y_train):
         pass
 
+    def launch_stream(self):
+        """Context for the training loop.  With launch-sequence replay requested (OCL_GRAPH=1, csrc/net.hip run_replayed) the loop runs
+        on a stream of its own, ordered after and before the caller's stream: hipStreamBeginCapture is refused on the default stream,
+        and the replay is what keeps a host-bound loop (ER + ASER: one synchronisation per step) from waiting on launch calls."""
+        import contextlib
+        import os
+
+        @contextlib.contextmanager
+        def ctx():
+            if not (self.cuda and os.environ.get("OCL_GRAPH") == "1") or debug.on():
+                yield
+                return
+            cur = torch.cuda.current_stream()
+            if cur != torch.cuda.default_stream():
+                yield
+                return
+            own = self.__dict__.get("_ocl_stream")
+            if own is None:
+                own = self.__dict__["_ocl_stream"] = torch.cuda.Stream()
+            own.wait_stream(cur)
+            with torch.cuda.stream(own):
+                yield
+            cur.wait_stream(own)
+        return ctx()
+
     def after_train(self):
         """agents/base.py:56-91 (review trick branch :62-88)."""
         self.old_labels += self.new_labels

@@ -108,6 +108,10 @@ class ExperienceReplay(ContinualLearner):
 
     # ---- the loop ------------------------------------------------------------------------------------------------------
     def train_learner(self, x_train, y_train):
+        with self.launch_stream():
+            self._train_learner(x_train, y_train)
+
+    def _train_learner(self, x_train, y_train):
         self.before_train(x_train, y_train)
         # device-resident task behind the reference's DataLoader (same sampler, same RNG draws)
         train_loader = DeviceLoader(x_train, y_train, self.batch, shuffle=True, drop_last=True)

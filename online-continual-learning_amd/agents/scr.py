@@ -134,6 +134,10 @@ class SupContrastReplay(ContinualLearner):
                                     scale=(0.2, 1.))
 
     def train_learner(self, x_train, y_train):
+        with self.launch_stream():
+            self._train_learner(x_train, y_train)
+
+    def _train_learner(self, x_train, y_train):
         self.before_train(x_train, y_train)
         # set up loader
         train_loader = DeviceLoader(x_train, y_train, self.batch, shuffle=True, drop_last=True)

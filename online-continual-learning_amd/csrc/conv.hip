@@ -2631,8 +2631,12 @@ int plan_wgrad(int N, int Hin, int Win, int Cin, int Ho, int Wo, int Cout, int k
     // pixel tile (KP output pixels, 128 / 64 / 32) and channel chunk KC: the largest tile whose patch + dy fit the LDS
     // target and the prefetch registers with a chunk of at least min(20, Cin) channels; else the best that fits at all.
     bool found = false;
+    // measurement knobs (kbench sweeps): largest pixel tile, workgroup target of the pixel split, smallest grid that stops the search
+    static const int env_kp = [] { const char* e = getenv("OCL_WGRAD_KP"); return e ? atoi(e) : 128; }();
+    static const int env_target = [] { const char* e = getenv("OCL_WGRAD_TARGET"); return e ? atoi(e) : 512; }();
+    static const int env_enough = [] { const char* e = getenv("OCL_WGRAD_ENOUGH"); return e ? atoi(e) : 384; }();
     for (int pass = 0; pass < 2 && !found; ++pass) {
-        for (int KPmax = 128; KPmax >= 32 && !found; KPmax /= 2) {
+        for (int KPmax = env_kp; KPmax >= 32 && !found; KPmax /= 2) {
             if (LP >= KPmax) {
                 a.imgs = 1; a.ppi = KPmax; a.tiles_per_img = cdiv(LP, KPmax); a.KP = KPmax;
             } else {
@@ -2681,12 +2685,12 @@ int plan_wgrad(int N, int Hin, int Win, int Cin, int Ho, int Wo, int Cout, int k
         const int by = a.nchunks * mb * a.nblocks;
         const int64_t slab = (int64_t)a.nchunks * mb * 64 * m * a.CoutP * 4;
         const int s_cap = (int)std::max<int64_t>(1, (12ll << 20) / slab);
-        int S = std::max(1, std::min(std::min(a.total_tiles, s_cap), cdiv(512, by)));
+        int S = std::max(1, std::min(std::min(a.total_tiles, s_cap), cdiv(env_target, by)));
         const int tpb = cdiv(a.total_tiles, S);
         S = cdiv(a.total_tiles, tpb);
         const int64_t blocks = (int64_t)by * S;
         if (blocks > best_blocks) { best_blocks = blocks; MTW = m; bestS = S; }
-        if (blocks >= 384) break;
+        if (blocks >= env_enough) break;
     }
     a.mblocks_per_chunk = cdiv(mtiles, 4 * MTW);
     a.Mrows_total = a.nchunks * a.mblocks_per_chunk * 64 * MTW;

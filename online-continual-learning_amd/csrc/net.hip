@@ -551,7 +551,7 @@ static int head_forward(ocl_net* n, const float* P, float* feat, float* h1, floa
 }
 
 static const int kTwoStreamMinBatch = 48;
-static const int kSideExtraMinBatch = 96;   // projection shortcut / head weight gradients on the side stream (MIR's 50-image passes lose 3 %)
+static const int kSideExtraMinBatch = 96;   // projection shortcut / head weight gradients on the side stream from 96 x 32 x 32 input pixels on
 
 static int ensure_side_stream(ocl_net* n) {
     if (n->s2) return OCL_OK;
@@ -894,7 +894,10 @@ int ocl_net_forward_segments(ocl_net* n, const float* const* xs, const int32_t* 
     static const bool env_single = [] { const char* e = getenv("OCL_SINGLE_STREAM"); return e && e[0] == '1'; }();
     static const bool env_noextra = [] { const char* e = getenv("OCL_SIDE_EXTRA"); return e && e[0] == '0'; }();
     static const bool env_nofuse = [] { const char* e = getenv("OCL_BN1_FUSE"); return e && e[0] == '0'; }();
-    const bool side = train && n->dbg_stop < 0 && N >= kSideExtraMinBatch && !prof_on() && !env_single && !env_noextra;
+    // (threshold in images x input pixels: MIR's 50-image 84 x 84 passes qualify, 5.05 -> 4.99 ms per step; OCL_SIDE_EXTRA_MIN_PIX overrides)
+    static const int64_t env_side_pix = [] { const char* e = getenv("OCL_SIDE_EXTRA_MIN_PIX"); return e ? (int64_t)atoll(e) : (int64_t)kSideExtraMinBatch * 1024; }();
+    const bool side_big = (int64_t)N * n->d.in_h * n->d.in_w >= env_side_pix;
+    const bool side = train && n->dbg_stop < 0 && side_big && !prof_on() && !env_single && !env_noextra;
     if (side && (rc = ensure_side_stream(n))) return rc;
     const bool fused = train && !frozen && !env_nofuse;
     const bool want_head = out || (flags & OCL_FWD_SAVE_TAPE);
@@ -1293,7 +1296,9 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
     auto lin_bwd = [&](const float* dy, int ncol, const float* xin, int kin, int tw, int tb, float* dx) -> int {
         // y = x W^T + b, W [ncol, kin]
         static const bool env_noextra = [] { const char* e = getenv("OCL_SIDE_EXTRA"); return e && e[0] == '0'; }();
-        const bool hs = two_streams && N >= kSideExtraMinBatch && !env_noextra;
+        static const int64_t env_side_pix = [] { const char* e = getenv("OCL_SIDE_EXTRA_MIN_PIX"); return e ? (int64_t)atoll(e) : (int64_t)kSideExtraMinBatch * 1024; }();
+        const bool hs_big = (int64_t)N * n->d.in_h * n->d.in_w >= env_side_pix;
+        const bool hs = two_streams && hs_big && !env_noextra;
         hipStream_t sw = hs ? n->s2 : s;
         int r = hs ? side_wait(n, s) : OCL_OK;   // dy is complete
         if (r) return r;

@@ -30,6 +30,9 @@ def main(tag, version, rnd="r3"):
         if os.path.isfile(src):
             line = [l for l in open(src) if l.startswith("{")][-1]
             open(os.path.join(p, "%s_bench_%s_%s.json" % (rnd, version, w)), "w").write(line)
+    if not os.path.isfile(os.path.join(g, "%s_pmc_summary.json" % tag)):
+        print("no PMC summary for", tag)
+        return
     d = json.load(open(os.path.join(g, "%s_pmc_summary.json" % tag)))
 
     def agg(tag_, prefix):
@@ -44,7 +47,7 @@ def main(tag, version, rnd="r3"):
                     "request for 16 B/lane streaming reads -> doubled; WRITE_SIZE uncalibrated, taken as is",
            "kernels": {}}
     for prefix, label in (("conv_t_kernel", "conv_t_kernel"), ("conv_q_kernel", "conv_q_kernel"), ("conv_s_kernel", "conv_s_kernel"), ("conv_wgrad_kernel", "conv_wgrad_kernel"), ("bn_fwd_kernel", "bn_fwd_kernel"), ("bn_bwd_fused", "bn_bwd_fused_kernel"), ("wgrad_reduce", "wgrad_reduce_kernel"),
-                          ("bn_bwd_reduce", "bn_bwd_reduce_kernel"), ("bn_bwd_apply", "bn_bwd_apply_kernel"),
+                          ("bn_bwd_reduce", "bn_bwd_reduce_kernel"), ("bn_bwd_apply_kernel", "bn_bwd_apply_kernel"), ("bn_bwd_apply_e", "bn_bwd_apply_e_kernel"),
                           ("rows_copy16<false>", "rows_copy16_gather")):
         fs, fn = agg("FETCH_SIZE", prefix)
         ws, wn = agg("WRITE_SIZE", prefix)

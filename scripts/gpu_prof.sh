@@ -3,7 +3,7 @@ mkdir -p gpurun_out
 export PYTHONDONTWRITEBYTECODE=1
 export TMPDIR=/tmp
 T=${1:-prof}
-Q="--no-cpu-baseline --no-also --no-accuracy --no-roofline"
+Q="--no-cpu-baseline --no-also --no-accuracy --no-roofline --preroll 0 --repeats 1"   # (60 steps per run: 10 warm-up + 50 timed)
 timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/${T}_prof -o scr -- python bench.py --steps 50 --warmup 10 $Q > gpurun_out/${T}_prof.log 2>&1; echo "prof rc=$?"
 timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/${T}_prof1 -o scr -- python bench.py --steps 50 --warmup 10 $Q --single-stream > gpurun_out/${T}_prof1.log 2>&1; echo "prof single-stream rc=$?"
 timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/${T}_prof2 -o aser -- python bench.py --workload aser --steps 50 --warmup 10 $Q --single-stream > gpurun_out/${T}_prof2.log 2>&1; echo "prof aser rc=$?"

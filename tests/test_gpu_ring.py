@@ -156,28 +156,28 @@ bench = importlib.util.module_from_spec(spec); spec.loader.exec_module(bench)
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(dev)
 out = {}
-side = torch.cuda.Stream()          # stream capture needs a non-default stream
-with torch.cuda.stream(side):
-    for wl in ("er", "scr"):
-        params, model, agent, hw, ncls = bench.build_agent(wl, 3, dev)
-        x, y = bench.synth_u8(14 * params.batch, hw, ncls, 17)
-        np.random.seed(5); random.seed(5); torch.manual_seed(5)
-        agent.train_learner(torch.from_numpy(x).to(dev), y)
-        torch.cuda.synchronize()
-        h = hashlib.sha256()
-        for k, v in model.state_dict().items():
-            h.update(v.detach().cpu().numpy().tobytes())
-        h.update(agent.buffer.buffer_img.detach().cpu().numpy().tobytes())
-        out[wl] = h.hexdigest()
+for wl in ("er", "aser", "scr"):     # (the agents move their loop to a stream of their own when OCL_GRAPH=1: capture needs a non-default stream)
+    params, model, agent, hw, ncls = bench.build_agent(wl, 3, dev)
+    x, y = bench.synth_u8(14 * params.batch, hw, ncls, 17)
+    np.random.seed(5); random.seed(5); torch.manual_seed(5)
+    agent.train_learner(torch.from_numpy(x).to(dev), y)
+    torch.cuda.synchronize()
+    h = hashlib.sha256()
+    for k, v in model.state_dict().items():
+        h.update(v.detach().cpu().numpy().tobytes())
+    h.update(agent.buffer.buffer_img.detach().cpu().numpy().tobytes())
+    h.update(agent.buffer.buffer_label.detach().cpu().numpy().tobytes())
+    out[wl] = h.hexdigest()
 print("DIGEST " + json.dumps(out))
 """
 
 
 def test_launch_sequence_replay_is_schedule_only():
     """OCL_GRAPH=1: the forward / backward launch sequences are captured into hipGraphs at their second occurrence and replayed from
-    then on.  Same kernels, same arguments, order-independent batch sums: 14 ER and 14 SCR steps at BASELINE size end in bit-identical
-    weights, BatchNorm buffers and replay memory with and without the replay; the verbose log must show that sequences WERE captured
-    (on the default stream hipStreamBeginCapture is refused and the engine falls back to ordinary launches)."""
+    then on (single-stream sequences only: the 20-image passes of ER / ASER and ASER's eval-mode scoring passes; SCR's 220-view pass
+    forks to the side stream and keeps its stream launches).  Same kernels, same arguments, order-independent batch sums
+    (OCL_DETERMINISTIC=1): 14 ER, ER + ASER and SCR steps at BASELINE size end in bit-identical weights, BatchNorm buffers and replay
+    memory with and without the replay; the verbose log must show that sequences WERE captured."""
     res = {}
     for flag in ("0", "1"):
         env = dict(os.environ, OCL_GRAPH=flag, OCL_GRAPH_VERBOSE="1", OCL_DETERMINISTIC="1", PYTHONDONTWRITEBYTECODE="1")
