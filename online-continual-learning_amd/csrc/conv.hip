@@ -77,6 +77,10 @@ __device__ __forceinline__ void bn_scale_shift(float gamma, float beta, float me
 //    two atomics per partial sum instead of one: +12 % on the SCR step, +13 % on ER (profiles/r4_batch_sums_ab.txt) -- which is why
 //    it is a mode and not the default.
 __constant__ int g_det_sums = 0;
+// MODE -1: read the flag at run time; 0 / 1: compiled for the default / deterministic mode only (conv_s_kernel: a 96-register kernel
+// that cannot carry both paths without spilling -- its two instantiations are chosen by the host's copy of the flag)
+template <int MODE>
+__device__ __forceinline__ bool fx_det() { return MODE < 0 ? g_det_sums != 0 : MODE == 1; }
 
 __device__ __forceinline__ void fx_split(double v, long long& hi, unsigned long long& lo) {
     if (fabs(v) < 7.0e13) {                                   // (false for NaN / Inf as well)
@@ -89,8 +93,9 @@ __device__ __forceinline__ void fx_split(double v, long long& hi, unsigned long 
         lo = 0ull;
     }
 }
+template <int MODE = -1>
 __device__ __forceinline__ void fx_add(StatCell* cell, double v) {
-    if (!g_det_sums) {
+    if (!fx_det<MODE>()) {
         atomicAdd((double*)&cell->lo, v);
         return;
     }
@@ -100,8 +105,9 @@ __device__ __forceinline__ void fx_add(StatCell* cell, double v) {
     atomicAdd(&cell->lo, lo);
     atomicAdd((unsigned long long*)&cell->hi, (unsigned long long)hi);
 }
+template <int MODE = -1>
 __device__ __forceinline__ double fx_decode(long long hi, unsigned long long lo) {
-    if (!g_det_sums) return __longlong_as_double((long long)lo);
+    if (!fx_det<MODE>()) return __longlong_as_double((long long)lo);
     if (hi >= (1ll << 55) || hi <= -(1ll << 55)) return __builtin_nan("");
     return (double)hi * (1.0 / 256.0) + (double)lo * (1.0 / 1099511627776.0);
 }
@@ -109,27 +115,40 @@ typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
 // the total of a cell's kStatReps replicas (deterministic mode: integer sums, exact in any order; default: the replicas in a fixed
 // order).  All replicas are requested before any is consumed: left to itself the compiler waited for each 16-byte load before issuing
 // the next -- eight dependent L2 round trips in the prologue of every kernel that reads a statistic.
+// B: replicas in flight at once (4 registers each): 8 by default, 4 in conv_s_kernel's prologue (a 96-register kernel: with all
+// sixteen loads of a (sum, sum of squares) pair in flight it spilled 50 VGPRs to scratch)
+template <int B = kStatReps, int MODE = -1>
 __device__ __forceinline__ double fx_total(const StatCell* __restrict__ cells, int64_t rep_stride, int64_t idx) {
-    u64x2_t c[kStatReps];
-#pragma unroll
-    for (int r = 0; r < kStatReps; ++r) c[r] = *(const u64x2_t*)(cells + r * rep_stride + idx);
-    if (!g_det_sums) {
+    static_assert(kStatReps % B == 0, "batch divides the replica count");
+    if (!fx_det<MODE>()) {   // the replicas in a fixed order
         double t = 0.0;
 #pragma unroll
-        for (int r = 0; r < kStatReps; ++r) t += __longlong_as_double((long long)c[r].x);
+        for (int r0 = 0; r0 < kStatReps; r0 += B) {
+            double c[B];
+#pragma unroll
+            for (int r = 0; r < B; ++r) c[r] = *(const double*)&cells[(r0 + r) * rep_stride + idx].lo;
+#pragma unroll
+            for (int r = 0; r < B; ++r) t += c[r];
+        }
         return t;
     }
     long long hi = 0;
     unsigned long long lo = 0;
     bool bad = false;
 #pragma unroll
-    for (int r = 0; r < kStatReps; ++r) {
-        const long long h = (long long)c[r].y;
-        bad |= h >= (1ll << 55) || h <= -(1ll << 55);
-        hi += h;
-        lo += c[r].x;
+    for (int r0 = 0; r0 < kStatReps; r0 += B) {
+        u64x2_t c[B];
+#pragma unroll
+        for (int r = 0; r < B; ++r) c[r] = *(const u64x2_t*)(cells + (r0 + r) * rep_stride + idx);
+#pragma unroll
+        for (int r = 0; r < B; ++r) {
+            const long long h = (long long)c[r].y;
+            bad |= h >= (1ll << 55) || h <= -(1ll << 55);
+            hi += h;
+            lo += c[r].x;
+        }
     }
-    return bad ? __builtin_nan("") : fx_decode(hi, lo);
+    return bad ? __builtin_nan("") : fx_decode<MODE>(hi, lo);
 }
 // two totals at once: all 2 * kStatReps loads in flight together
 __device__ __forceinline__ void fx_total2(const StatCell* __restrict__ cells, int64_t rep_stride, int64_t idx1, int64_t idx2, double& t1, double& t2) {
@@ -193,24 +212,33 @@ __device__ __forceinline__ double fx_total_atomic(const StatCell* cells, int64_t
     }
     return bad ? __builtin_nan("") : fx_decode(hi, lo);
 }
+static int g_det_host = 0;   // the host's copy of g_det_sums (conv_s_kernel's instantiation is chosen by it)
 int set_deterministic_sums(int on) {
     const int v = on ? 1 : 0;
+    g_det_host = v;
     OCL_HIP(hipDeviceSynchronize());   // (no launch may straddle the switch: the cells are interpreted by the flag)
     OCL_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_det_sums), &v, sizeof(int)));
     return OCL_OK;
 }
 
 // mean / invstd of (group g, channel c) from the replicated batch sums (biased variance, nn.BatchNorm2d's normalisation)
+template <int B = 2 * kStatReps, int MODE = -1>   // replica loads in flight (see fx_total)
 __device__ __forceinline__ void bn_batch_moments(const StatCell* __restrict__ stats, int64_t rep_stride, int g, int c, int C, double M, float eps,
                                                  double& mean, double& var) {
     double s1, s2;
-    fx_total2(stats, rep_stride, ((int64_t)g * 2 + 0) * C + c, ((int64_t)g * 2 + 1) * C + c, s1, s2);
+    if constexpr (B >= 2 * kStatReps) {
+        fx_total2(stats, rep_stride, ((int64_t)g * 2 + 0) * C + c, ((int64_t)g * 2 + 1) * C + c, s1, s2);
+    } else {
+        s1 = fx_total<B, MODE>(stats, rep_stride, ((int64_t)g * 2 + 0) * C + c);
+        s2 = fx_total<B, MODE>(stats, rep_stride, ((int64_t)g * 2 + 1) * C + c);
+    }
     mean = s1 / M;
     var = s2 / M - mean * mean;
     if (var < 0.0) var = 0.0;
     (void)eps;
 }
 // running statistics: one update per group, in order (= the reference's separate forward calls), unbiased variance, momentum
+template <int MODE = -1>
 __device__ __forceinline__ void bn_running_update(const StatCell* __restrict__ stats, int64_t rep_stride, int G, int C, double M, float momentum,
                                                   float eps, float* __restrict__ running_mean, float* __restrict__ running_var,
                                                   int64_t* __restrict__ nbt, int tid, int nthreads) {
@@ -218,7 +246,7 @@ __device__ __forceinline__ void bn_running_update(const StatCell* __restrict__ s
         float rm = running_mean[c], rv = running_var[c];
         for (int gg = 0; gg < G; ++gg) {
             double mean, var;
-            bn_batch_moments(stats, rep_stride, gg, c, C, M, eps, mean, var);
+            bn_batch_moments<1, MODE>(stats, rep_stride, gg, c, C, M, eps, mean, var);   // (one workgroup per launch runs this: few loads in flight, few registers)
             const double unb = M > 1.0 ? var * M / (M - 1.0) : var;
             rm = momentum * (float)mean + (1.f - momentum) * rm;
             rv = momentum * (float)unb + (1.f - momentum) * rv;
@@ -1280,8 +1308,9 @@ __global__ void __launch_bounds__(256, 2) conv_q_kernel(const ConvArgs a) {
 // The kernel must stay free of scratch: a build with 10 spilled VGPRs was 1 - 4 us per launch slower than the one before it.
 constexpr int kDepthS = 4;    // weight rounds in flight per wave
 constexpr int kPFS = 7;       // patch units (16 bytes) per lane and staging pass: a wave stages 448 units per pass (layer 4 needs 360 - 405; 8 would spill at 96 VGPRs)
-template <int NT, bool TRACE, bool BNB = false>   // BNB: instantiated with the EPI_BNB epilogue
+template <int NT, bool TRACE, bool BNB = false, bool DET = false>   // BNB: instantiated with the EPI_BNB epilogue; DET: for the deterministic batch sums
 __global__ void __launch_bounds__(256, NT == 1 ? 5 : 4) conv_s_kernel(const ConvArgs a) {
+    constexpr int FXM = DET ? 1 : 0;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     int* ctab = (int*)lds_raw;
     int* qoff = ctab + 16;                           // [4][Qpad / 4] patch offset of group q = 4 rho + g, stored [g][rho] (one wave's channel slice)
@@ -1359,7 +1388,7 @@ __global__ void __launch_bounds__(256, NT == 1 ? 5 : 4) conv_s_kernel(const Conv
         for (int j = tid; j < a.groups * C; j += 256) {
             const int gq = j / C, c = j - gq * C;
             double mean, var;
-            bn_batch_moments(a.xf_stats, a.xf_rep_stride, gq, c, C, M, a.xf_eps, mean, var);
+            bn_batch_moments<1, FXM>(a.xf_stats, a.xf_rep_stride, gq, c, C, M, a.xf_eps, mean, var);
             const double xv = var + (double)a.xf_eps;
             double invstd = (double)rsqrtf((float)xv);
             invstd = invstd * (1.5 - 0.5 * xv * invstd * invstd);
@@ -1375,7 +1404,7 @@ __global__ void __launch_bounds__(256, NT == 1 ? 5 : 4) conv_s_kernel(const Conv
             }
         }
         if (lead && a.xf_running_mean)
-            bn_running_update(a.xf_stats, a.xf_rep_stride, a.groups, C, M, a.xf_momentum, a.xf_eps, a.xf_running_mean, a.xf_running_var, a.xf_nbt, tid, 256);
+            bn_running_update<FXM>(a.xf_stats, a.xf_rep_stride, a.groups, C, M, a.xf_momentum, a.xf_eps, a.xf_running_mean, a.xf_running_var, a.xf_nbt, tid, 256);
     }
     stamp(1);
     const int nr = a.Qpad >> 2;                      // rounds of 4 groups; a multiple of 4 (the planner pads with zero-weight groups)
@@ -1507,11 +1536,11 @@ __global__ void __launch_bounds__(256, NT == 1 ? 5 : 4) conv_s_kernel(const Conv
         const float4 z = live ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         const float s1x = row16_sum(z.x), s1y = row16_sum(z.y), s1z = row16_sum(z.z), s1w = row16_sum(z.w);
         const float s2x = row16_sum(z.x * z.x), s2y = row16_sum(z.y * z.y), s2z = row16_sum(z.z * z.z), s2w = row16_sum(z.w * z.w);
-        if (r16 == 0 && co < a.Cout) {
+        if (r16 < 8 && co < a.Cout) {   // (every lane of the row holds the eight sums: lane j adds sum j -- one accumulation per lane)
+            const int j = r16;
+            const float v = j == 0 ? s1x : j == 1 ? s1y : j == 2 ? s1z : j == 3 ? s1w : j == 4 ? s2x : j == 5 ? s2y : j == 6 ? s2z : s2w;
             StatCell* st_ = a.stats + (int64_t)((blockIdx.x + blockIdx.y + wave) % kStatReps) * a.stat_rep_stride + ((int64_t)d1.y * 2) * a.Cout + co;
-            fx_add(st_ + 0, (double)s1x); fx_add(st_ + 1, (double)s1y); fx_add(st_ + 2, (double)s1z); fx_add(st_ + 3, (double)s1w);
-            fx_add(st_ + a.Cout + 0, (double)s2x); fx_add(st_ + a.Cout + 1, (double)s2y);
-            fx_add(st_ + a.Cout + 2, (double)s2z); fx_add(st_ + a.Cout + 3, (double)s2w);
+            fx_add<FXM>(st_ + (j >> 2) * a.Cout + (j & 3), (double)v);
         }
     }
     float* op = a.out + (int64_t)oo + co;
@@ -1550,11 +1579,11 @@ __global__ void __launch_bounds__(256, NT == 1 ? 5 : 4) conv_s_kernel(const Conv
         }
         const float s1x = row16_sum(b1[0]), s1y = row16_sum(b1[1]), s1z = row16_sum(b1[2]), s1w = row16_sum(b1[3]);
         const float s2x = row16_sum(b2[0]), s2y = row16_sum(b2[1]), s2z = row16_sum(b2[2]), s2w = row16_sum(b2[3]);
-        if (r16 == 0 && co < a.Cout) {
+        if (r16 < 8 && co < a.Cout) {   // (every lane of the row holds the eight sums: lane j adds sum j -- one accumulation per lane)
+            const int j = r16;
+            const float v = j == 0 ? s1x : j == 1 ? s1y : j == 2 ? s1z : j == 3 ? s1w : j == 4 ? s2x : j == 5 ? s2y : j == 6 ? s2z : s2w;
             StatCell* st_ = a.stats + (int64_t)((blockIdx.x + blockIdx.y + wave) % kStatReps) * a.stat_rep_stride + ((int64_t)d1.y * 2) * a.Cout + co;
-            fx_add(st_ + 0, (double)s1x); fx_add(st_ + 1, (double)s1y); fx_add(st_ + 2, (double)s1z); fx_add(st_ + 3, (double)s1w);
-            fx_add(st_ + a.Cout + 0, (double)s2x); fx_add(st_ + a.Cout + 1, (double)s2y);
-            fx_add(st_ + a.Cout + 2, (double)s2z); fx_add(st_ + a.Cout + 3, (double)s2w);
+            fx_add<FXM>(st_ + (j >> 2) * a.Cout + (j & 3), (double)v);
         }
     }
     if (!live) return;
@@ -1566,7 +1595,11 @@ __global__ void __launch_bounds__(256, NT == 1 ? 5 : 4) conv_s_kernel(const Conv
 }
 
 typedef void (*conv_fn_t)(const ConvArgs);
-static conv_fn_t convs_fn(int nt, bool trace = false, bool bnb = false) {
+static conv_fn_t convs_fn(int nt, bool trace = false, bool bnb = false, bool det = false) {
+    if (det) {
+        if (bnb) return nt == 2 ? conv_s_kernel<2, false, true, true> : conv_s_kernel<1, false, true, true>;
+        return nt == 2 ? conv_s_kernel<2, false, false, true> : conv_s_kernel<1, false, false, true>;
+    }
     if (bnb) return nt == 2 ? conv_s_kernel<2, false, true> : conv_s_kernel<1, false, true>;
     if (trace) return nt == 2 ? conv_s_kernel<2, true> : conv_s_kernel<1, true>;
     return nt == 2 ? conv_s_kernel<2, false> : conv_s_kernel<1, false>;
@@ -2268,7 +2301,8 @@ int launch_conv(const ConvPlan& p, hipStream_t s) {
             return OCL_ERR_STATE;
         }
         ProfScope ps(PROF_CONV, s);
-        hipLaunchKernelGGL(convs_fn(p.NT, p.a.trace != nullptr, (p.a.flags & EPI_BNB) != 0), dim3(p.grid_x, p.grid_y), dim3(256), p.lds_bytes, s, p.a);
+        hipLaunchKernelGGL(convs_fn(p.NT, p.a.trace != nullptr && !g_det_host, (p.a.flags & EPI_BNB) != 0, g_det_host != 0), dim3(p.grid_x, p.grid_y), dim3(256),
+                           p.lds_bytes, s, p.a);
         OCL_LAUNCH_CHECK();
         return OCL_OK;
     }
@@ -3601,7 +3635,9 @@ int conv_kernels_init() {
             OCL_HIP(hipFuncSetAttribute((const void*)convt_fn(m, 1, pf, 0, 0, 1, 1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
         }
     for (int nt = 1; nt <= 2; ++nt)
-        OCL_HIP(hipFuncSetAttribute((const void*)convs_fn(nt, false, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+        for (int det = 0; det < 2; ++det)
+            for (int bnb = det ? 0 : 1; bnb < 2; ++bnb)
+                OCL_HIP(hipFuncSetAttribute((const void*)convs_fn(nt, false, bnb != 0, det != 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     for (int st = 0; st < 3; ++st) {
         OCL_HIP(hipFuncSetAttribute((const void*)convq_fn(2, 4, st), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
         OCL_HIP(hipFuncSetAttribute((const void*)convq_fn(2, 12, st), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
