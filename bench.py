@@ -104,13 +104,8 @@ def pmc_traffic(kernel):
 
 
 def _pci_dir(index):
-    """sysfs directory of the PCI function behind torch device `index` (HIP_VISIBLE_DEVICES already applied), or None."""
-    try:
-        p = torch.cuda.get_device_properties(index)
-        d = "/sys/bus/pci/devices/%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
-        return d if os.path.isdir(d) else None
-    except Exception:
-        return None
+    from ocl_amd import dist as odist
+    return odist._pci_dir(index)
 
 
 def _read(path):
@@ -162,38 +157,6 @@ def gpu_env_static(index):
         if cap:
             out["power_cap_w"] = int(cap) / 1e6
     return out
-
-
-def pin_to_gpu_numa(local, n_local):
-    """Rank placement for --gpus N (one Python launch loop per GPU, ~150 launches per 2 ms step each): the rank's threads go to the
-    CPUs of its GPU's NUMA node (sysfs local_cpulist), and the ranks whose GPUs share a node split that list into disjoint slices.
-    Returns the CPU set taken (None when sysfs does not say: nothing is pinned)."""
-    try:
-        d = _pci_dir(local)
-        txt = _read(os.path.join(d, "local_cpulist")) if d else None
-        if not txt or not hasattr(os, "sched_setaffinity"):
-            return None
-        cpus = []
-        for part in txt.strip().split(","):
-            a, _, b = part.partition("-")
-            cpus += list(range(int(a), int(b or a) + 1))
-        allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
-        if not allowed:
-            return None
-        peers = []
-        for r in range(min(n_local, torch.cuda.device_count())):
-            dr = _pci_dir(r)
-            if dr and _read(os.path.join(dr, "local_cpulist")) == txt:
-                peers.append(r)
-        if local not in peers:
-            return None
-        k, n = peers.index(local), len(peers)
-        per = max(1, len(allowed) // n)
-        mine = allowed[k * per:(k + 1) * per] or allowed
-        os.sched_setaffinity(0, mine)
-        return mine
-    except Exception:
-        return None
 
 
 def build_agent(workload, seed, device):
@@ -511,17 +474,24 @@ def accuracy_oracle_worker(seed, kind, threads):
     print(json.dumps(dict(acc=np.array(accs).tolist(), wall_s=time.perf_counter() - t0)))
 
 
-def accuracy_oracle(seeds, threads):
+def accuracy_oracle_start(seeds, threads):
     """The same streams through the CPU oracle (identity augmentation), rank 0 at N = 1 only: one process per (stream kind, seed),
-    all at once on the host cores (test infrastructure: the checker, not the thing measured)."""
+    all at once on the host cores (test infrastructure: the checker, not the thing measured).  Started AFTER every timed GPU leg and
+    the cpu_baseline sample, so that the HIP accuracy runs (not timing-critical) overlap the oracle's ~5 minutes."""
     import subprocess
     t0 = time.perf_counter()
-    # every seed of the smooth and texture streams (the spread over the seeds is the yardstick for the augmentation comparison), the
-    # first seed of the white-noise stream (the like-for-like check of the identity-augmentation run): seven concurrent runs
-    todo = {"smooth_prototype": list(seeds), "noise_prototype": list(seeds[:1]), "texture_prototype": list(seeds)}
+    # every seed of the texture stream (the spread over the seeds is the yardstick for the augmentation comparison on the stream where the
+    # augmentation must not hurt), the first seed of the white-noise and smooth streams (the like-for-like check of the identity-
+    # augmentation runs): five concurrent runs
+    todo = {"smooth_prototype": list(seeds[:1]), "noise_prototype": list(seeds[:1]), "texture_prototype": list(seeds)}
     procs = {(k, s): subprocess.Popen([sys.executable, os.path.abspath(__file__), "--oracle-accuracy-worker", str(s), k, str(threads)],
                                       stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=dict(os.environ, OMP_NUM_THREADS=str(threads)))
              for k in ACC_STREAMS for s in todo[k]}
+    return procs, todo, t0, threads
+
+
+def accuracy_oracle_finish(handle):
+    procs, todo, t0, threads = handle
     res = {k: json.loads(p.communicate()[0].strip().splitlines()[-1]) for k, p in procs.items()}
     out = {}
     for kind in ACC_STREAMS:
@@ -621,7 +591,8 @@ def main():
     rank, world, local = odist.init_from_env()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    pinned = pin_to_gpu_numa(local, int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))) if world > 1 else None
+    # every rank (also the single one) goes to the CPUs of its GPU's NUMA node before the first model is built (dist.pin_to_gpu_numa)
+    pinned = odist.pin_to_gpu_numa(local, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
     import contextlib
     also, acc_res, acc_seeds = {}, None, None
     with contextlib.redirect_stdout(sys.stderr):   # the agents print like the reference ("buffer has N slots"): stdout carries the JSON only
@@ -631,8 +602,15 @@ def main():
         if args.workload == "scr" and not args.no_also and world == 1:
             for wl in ("aser", "er", "mir"):
                 also[wl] = gpu_leg(args, rank, world, local, workload=wl, steps=args.also_steps, warmup=10)
-        if not args.no_accuracy and world == 1:
-            acc_res, acc_seeds = accuracy_leg(args, rank, world, local)
+    cpu_line, oracle_handle = None, None
+    if rank == 0 and world == 1:
+        with contextlib.redirect_stdout(sys.stderr):
+            if not args.no_cpu_baseline:
+                cpu_line = cpu_leg(args)        # (before the oracle's accuracy processes take the host cores)
+            if not args.no_accuracy:
+                if not args.no_cpu_baseline:
+                    oracle_handle = accuracy_oracle_start([odist.run_seed(args.seed, rank) + 100 * i for i in range(ACC_CFG["seeds"])], 8)
+                acc_res, acc_seeds = accuracy_leg(args, rank, world, local)
     if rank != 0:
         return
     w = WORKLOADS[args.workload]
@@ -665,14 +643,12 @@ def main():
                    "stream_batch": bs, "images_through_network_per_step": {"scr": 220, "aser": 610, "er": 20, "mir": 120}[args.workload],
                    "parallelism": "%d independent stream(s), one per GPU" % world},
     }
-    if world > 1:
-        line["config"]["rank_placement"] = ("each rank pinned to a disjoint slice of its GPU's NUMA-local CPUs (rank 0: %d CPUs)" % len(pinned)
-                                            if pinned else "not pinned (sysfs gave no local_cpulist)")
+    line["config"]["rank_placement"] = ("each rank pinned to a disjoint slice of its GPU's NUMA-local CPUs (rank 0: %d CPUs, first %d)" % (len(pinned), pinned[0])
+                                        if pinned else "not pinned (OCL_PIN=0, or sysfs gave no local_cpulist)")
     if "roofline" in res:
         line["roofline"] = res["roofline"]
-    if not args.no_cpu_baseline and world == 1:
-        with contextlib.redirect_stdout(sys.stderr):
-            line["cpu_baseline"] = cpu_leg(args)
+    if cpu_line is not None:
+        line["cpu_baseline"] = cpu_line
     if also:
         names = {"aser": ("ER + ASER retrieve / update, Split-CIFAR100-shaped synthetic stream, mem_size 5000, k 3", 2, 610),
                  "er": ("ER random / random, Split-CIFAR10-shaped synthetic stream, mem_size 1000", 0, 20),
@@ -691,8 +667,8 @@ def main():
                                                     "avg_launch_us", "launches_per_step", "algorithmic_gflop_per_step", "whole_step_frac",
                                                     "wgrad", "knn_buffer", "per_step_ms", "launches_per_step_all")} if rf else None}
     if acc_res is not None:
-        if world == 1 and not args.no_cpu_baseline:
-            orc = accuracy_oracle(acc_seeds, 8)   # 6 concurrent runs (2 streams x 3 seeds) x 8 intra-op threads
+        if oracle_handle is not None:
+            orc = accuracy_oracle_finish(oracle_handle)   # 5 concurrent runs x 8 intra-op threads, started before the HIP accuracy runs
             acc_res["cpu_oracle"] = orc
             for kind in ACC_STREAMS:
                 h, hi, o = acc_res[kind]["hip"], acc_res[kind]["hip_identity_augmentation"], orc[kind]

@@ -92,3 +92,60 @@ def sum_over_ranks(value, device=None):
         t = t.to(device or torch.device("cuda", torch.cuda.current_device()))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
+
+
+# ---- rank / process placement -------------------------------------------------------------------------------------------------------
+def _pci_dir(index):
+    """sysfs directory of the PCI function behind torch device `index` (HIP_VISIBLE_DEVICES already applied), or None."""
+    try:
+        p = torch.cuda.get_device_properties(index)
+        d = "/sys/bus/pci/devices/%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        return d if os.path.isdir(d) else None
+    except Exception:
+        return None
+
+
+def _read(path):
+    try:
+        with open(path) as f:
+            return f.read()
+    except Exception:
+        return None
+
+
+def pin_to_gpu_numa(local=0, n_local=1):
+    """Pins the calling process to the CPUs of its GPU's NUMA node (sysfs local_cpulist of the GPU's PCI function); ranks whose GPUs
+    share a node split that list into disjoint slices.  Why: the step is ~150 kernel launches per 2 ms from one Python thread; kernel
+    arguments, doorbells and the pinned staging ring live in host memory that is first touched by this process -- from the far socket
+    every launch pays a cross-socket hop (leases whose GPU hangs off the other socket ran the same tree 12 - 17 % slower, the small
+    launch-latency-bound kernels 40 - 100 %: DESIGN.md section 7).  Call it before the first model is built (the runtime's queues and
+    the kernel-argument pools are created on first use).  Returns the CPU list taken, or None when sysfs does not say (nothing is
+    pinned).  OCL_PIN=0 disables it."""
+    if os.environ.get("OCL_PIN", "1") == "0":
+        return None
+    try:
+        d = _pci_dir(local)
+        txt = _read(os.path.join(d, "local_cpulist")) if d else None
+        if not txt or not hasattr(os, "sched_setaffinity"):
+            return None
+        cpus = []
+        for part in txt.strip().split(","):
+            a, _, b = part.partition("-")
+            cpus += list(range(int(a), int(b or a) + 1))
+        allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
+        if not allowed:
+            return None
+        peers = []
+        for r in range(min(max(1, n_local), torch.cuda.device_count())):
+            dr = _pci_dir(r)
+            if dr and _read(os.path.join(dr, "local_cpulist")) == txt:
+                peers.append(r)
+        if local not in peers:
+            peers = [local]
+        k, n = peers.index(local), len(peers)
+        per = max(1, len(allowed) // n)
+        mine = allowed[k * per:(k + 1) * per] or allowed
+        os.sched_setaffinity(0, mine)
+        return mine
+    except Exception:
+        return None

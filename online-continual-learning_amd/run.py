@@ -41,6 +41,8 @@ def sharded_runs(params, make_stream_fn, base_seed=0):
     """Each rank performs ONE independent run (seed base+rank), then the accuracy arrays are all-gathered and every
     rank computes the reference's summary metrics."""
     rank, world, local = odist.init_from_env()
+    import os
+    odist.pin_to_gpu_numa(local, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))   # this rank's launch loop next to its GPU
     seed = odist.run_seed(base_seed, rank)
     tasks, tests = make_stream_fn(seed)
     acc, t_train, n_img, _ = single_run(params, tasks, tests, seed)
