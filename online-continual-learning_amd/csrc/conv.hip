@@ -2818,7 +2818,8 @@ int launch_pack_weights(const float* params, float* arena, const PackDesc* descs
                         int mask, StatCell* zero_a, int64_t zero_a_n, StatCell* zero_b, int64_t zero_b_n) {
     ProfScope ps(PROF_BN, s);
     const int extra = (zero_a_n + zero_b_n) > 0 ? 1 : 0;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(std::min(64, cdiv(max_elems, 256)), n_layers + extra), dim3(256), 0, s, params, arena,
+    // (up to 256 workgroups per layer: layer 4's 230 k weights in 4 passes per thread instead of 14)
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(std::min(256, cdiv(max_elems, 256)), n_layers + extra), dim3(256), 0, s, params, arena,
                        descs_dev, mask, n_layers, zero_a, zero_a_n, zero_b, zero_b_n);
     OCL_LAUNCH_CHECK();
     return OCL_OK;
