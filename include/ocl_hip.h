@@ -47,6 +47,12 @@ int ocl_gather_rows(const void* src, const int64_t* idx, int64_t n, int64_t row_
                     void* stream);
 int ocl_scatter_rows(void* dst, const int64_t* idx, int64_t n, int64_t row_bytes, const void* src,
                      void* stream);
+/* The pair buffer.buffer_img[indices], buffer.buffer_label[indices] of every retrieval (utils/buffer/buffer_utils.py:19-21,115-116;
+ * utils/buffer/aser_utils.py:152-155) as ONE call and one launch: rows of two arrays by the same index vector.  idx_host != NULL:
+ * the indices were drawn on the host (numpy / torch-CPU generators); they are uploaded into idx_dev (n int64, caller-owned) first,
+ * asynchronously.  idx_host == NULL: idx_dev already holds them (e.g. the ranking of ocl_argsort_desc). */
+int ocl_gather_rows_pair(const void* src_a, int64_t row_bytes_a, void* dst_a, const void* src_b, int64_t row_bytes_b, void* dst_b,
+                         const int64_t* idx_host, int64_t* idx_dev, int64_t n, void* stream);
 /* Host -> device upload of a small host array (index vectors the reference builds with torch.tensor(...) / torch.from_numpy(...)
  * and moves with maybe_cuda: utils/buffer/buffer_utils.py:17-21, reservoir_update.py:52-60).  Asynchronous on `stream`; `host`
  * may be reused as soon as the call returns (payloads <= 64 KB are staged through pinned memory). */

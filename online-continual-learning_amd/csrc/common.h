@@ -58,6 +58,8 @@ struct ProfScope {
 enum AsyncErr : unsigned { ASYNC_ERR_BN_BARRIER = 1u };
 unsigned* async_error_word_device();        // device-visible address (nullptr if the allocation failed)
 int check_async_error(const char* where);   // OCL_OK, or OCL_ERR_STATE with the message set and the word cleared
+// small host -> device upload through the pinned staging ring (runtime.hip): asynchronous on `s`, `host` reusable on return
+int upload_small(const void* host, size_t nbytes, void* dev, hipStream_t s);
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }

@@ -52,6 +52,19 @@ static int rows_copy(const void* src, const int64_t* idx, int64_t n, int64_t row
     return OCL_OK;
 }
 
+// rows of TWO arrays by one index vector in one launch (replay-buffer images + their labels: every retrieval of the reference is the
+// pair buffer_img[indices], buffer_label[indices]): a in 16-byte units over grid.y, b (a few bytes per row) by the first block of the row
+__global__ void __launch_bounds__(256) rows_gather_pair(const uint4* __restrict__ a, uint4* __restrict__ da, int64_t units_a,
+                                                        const uint32_t* __restrict__ b, uint32_t* __restrict__ db, int64_t units_b,
+                                                        const int64_t* __restrict__ idx) {
+    const int64_t r = blockIdx.x;
+    const int64_t row = idx[r];
+    for (int64_t u = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; u < units_a; u += (int64_t)gridDim.y * blockDim.x)
+        da[r * units_a + u] = a[row * units_a + u];
+    if (blockIdx.y == 0)
+        for (int64_t u = threadIdx.x; u < units_b; u += blockDim.x) db[r * units_b + u] = b[row * units_b + u];
+}
+
 __global__ void __launch_bounds__(256) gather_u8_hwc_f32_chw(const uint8_t* __restrict__ src, const int64_t* __restrict__ idx,
                                                              int h, int w, int c, float* __restrict__ dst) {
     const int64_t r = blockIdx.x;
@@ -876,6 +889,32 @@ int ocl_gather_rows(const void* src, const int64_t* idx, int64_t n, int64_t row_
 }
 int ocl_scatter_rows(void* dst, const int64_t* idx, int64_t n, int64_t row_bytes, const void* src, void* stream) {
     return rows_copy<true>(src, idx, n, row_bytes, dst, stream);
+}
+
+int ocl_gather_rows_pair(const void* src_a, int64_t row_bytes_a, void* dst_a, const void* src_b, int64_t row_bytes_b, void* dst_b,
+                         const int64_t* idx_host, int64_t* idx_dev, int64_t n, void* stream) {
+    OCL_REQUIRE(n >= 0 && row_bytes_a > 0 && row_bytes_b > 0 && (row_bytes_a % 4) == 0 && (row_bytes_b % 4) == 0,
+                "gather_rows_pair: n=%lld row bytes %lld / %lld (must be > 0, %%4)", (long long)n, (long long)row_bytes_a, (long long)row_bytes_b);
+    if (n == 0) return OCL_OK;
+    OCL_REQUIRE(src_a && dst_a && src_b && dst_b && idx_dev, "gather_rows_pair: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (idx_host) {   // the index vector was built on the host (numpy / torch-CPU RNG draws): upload it here, through the staging ring
+        int rc = ocl::upload_small(idx_host, (size_t)n * sizeof(int64_t), idx_dev, s);
+        if (rc != OCL_OK) return rc;
+    }
+    const bool v16 = (row_bytes_a % 16) == 0 && (((uintptr_t)src_a | (uintptr_t)dst_a) % 16) == 0;
+    if (!v16) {
+        int rc = rows_copy<false>(src_a, idx_dev, n, row_bytes_a, dst_a, stream);
+        if (rc != OCL_OK) return rc;
+        return rows_copy<false>(src_b, idx_dev, n, row_bytes_b, dst_b, stream);
+    }
+    ProfScope ps(PROF_KNN, s);
+    const int64_t units = row_bytes_a / 16;
+    dim3 grid((unsigned)n, (unsigned)max((int64_t)1, min((int64_t)8, (units + 1023) / 1024)));
+    hipLaunchKernelGGL(rows_gather_pair, grid, dim3(256), 0, s, (const uint4*)src_a, (uint4*)dst_a, units, (const uint32_t*)src_b,
+                       (uint32_t*)dst_b, row_bytes_b / 4, idx_dev);
+    OCL_LAUNCH_CHECK();
+    return OCL_OK;
 }
 
 int ocl_gather_u8_hwc_to_f32_chw(const uint8_t* src, const int64_t* idx, int64_t n, int h, int w, int c, float* dst,

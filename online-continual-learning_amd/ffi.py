@@ -33,6 +33,7 @@ SIGNATURES = {
     "ocl_upload": (C.c_int, [vp, i64, vp, vp]),
     "ocl_gather_rows": (C.c_int, [vp, vp, i64, i64, vp, vp]),
     "ocl_scatter_rows": (C.c_int, [vp, vp, i64, i64, vp, vp]),
+    "ocl_gather_rows_pair": (C.c_int, [vp, i64, vp, vp, i64, vp, vp, vp, i64, vp]),
     "ocl_gather_u8_hwc_to_f32_chw": (C.c_int, [vp, vp, i64, C.c_int, C.c_int, C.c_int, vp, vp]),
     "ocl_sgd_step": (C.c_int, [vp, vp, i64, f32, f32, f32, vp, vp]),
     "ocl_ce_fwd_bwd": (C.c_int, [vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]),

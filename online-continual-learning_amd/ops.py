@@ -71,6 +71,36 @@ def gather_rows(src, idx, out=None):
     return out
 
 
+def gather_pair(src_a, src_b, idx):
+    """(src_a[idx], src_b[idx]) -- replay-buffer images and labels by one index vector -- as ONE call and one launch.  idx: an int64
+    tensor on the host (the usual case: indices drawn by the numpy / torch-CPU generators; uploaded inside the call) or on the device."""
+    ffi.init()
+    n = idx.numel()
+    dev = src_a.device
+    out_a = torch.empty((n,) + tuple(src_a.shape[1:]), dtype=src_a.dtype, device=dev)
+    out_b = torch.empty((n,) + tuple(src_b.shape[1:]), dtype=src_b.dtype, device=dev)
+    if n == 0:
+        return out_a, out_b
+    if not (src_a.is_contiguous() and src_b.is_contiguous()):
+        raise RuntimeError("gather_pair: sources must be contiguous")
+    rb_a = src_a[0].numel() * src_a.element_size()
+    rb_b = src_b[0].numel() * src_b.element_size()
+    if idx.is_cuda:
+        idx = _i64(idx)
+        host_ptr, idx_dev = ffi.vp(0), idx
+    else:
+        idx = idx.contiguous()
+        if idx.dtype != torch.int64:
+            raise RuntimeError("gather_pair: int64 indices")
+        host_ptr, idx_dev = ffi.vp(idx.data_ptr()), torch.empty(n, dtype=torch.int64, device=dev)
+    if dev.index != torch._C._cuda_getDevice():
+        with torch.cuda.device(dev):
+            return gather_pair(src_a, src_b, idx)
+    ffi.check(ffi.lib().ocl_gather_rows_pair(ffi.ptr(src_a), rb_a, ffi.ptr(out_a), ffi.ptr(src_b), rb_b, ffi.ptr(out_b), host_ptr,
+                                             ffi.ptr(idx_dev), n, ffi.stream()), "gather_rows_pair")
+    return out_a, out_b
+
+
 def scatter_rows(dst, idx, src):
     """dst[idx] = src (utils/buffer/reservoir_update.py:59-60)."""
     ffi.init()

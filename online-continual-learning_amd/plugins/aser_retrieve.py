@@ -58,4 +58,4 @@ class ASER_retrieve(object):
         if trace:
             debug.emit("aser_retrieve", cand_ind=cand_slots.numpy().copy(), sv=score.cpu().numpy(), ret=cand_slots[best.cpu()].numpy(),
                        order_adv=order_adv.cpu().numpy(), order_coop=None if order_coop is None else order_coop.cpu().numpy())
-        return ops.gather_rows(cand_x, best), ops.gather_rows(cand_y, best)
+        return ops.gather_pair(cand_x, cand_y, best)

@@ -103,7 +103,8 @@ class ASER_update(object):
         ClassBalancedRandomSampling.update_cache(buffer.label_host, self.out_dim, new_y=new_labels, ind=leaving.tolist(), device=self.device)
         if leaving.numel():
             dev = buffer.buffer_img.device
-            src, dst = ops.upload(entering, dev), ops.upload(leaving, dev)
-            ops.scatter_rows(buffer.buffer_img, dst, ops.gather_rows(cur_x, src))
-            ops.scatter_rows(buffer.buffer_label, dst, ops.gather_rows(cur_y, src))
+            dst = ops.upload(leaving, dev)
+            new_x, new_y = ops.gather_pair(cur_x, cur_y, entering)
+            ops.scatter_rows(buffer.buffer_img, dst, new_x)
+            ops.scatter_rows(buffer.buffer_label, dst, new_y)
             buffer.label_host[leaving.numpy()] = new_labels

@@ -60,7 +60,5 @@ def add_minority_class_input(cur_x, cur_y, mem_size, num_class, cur_y_host=None)
     cur_y_cpu = torch.from_numpy(_host_labels(cur_y, cur_y_host))
     minority_ind = nonzero_indices(cls_proportion[cur_y_cpu] < threshold)
 
-    ind_dev = ops.upload(minority_ind, cur_x.device)
-    minority_batch_x = ops.gather_rows(cur_x.contiguous(), ind_dev)
-    minority_batch_y = ops.gather_rows(cur_y.contiguous(), ind_dev)
+    minority_batch_x, minority_batch_y = ops.gather_pair(cur_x.contiguous(), cur_y.contiguous(), minority_ind)
     return minority_batch_x, minority_batch_y

@@ -62,9 +62,7 @@ def random_retrieve(buffer, num_retrieve, excl_indices=None, return_indices=Fals
     indices = torch.from_numpy(np.random.choice(valid_indices, num_retrieve, replace=False)).long()
 
     debug.emit("random_retrieve", indices=indices.numpy().copy())
-    idx_dev = ops.upload(indices, buffer.buffer_img.device)
-    x = ops.gather_rows(buffer.buffer_img, idx_dev)
-    y = ops.gather_rows(buffer.buffer_label, idx_dev)
+    x, y = ops.gather_pair(buffer.buffer_img, buffer.buffer_label, indices)   # (index upload + both gathers: one call, one launch)
     y.host = buffer.label_host[indices.numpy()] if num_retrieve else np.zeros(0, dtype=np.int64)
 
     if return_indices:
@@ -184,9 +182,7 @@ class ClassBalancedRandomSampling:
         """Up to n_smp_cls slots of every class present, excluding `excl_indices` -> (x, y, slot indices [host])."""
         sample_ind = cls.draw_fast(n_smp_cls, excl_indices)
 
-        idx_dev = ops.upload(sample_ind, buffer_x.device)
-        x = ops.gather_rows(buffer_x, idx_dev)
-        y = ops.gather_rows(buffer_y, idx_dev)
+        x, y = ops.gather_pair(buffer_x, buffer_y, sample_ind)
         if label_host is not None:
             y.host = label_host[sample_ind.numpy()]
         return x, y, sample_ind
