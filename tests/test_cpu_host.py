@@ -339,3 +339,36 @@ def test_class_balanced_draw_memo_survives_mutations_outside_update_cache():
         assert torch.equal(torch.get_rng_state(), s_py)  # ... from the same generator state
     finally:
         C.class_index_cache, C.class_num_cache = saved
+
+
+def test_texture_accuracy_stream_is_flip_invariant_and_class_separable():
+    """bench.py's `texture_prototype` stream (the stream on which the SCR augmentation must not hurt): 100 classes of luminance plaids.
+    By construction a class is a set of (+-theta pair, frequency band, waveform) components, so a horizontal flip maps every class to
+    itself and position / phase carry no label information: a nearest-class-mean rule on the (translation-invariant) magnitude spectrum
+    separates the classes, does equally well on the mirrored test images, and fails on the raw pixels (no fixed pixel pattern to
+    memorise).  All three channels are equal (hue / saturation jitter and grayscale are neutral)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    specs = bench.texture_classes(100)
+    assert len(specs) == 100 and len(set(specs)) == 100
+    tasks, tests = bench.accuracy_stream(0, 10, 10, 30, 10, 0.3, kind="texture_prototype")
+    x = np.concatenate([t[0] for t in tasks]); y = np.concatenate([t[1] for t in tasks])
+    xt = np.concatenate([t[0] for t in tests]); yt = np.concatenate([t[1] for t in tests])
+    assert x.dtype == np.uint8 and x.shape[1:] == (32, 32, 3) and np.array_equal(x[..., 0], x[..., 1]) and np.array_equal(x[..., 0], x[..., 2])
+    assert sorted(set(y.tolist())) == list(range(100))
+
+    def spectrum(a):
+        a = a[..., 0].astype(np.float32)
+        return np.abs(np.fft.fft2(a - a.mean((1, 2), keepdims=True))).reshape(len(a), -1)
+
+    def ncm(f, ft):
+        mu = np.stack([f[y == c].mean(0) for c in range(100)])
+        d = ((ft[:, None, :] - mu[None]) ** 2).sum(-1)
+        return float((d.argmin(1) == yt).mean())
+
+    acc = ncm(spectrum(x), spectrum(xt))
+    acc_flip = ncm(spectrum(x), spectrum(xt[:, :, ::-1]))
+    acc_raw = ncm(x[..., 0].reshape(len(x), -1).astype(np.float32), xt[..., 0].reshape(len(xt), -1).astype(np.float32))
+    assert acc > 0.7 and abs(acc - acc_flip) < 0.03 and acc_raw < 0.2, (acc, acc_flip, acc_raw)
