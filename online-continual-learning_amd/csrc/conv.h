@@ -202,6 +202,8 @@ struct WgradArgs {
 struct WgradPlan {
     WgradArgs a;
     int MTW, NTW;
+    int tab;                    // 1: tile-invariant staging tables in registers (conv_wgrad_kernel<..., TAB = 1>); OCL_WGRAD_TAB
+    int q_rgw;                  // > 0: the 4x4x1 form (conv_wgrad_kernel<1, 1, PF, q_rgw>: row groups per wave); experimental, OCL_WGRAD_Q=1
     int grid_x, grid_y;
     size_t lds_bytes;
     size_t partial_floats;

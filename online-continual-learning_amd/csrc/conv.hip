@@ -2343,14 +2343,32 @@ struct WTile {
     int img0, p0, oy0, nrows;
 };
 
-template <int MTW, int NTW, int PF>
+//
+// RGW > 0 selects the 4x4x1 form of the product for layers with at most 20 output channels and one channel chunk (stem, layer 1;
+// EXPERIMENTAL, OCL_WGRAD_Q=1, see plan_wgrad).  The 16x16x4 tiles pad layer 1's 180 x 20 gradient to 192 x 32: 41 % of the issued
+// MFMAs multiply zeros, and by the probes of round 3 the kernel is bound by the MFMAs it issues.  With v_mfma_f32_4x4x1_16b_f32 the
+// sixteen blocks of an instruction are sixteen PIXELS (the reduction dimension), and nothing is padded beyond quads:
+//   block b = pixel s0 + b of the tile;   A: lane 4b + i holds the 16-byte unit u = 4 * rowgroup + i = (tap, channel quad) of that
+//   pixel's patch (one ds_read_b128 feeds four MFMAs, k = channel inside the quad);   B: lane 4b + j holds dy[pixel][4s + j];
+//   D: register e of lane 4b + j accumulates  x[unit 4 * rowgroup + e][k] * dy[4s + j]  summed over the pixels b, b + 16, ...
+// so a wave owns RGW row groups (16 rows each) x 5 column quads x 4 channels = 20 * RGW accumulators, fed by RGW + 5 operand reads
+// per 16 pixels, and the sixteen per-block partial sums are combined once, at the end (two DPP row shifts, two cross-row shuffles),
+// in a fixed order.  The slab format is the 16x16x4 form's: the reduction kernels do not know which form wrote it.
+//
+// TAB = 1: the staging of a pixel tile with its tile-invariant half precomputed.  Which pixel slot / channel quad / patch position a
+// thread's units are does not change from tile to tile; only the tile's base addresses and its validity limits do.  The TAB = 0 form
+// re-derives everything per tile from packed positions (~1100 instructions per tile and wave around ~600 of the K loop); here the
+// thread keeps per unit a constant byte offset, an LDS address and a packed (row, patch row, image) word, and a tile costs an add,
+// two compares and a select per load.  Units that lie outside the tile or the patch for good store into a 16-byte dummy slot in
+// front of the pixel table instead of branching around the store.  Same values into the same LDS cells: bit-identical results.
+template <int MTW, int NTW, int PF, int RGW = 0, int TAB = 0>
 __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    int* pixoff = (int*)lds_raw;                    // [KP]
+    int* pixoff = (int*)lds_raw + 4;                // [KP]   (in front of it: the dummy slot of the TAB form)
     float* dyt = (float*)(pixoff + a.KP);           // [KP][DP]
     float* patch = dyt + (size_t)a.KP * a.DP;       // [imgs][PR][PC][CP]
     float* xft = patch + (((size_t)a.imgs * a.PR * a.PC * a.CP + 3) & ~(size_t)3);   // input transform (WgradArgs::xf): [groups][Cin/4][2][4] scale / shift quads
-    constexpr int BNW = 16 * NTW;
+    constexpr int BNW = RGW > 0 ? 4 * kQBlocks : 16 * NTW;
     constexpr int Q = BNW / 4;
     constexpr int DPF = (128 * Q + 255) / 256;      // dy prefetch registers (KP <= 128)
 
@@ -2378,6 +2396,27 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
     for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) acc[mt][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // 4x4x1 form: LDS offset of the lane's unit inside a pixel's patch (0 for the units past the last one: their rows are not written)
+    constexpr int RG = RGW > 0 ? RGW : 1;
+    int qoff[RG];
+    f32x4 qacc[RG][kQBlocks][4];
+    if constexpr (RGW > 0) {
+        const int qk4 = a.KC >> 2, units = a.ntaps * qk4;
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+            const int u = (((int)blockIdx.y * 4 + wave) * RG + r) * 4 + (lane & 3);
+            int c4;
+            const int t = fdiv(min(u, units - 1), qk4, 1.0f / (float)qk4, c4);
+            qoff[r] = u < units ? ((tap_sel(a.tdy, t) - a.min_dy) * a.PC + (tap_sel(a.tdx, t) - a.min_dx)) * a.CP + c4 * 4 : 0;
+#pragma unroll
+            for (int s = 0; s < kQBlocks; ++s)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    qacc[r][s][k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    asm volatile("" : "+a"(qacc[r][s][k]));
+                }
+        }
+    }
 
     const float inv_tpi = 1.0f / (float)a.tiles_per_img, inv_wo0 = 1.0f / (float)a.Wo;
     auto geom = [&](int tile) __attribute__((always_inline)) -> WTile {
@@ -2497,17 +2536,161 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
         }
     };
 
+    // ---- TAB form of the same two steps -------------------------------------------------------------------------------
+    constexpr int TDPF = TAB ? DPF : 1, TPF = TAB ? PF : 1;
+    int d_pl[TDPF], d_il[TDPF], d_goff[TDPF], d_lds[TDPF];   // pixel inside its image (huge: never valid), image inside the tile, byte offset from the tile's dy base, LDS float offset of the quad (dummy slot when the unit is outside the tile)
+    int px_pl = 0, px_il = 0, px_idx = -4, pxo = 0;          // the pixel-table entry of pixel slot `tid` (threads past the tile write the dummy slot)
+    int p_word[TPF], p_goff[TPF], p_lds[TPF];   // row | patch row << 16 | image << 24 (row 0xffff: never loaded);  byte offset from the tile's x base;  LDS byte offset | channel quad << 24
+    if constexpr (TAB) {
+        const int dummy_f = (int)((float*)lds_raw - dyt);   // float offset of the dummy slot relative to dyt (negative)
+#pragma unroll
+        for (int i = 0; i < DPF; ++i) {
+            const int u = tid + i * 256;
+            int c4, pl;
+            const int q = fdiv(u, Q, 1.0f / (float)Q, c4);
+            const int il = fdiv(q, a.ppi, inv_ppi, pl);
+            const bool in_tile = q < a.KP;
+            d_pl[i] = (in_tile && il < a.imgs && n0 + c4 * 4 < a.Cout) ? pl : 0x20000000;
+            d_il[i] = il;
+            d_goff[i] = ((il * LP + pl) * a.Cout + n0 + c4 * 4) * 4;
+            d_lds[i] = in_tile ? q * a.DP + c4 * 4 : dummy_f;
+        }
+        {
+            int pl;
+            const int il = fdiv(tid, a.ppi, inv_ppi, pl);
+            px_pl = (tid < a.KP && il < a.imgs) ? pl : 0x20000000;
+            px_il = il;
+            px_idx = tid < a.KP ? tid : -4;
+        }
+        const int n_units = a.imgs * a.PR * a.PC * kc4;
+#pragma unroll
+        for (int i = 0; i < PF; ++i) {
+            const int u = tid + i * 256;
+            int c4, pc, pr;
+            const int pix = fdiv(u, kc4, 1.0f / (float)kc4, c4);
+            const int row = fdiv(pix, a.PC, 1.0f / (float)a.PC, pc);
+            const int il = fdiv(row, a.PR, a.inv_PR, pr);
+            const int ix = a.min_dx + pc;
+            const bool inside = u < n_units;
+            const bool x_ok = inside && ix >= 0 && ix < a.Win;
+            p_word[i] = (x_ok ? row : 0xffff) | ((pr & 255) << 16) | ((il & 127) << 24);
+            p_goff[i] = (((il * a.Hin + pr) * a.Win + pc) * a.Cin + c4 * 4) * 4;
+            p_lds[i] = (inside ? (int)((patch - (float*)lds_raw) + (row * a.PC + pc) * a.CP + c4 * 4) * 4 : 0) | (c4 << 24);
+        }
+    }
+    auto load_tile_t = [&](const WTile& t) __attribute__((always_inline)) {
+        const int dbase = (t.img0 * LP + t.p0) * a.Cout * 4;
+        const int ox0 = t.p0 - t.oy0 * a.Wo;
+#pragma unroll
+        for (int i = 0; i < TDPF; ++i) {
+            const int p = t.p0 + d_pl[i], n = t.img0 + d_il[i];
+            const bool v = (p < LP) & (n < a.N);
+            dv[i] = buf_load16(rs_dy, v ? dbase + d_goff[i] : kOob);   // zeros when masked
+        }
+        {   // LDS patch offset of pixel slot `tid`: (row, column) of the pixel relative to the tile's first output row (branch-free division)
+            const int p = t.p0 + px_pl, n = t.img0 + px_il;
+            const bool v = (p < LP) & (n < a.N);
+            const int r = (ox0 + px_pl) & 0x3fffff;
+            int dr = (int)((float)r * inv_wo), ox = r - dr * a.Wo;
+            const int lo = ox < 0 ? 1 : 0, hi = ox >= a.Wo ? 1 : 0;
+            dr += hi - lo;
+            ox += (lo - hi) * a.Wo;
+            pxo = v ? ((px_il * a.PR + dr * a.stride) * a.PC + ox * a.stride) * a.CP : 0;
+        }
+        const int iy0 = t.oy0 * a.stride + a.min_dy;
+        const int base = (((t.img0 * a.Hin + iy0) * a.Win + a.min_dx) * a.Cin + c0) * 4;   // bytes; may be negative (halo)
+        okm = 0;
+#pragma unroll
+        for (int i = 0; i < TPF; ++i) {
+            const int row = p_word[i] & 0xffff, iy = iy0 + ((p_word[i] >> 16) & 255);
+            const bool ok = (row < t.nrows) & (iy >= 0) & (iy < a.Hin);
+            pv[i] = buf_load16(rs_x, ok ? base + p_goff[i] : kOob);
+            okm |= ok ? (1u << i) : 0u;
+        }
+    };
+    auto store_tile_t = [&](const WTile& t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < TDPF; ++i) *(float4*)(dyt + d_lds[i]) = dv[i];
+        pixoff[px_idx] = pxo;
+#pragma unroll
+        for (int i = 0; i < TPF; ++i) {
+            float4 v = pv[i];
+            if (a.xf) {   // block-uniform
+                int rem;
+                const int gq = min(fdiv(t.img0 + (p_word[i] >> 24), a.xf_group_size, inv_gs, rem), a.xf_groups - 1);
+                const float* tb = xft + (size_t)(gq * (a.Cin >> 2) + (c0 >> 2) + ((unsigned)p_lds[i] >> 24)) * 8;
+                const float4 sc = *(const float4*)tb, sh = *(const float4*)(tb + 4);
+                v.x = fmaxf(__fmaf_rn(v.x, sc.x, sh.x), 0.f); v.y = fmaxf(__fmaf_rn(v.y, sc.y, sh.y), 0.f);
+                v.z = fmaxf(__fmaf_rn(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(__fmaf_rn(v.w, sc.w, sh.w), 0.f);
+                if (!((okm >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            float* d = (float*)(lds_raw + (p_lds[i] & 0xffffff));
+            *(float2*)d = make_float2(v.x, v.y);
+            *(float2*)(d + 2) = make_float2(v.z, v.w);
+        }
+    };
+
     int tile = blockIdx.x;
     WTile cur = geom(tile);
-    if (tile < a.total_tiles) load_tile(cur);
+    if (tile < a.total_tiles) {
+        if constexpr (TAB) load_tile_t(cur);
+        else load_tile(cur);
+    }
     for (; tile < a.total_tiles; tile += a.S) {
         __syncthreads();  // previous tile consumed
-        store_tile(cur);
+        if constexpr (TAB) store_tile_t(cur);
+        else store_tile(cur);
         __syncthreads();
         const int next = tile + a.S;
         if (next < a.total_tiles) {
             cur = geom(next);
-            load_tile(cur);
+            if constexpr (TAB) load_tile_t(cur);
+            else load_tile(cur);
+        }
+        if constexpr (RGW > 0) {   // 16 pixels per step (KP is a multiple of 16 in this form); operands of step g + 1 are read while the MFMAs of step g issue
+            const float* dq = dyt + (size_t)(lane >> 2) * a.DP + (lane & 3);
+            const int* pq = pixoff + (lane >> 2);
+            const int ng = a.KP >> 4;
+            float bv[2][kQBlocks];
+            float4 av[2][RG];
+            int po_n = pq[0];   // (the pixel's patch offset is read one step ahead of the operand reads that depend on it)
+            auto fetch = [&](int set, int g) __attribute__((always_inline)) {
+                const int po = po_n;
+                po_n = pq[min(g + 1, ng - 1) * 16];
+#pragma unroll
+                for (int r = 0; r < RG; ++r) av[set][r] = *(const float4*)(patch + po + qoff[r]);
+#pragma unroll
+                for (int s = 0; s < kQBlocks; ++s) bv[set][s] = dq[(size_t)g * 16 * a.DP + 4 * s];
+            };
+            auto fma = [&](int set) __attribute__((always_inline)) {
+#pragma unroll
+                for (int r = 0; r < RG; ++r)
+#pragma unroll
+                    for (int s = 0; s < kQBlocks; ++s) {
+                        qacc[r][s][0] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[set][r].x, bv[set][s], qacc[r][s][0], 0, 0, 0);
+                        qacc[r][s][1] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[set][r].y, bv[set][s], qacc[r][s][1], 0, 0, 0);
+                        qacc[r][s][2] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[set][r].z, bv[set][s], qacc[r][s][2], 0, 0, 0);
+                        qacc[r][s][3] = __builtin_amdgcn_mfma_f32_4x4x1f32(av[set][r].w, bv[set][s], qacc[r][s][3], 0, 0, 0);
+                    }
+            };
+            fetch(0, 0);
+            int g = 0;
+            for (; g + 2 <= ng; g += 2) {
+                fetch(1, g + 1);
+                fma(0);
+                if (g + 2 < ng) fetch(0, g + 2);
+                fma(1);
+            }
+            if (g < ng) fma(0);
+            // (the accumulators are pinned to AccVGPRs across the tile loop: left alone, the register allocator keeps them in ArchVGPRs
+            // outside the pixel loop and copies all 80 * RGW of them in and out per tile -- spilling at RGW = 3)
+#pragma unroll
+            for (int r = 0; r < RG; ++r)
+#pragma unroll
+                for (int s = 0; s < kQBlocks; ++s)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) asm volatile("" : "+a"(qacc[r][s][k]));
+            continue;
         }
         const float* pb = dyt + (size_t)g * a.DP + r16;
         // (A hand-pipelined form of this loop -- two operand register sets, the reads of iteration i + 1 issued in front of the MFMAs of
@@ -2543,6 +2726,43 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
     // partial tile out: rows (chunk, mblock, m), cols co
     const int mrows_chunk = a.mblocks_per_chunk * 64 * MTW;
     float* dst = a.partial + (int64_t)blockIdx.x * a.Mrows_total * a.CoutP;
+    if constexpr (RGW > 0) {
+        // Sum over the sixteen blocks (lanes 4b + j, b = 0..15), in a fixed order.  The four registers e of an accumulator are four rows
+        // of the gradient, and the wave has four DPP rows: two v_permlane16_swap + one v_permlane32_swap (gfx950: exchanges of whole
+        // 16- / 32-lane groups between two registers, no LDS) add the rows' partial sums so that DPP row R is left with register R's --
+        // a reduce-scatter, 3 exchanges + 3 adds per accumulator instead of 8 shuffles + 8 adds -- then two row shifts add the four
+        // blocks of the row, and lanes 12..15 of every row store (16 lanes, one instruction per accumulator).
+        const int qk4 = a.KC >> 2, units = a.ntaps * qk4;
+        int rowoff[RG];   // slab offset of (row of unit 4 * rowgroup + DPP row, channel 0) + column j, -1: past the last unit / not a storing lane
+#pragma unroll
+        for (int r = 0; r < RG; ++r) {
+            const int u = (((int)blockIdx.y * 4 + wave) * RG + r) * 4 + (lane >> 4);
+            int c4;
+            const int t = fdiv(min(u, units - 1), qk4, 1.0f / (float)qk4, c4);
+            rowoff[r] = (u < units && (lane & 12) == 12) ? (t * a.KC + c4 * 4) * a.CoutP + (lane & 3) : -1;
+        }
+        auto sw16 = [](float x, float y) __attribute__((always_inline)) -> float {   // rows: [x0 + x1, y0 + y1, x2 + x3, y2 + y3]
+            const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y), false, false);
+            return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+        };
+        auto sw32 = [](float x, float y) __attribute__((always_inline)) -> float {   // halves: [x.lo + x.hi, y.lo + y.hi]
+            const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, x), __builtin_bit_cast(unsigned, y), false, false);
+            return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+        };
+#pragma unroll
+        for (int r = 0; r < RG; ++r)
+#pragma unroll
+            for (int s = 0; s < kQBlocks; ++s)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const f32x4 v = qacc[r][s][k];
+                    float x = sw32(sw16(v[0], v[1]), sw16(v[2], v[3]));   // DPP row R: register R summed over the four rows
+                    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x114, 0xf, 0xf, true));   // row_shr:4
+                    x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x118, 0xf, 0xf, true));   // row_shr:8
+                    if (rowoff[r] >= 0 && 4 * s + (lane & 3) < a.Cout) dst[rowoff[r] + k * a.CoutP + 4 * s] = x;
+                }
+        return;
+    }
 #pragma unroll
     for (int mt = 0; mt < MTW; ++mt)
 #pragma unroll
@@ -2557,16 +2777,25 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
 }
 
 typedef void (*wgrad_fn_t)(const WgradArgs);
-static wgrad_fn_t wgrad_fn(int M, int N, int PF) {
-#define OCL_CASE(A, B)                                               \
-    if (M == A && N == B) {                                          \
-        if (PF == 4) return conv_wgrad_kernel<A, B, 4>;              \
-        if (PF == 8) return conv_wgrad_kernel<A, B, 8>;              \
+static wgrad_fn_t wgrad_fn(int M, int N, int PF, int tab) {
+#define OCL_CASE(A, B)                                                                                          \
+    if (M == A && N == B) {                                                                                     \
+        if (PF == 4) return tab ? conv_wgrad_kernel<A, B, 4, 0, 1> : conv_wgrad_kernel<A, B, 4, 0, 0>;          \
+        if (PF == 8) return tab ? conv_wgrad_kernel<A, B, 8, 0, 1> : conv_wgrad_kernel<A, B, 8, 0, 0>;          \
     }
     OCL_CASE(1, 1) OCL_CASE(1, 2) OCL_CASE(1, 3) OCL_CASE(1, 4) OCL_CASE(1, 5)
     OCL_CASE(2, 1) OCL_CASE(2, 2) OCL_CASE(2, 3) OCL_CASE(2, 4) OCL_CASE(2, 5)
     OCL_CASE(3, 1) OCL_CASE(3, 2) OCL_CASE(3, 3) OCL_CASE(3, 4) OCL_CASE(3, 5)
     OCL_CASE(4, 1) OCL_CASE(4, 2) OCL_CASE(4, 3) OCL_CASE(4, 4) OCL_CASE(4, 5)
+#undef OCL_CASE
+    return nullptr;
+}
+static wgrad_fn_t wgrad_q_fn(int rgw, int PF, int tab) {
+#define OCL_CASE(R)                                                                                                     \
+    if (rgw == R)                                                                                                       \
+        return tab ? (PF == 4 ? conv_wgrad_kernel<1, 1, 4, R, 1> : conv_wgrad_kernel<1, 1, 8, R, 1>)                    \
+                   : (PF == 4 ? conv_wgrad_kernel<1, 1, 4, R, 0> : conv_wgrad_kernel<1, 1, 8, R, 0>);
+    OCL_CASE(1) OCL_CASE(2) OCL_CASE(3)
 #undef OCL_CASE
     return nullptr;
 }
@@ -2684,8 +2913,8 @@ int plan_wgrad(int N, int Hin, int Win, int Cin, int Ho, int Wo, int Cout, int k
                 if (Cin % KC) continue;
                 if (pass == 0 && KC < std::min(20, Cin)) break;
                 a.KC = KC; a.CP = wg_cp(KC, stride);
-                const size_t bytes = (size_t)a.KP * 4 + (size_t)a.KP * a.DP * 4 + (size_t)a.imgs * a.PR * a.PC * a.CP * 4 +
-                                     (size_t)xf_groups * Cin * 8 + (xf_groups ? 16 : 0);   // (+ the input-transform table)
+                const size_t bytes = 16 + (size_t)a.KP * 4 + (size_t)a.KP * a.DP * 4 + (size_t)a.imgs * a.PR * a.PC * a.CP * 4 +
+                                     (size_t)xf_groups * Cin * 8 + (xf_groups ? 16 : 0);   // (dummy slot + ... + the input-transform table)
                 const bool fits = (pass == 0 ? bytes <= kLdsTarget : bytes <= kLdsLimit - 1024) &&
                                   a.imgs * a.PR * a.PC * (KC / 4) <= 256 * kPatchPF;
                 if (fits) { p->lds_bytes = bytes; found = true; break; }
@@ -2733,11 +2962,50 @@ int plan_wgrad(int N, int Hin, int Win, int Cin, int Ho, int Wo, int Cout, int k
     p->MTW = MTW; p->NTW = NTW;
     p->grid_x = a.S; p->grid_y = by;
     p->partial_floats = (size_t)a.S * a.Mrows_total * a.CoutP;
+    // staging with precomputed unit tables (conv_wgrad_kernel, TAB): the default; OCL_WGRAD_TAB=0 selects the form that re-derives the
+    // units per tile (bit-identical results: scripts/gpu_r4z3.sh, profiles/r4_wgrad_tab_ab.txt)
+    static const int env_tab = [] { const char* e = getenv("OCL_WGRAD_TAB"); return e ? atoi(e) : 1; }();
+    p->tab = env_tab ? 1 : 0;
+    // EXPERIMENTAL (OCL_WGRAD_Q=1, default off: written at the end of round 4 without GPU time left to validate it): the 4x4x1 form for
+    // <= 20 output channels and a single channel chunk -- stem and layer 1, the two largest pixel counts of the network.
+    //   OCL_WGRAD_Q_RGW     row groups (16 gradient rows) per wave, 1..3 (default: the smallest count that covers the rows with one
+    //                       row block, i.e. the patch is staged once per pixel tile)
+    //   OCL_WGRAD_Q_TARGET  workgroups aimed at by the pixel split (default 256: the block sums of the epilogue cost about one pixel
+    //                       tile's MFMAs, so fewer, longer workgroups than the 16x16x4 form)
+    static const int env_q = [] { const char* e = getenv("OCL_WGRAD_Q"); return e ? atoi(e) : 0; }();
+    // (the stem's 9 units fill 3 of 4 waves: measured slower; the block sums of the epilogue cost about 1.7 pixel tiles, and the form
+    // runs one workgroup per CU: it pays from ~6 tiles of 128 pixels per workgroup at 256 workgroups -- SCR's 220 views yes (-33 us per
+    // pass), 20 images of 84 x 84 no (+40 us); OCL_WGRAD_Q=2 lifts that limit)
+    if (env_q && Cout <= 4 * kQBlocks && Cin >= 8 && a.nchunks == 1 && a.CP % 4 == 0 && a.KP % 16 == 0 &&
+        ((int64_t)a.total_tiles * a.KP >= 6 * 128 * 256 || env_q >= 2)) {
+        static const int env_rgw = [] { const char* e = getenv("OCL_WGRAD_Q_RGW"); return e ? atoi(e) : 0; }();
+        static const int env_qtarget = [] { const char* e = getenv("OCL_WGRAD_Q_TARGET"); return e ? atoi(e) : 256; }();
+        const int rg = cdiv(a.ntaps * (a.KC / 4), 4);
+        int rgw = rg <= 4 ? 1 : rg <= 8 ? 2 : 3;
+        if (env_rgw >= 1 && env_rgw <= 3) rgw = env_rgw;
+        a.nblocks = 1;
+        a.DP = a.CoutP = 4 * kQBlocks;
+        const size_t bytes = 16 + (size_t)a.KP * 4 + (size_t)a.KP * a.DP * 4 + (((size_t)a.imgs * a.PR * a.PC * a.CP + 3) & ~(size_t)3) * 4 +
+                             (size_t)xf_groups * Cin * 8 + (xf_groups ? 16 : 0);
+        p->lds_bytes = bytes;
+        a.mblocks_per_chunk = cdiv(a.Mchunk, 64);   // slab rows as the 16x16x4 form with MTW = 1 (the reduction reads this format)
+        a.Mrows_total = a.mblocks_per_chunk * 64;
+        const int qby = cdiv(rg, 4 * rgw);
+        const int64_t slab = (int64_t)a.Mrows_total * a.CoutP * 4;
+        const int s_cap = (int)std::max<int64_t>(1, (12ll << 20) / slab);
+        int S = std::max(1, std::min(std::min(a.total_tiles, s_cap), cdiv(env_qtarget, qby)));
+        S = cdiv(a.total_tiles, cdiv(a.total_tiles, S));
+        a.S = S;
+        p->MTW = 1; p->NTW = 1; p->q_rgw = rgw;
+        p->grid_x = S; p->grid_y = qby;
+        p->partial_floats = (size_t)S * a.Mrows_total * a.CoutP;
+    }
     return OCL_OK;
 }
 
 int launch_wgrad(const WgradPlan& p, hipStream_t s) {
-    wgrad_fn_t fn = wgrad_fn(p.MTW, p.NTW, wgrad_pf_for(p.a.imgs * p.a.PR * p.a.PC * (p.a.KC / 4)));
+    const int pf = wgrad_pf_for(p.a.imgs * p.a.PR * p.a.PC * (p.a.KC / 4));
+    wgrad_fn_t fn = p.q_rgw ? wgrad_q_fn(p.q_rgw, pf, p.tab) : wgrad_fn(p.MTW, p.NTW, pf, p.tab);
     if (!fn) {
         set_error("launch_wgrad: no kernel for MTW=%d NTW=%d", p.MTW, p.NTW);
         return OCL_ERR_STATE;
@@ -3610,7 +3878,12 @@ int conv_kernels_init() {
     for (int m = 1; m <= 4; ++m)
         for (int n = 1; n <= 5; ++n)
             for (int pf = 4; pf <= 8; pf += 4)
-                OCL_HIP(hipFuncSetAttribute((const void*)wgrad_fn(m, n, pf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+                for (int tab = 0; tab < 2; ++tab)
+                    OCL_HIP(hipFuncSetAttribute((const void*)wgrad_fn(m, n, pf, tab), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+    for (int r = 1; r <= 3; ++r)
+        for (int pf = 4; pf <= 8; pf += 4)
+            for (int tab = 0; tab < 2; ++tab)
+                OCL_HIP(hipFuncSetAttribute((const void*)wgrad_q_fn(r, pf, tab), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     for (int m = 1; m <= 5; ++m)
         for (int n = 1; n <= 2; ++n)
             for (int pf = 4; pf <= 8; pf += 4)
