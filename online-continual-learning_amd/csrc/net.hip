@@ -381,7 +381,15 @@ static int get_plans(ocl_net* n, int N, int groups, PlanSet** out) {
             // stride-2 3x3: the four parity classes as one launch where conv_t_kernel can take them (OCL_DGRAD_MERGE=0: four launches)
             static const bool merge = [] { const char* e = getenv("OCL_DGRAD_MERGE"); return !(e && e[0] == '0'); }();
             std::vector<ConvGeomDesc> dg;
-            const bool bnb = env_bnb && c.xf_src >= 0 && c.stride == 1 && groups <= 2;   // conv2 of a block: its data gradient enters bn1's backward
+            // (stage 2, OCL_BNB_EPI2=1, written at the end of round 4 and NOT yet run on a GPU: the data gradient of conv1 of an identity
+            // block completes dL/dz of the block in front of it -- or of the stem -- and carries the reduction half of THAT BatchNorm's
+            // backward (bn2 of a block without a projection shortcut, the stem's) the same way; see trunk_backward)
+            static const bool env_bnb2 = [] { const char* e = getenv("OCL_BNB_EPI2"); return e && e[0] == '1'; }();
+            bool bnb2 = false;
+            if (env_bnb && env_bnb2 && c.stride == 1 && groups <= 2)
+                for (size_t k = 0; k < n->blocks.size(); ++k)
+                    if (n->blocks[k].conv1 == (int)i && n->blocks[k].convs < 0 && (k == 0 || n->blocks[k - 1].convs < 0)) bnb2 = true;
+            const bool bnb = (env_bnb && c.xf_src >= 0 && c.stride == 1 && groups <= 2) || bnb2;   // conv2 of a block: its data gradient enters bn1's backward
             geom_dgrad(c, N, &dg, merge, bnb ? groups : 1);
             if (bnb && dg.size() == 1) {
                 dg[0].bnb = 1;
@@ -1149,6 +1157,7 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
         return true;
     };
     if (stop_here(99, 0)) return OCL_OK;   // right after the head: gA = dL/dz of the last block
+    bool prev_epi = false;   // gA is already ReLU-masked and the batch sums of the BatchNorm it enters are in that BatchNorm's arena
     const ConvInfo& c0 = n->convs[0];
     for (int bi = (int)n->blocks.size() - 1; bi >= 0; --bi) {
         const BlockInfo& b = n->blocks[bi];
@@ -1161,7 +1170,10 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
         int rB, rC = -1;
         gB = take_dy(&rB);
         if (b.convs >= 0) gC = take_dy(&rC);
-        if ((rc = bn_bwd(gA, z, b.conv2, gB, b.convs, gC))) return rc;
+        if (prev_epi) {   // gA arrived masked, bn2's batch sums with it (epilogue of the block behind): the streaming apply kernel
+            if ((rc = bn_apply_e(b.conv2, gA, gB))) return rc;
+        } else if ((rc = bn_bwd(gA, z, b.conv2, gB, b.convs, gC))) return rc;
+        prev_epi = false;
         if (stop_here(bi, 1)) return OCL_OK;                                 // gB = dL/dy2, gC = dL/dys
         if ((rc = publish())) return rc;
         if (b.convs >= 0) {
@@ -1192,7 +1204,14 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
             if (stop_here(bi, 4)) return OCL_OK;
             if ((rc = dgrad(b.convs, gC, gE, nullptr, nullptr, EPI_ACCUM))) return rc;
         } else {
-            if ((rc = dgrad(b.conv1, gB1, gE, gA, z, 0))) return rc;         // + identity shortcut: dz * (z>0)
+            // + identity shortcut: dz * (z>0).  Stage 2 (OCL_BNB_EPI2=1): this launch completes dL/dz of the block in front (of the stem for
+            // block 0), so its epilogue also masks that gradient with (xin > 0) and sums it for the BatchNorm behind xin
+            const bool single_target = bi == 0 || n->blocks[bi - 1].convs < 0;
+            const bool epi2 = ps->dgrad_bnb[b.conv1] && single_target && !frozen && G <= 2 && n->dbg_stop < 0;
+            BnbEpi be2;
+            if (epi2) be2 = bnb_desc(bi == 0 ? 0 : n->blocks[bi - 1].conv2, xin);
+            if ((rc = dgrad(b.conv1, gB1, gE, gA, z, 0, epi2 ? &be2 : nullptr))) return rc;
+            prev_epi = epi2;
         }
         if (stop_here(bi, 5)) return OCL_OK;                                 // gE = dL/dx of the block
         std::swap(gA, gE);
@@ -1200,7 +1219,9 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
     // stem
     int rS;
     float* gS = take_dy(&rS);
-    if ((rc = bn_bwd(gA, at(n->zstem_off, c0), 0, gS, -1, nullptr))) return rc;
+    if (prev_epi) {
+        if ((rc = bn_apply_e(0, gA, gS))) return rc;
+    } else if ((rc = bn_bwd(gA, at(n->zstem_off, c0), 0, gS, -1, nullptr))) return rc;
     // The stem's weight gradient is the tail of the backward: it runs on the caller's stream (no two more cross-stream hand-offs, ~30 us
     // of event latency in the trace) BESIDE the side stream's last kernels -- layer 1's weight gradients, the largest of the step, are
     // still running there when the chain ends -- with its own slab region (the slabs of one layer stay under 12 MB; the stem's start

@@ -17,10 +17,11 @@ LDS_LIMIT = 160 * 1024
 PIPE_QS = {1: 64, 2: 32, 3: 16, 4: 16, 5: 16}      # conv.hip: pipe_qs(MT)
 
 
-def _plan_lines(n, groups, hw):
+def _plan_lines(n, groups, hw, env=None):
     if not os.path.exists(KBENCH):
         subprocess.run(["make", "-C", CSRC, "kbench"], check=True, stdout=subprocess.DEVNULL)
-    r = subprocess.run([KBENCH, str(n), str(groups), str(hw), "plan"], capture_output=True, text=True, timeout=120)
+    r = subprocess.run([KBENCH, str(n), str(groups), str(hw), "plan"], capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     return r.stdout.splitlines()
 
@@ -107,3 +108,24 @@ def test_ring_schedule_index_model():
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     assert m.main(400, seed=7) == 400
+
+
+def test_weight_gradient_forms_chosen_by_the_planner():
+    """The table-driven staging is the default form of every layer (OCL_WGRAD_TAB=0 selects the other); the 4x4x1 form (OCL_WGRAD_Q=1)
+    is only planned where it was measured faster: layer 1's 3x3 convolutions (<= 20 output channels, one channel chunk, not the stem)
+    of a pass with at least ~6 tiles of 128 pixels per workgroup -- SCR's 220 views, not a replay-sized batch, not 20 images of 84x84;
+    its slabs are 20 columns wide and its pixel tiles whole 16-pixel steps."""
+    for l in [l for l in _plan_lines(220, 2, 32) if " wgrad " in l]:
+        f = _fields(l)
+        assert f["tab"] == 1 and f["q4"] == 0
+    assert all(_fields(l)["tab"] == 0 for l in _plan_lines(220, 2, 32, {"OCL_WGRAD_TAB": "0"}) if " wgrad " in l)
+    q = {l.split()[0]: _fields(l) for l in _plan_lines(220, 2, 32, {"OCL_WGRAD_Q": "1"}) if " wgrad " in l}
+    on = sorted(k for k, f in q.items() if f["q4"])
+    assert on == ["layer1.0.conv1", "layer1.0.conv2", "layer1.1.conv1", "layer1.1.conv2"]
+    for k in on:
+        f = q[k]
+        assert f["q4"] == 3 and f["KP"] % 16 == 0 and f["CP"] % 4 == 0 and f["KC"] == 20 and f["lds"] <= 72 * 1024
+        assert 128 <= f["grid"] <= 256                    # one workgroup per CU: a single wave of workgroups
+    for n, groups, hw in [(20, 1, 32), (20, 1, 84)]:
+        assert not any(_fields(l)["q4"] for l in _plan_lines(n, groups, hw, {"OCL_WGRAD_Q": "1"}) if " wgrad " in l)
+    assert any(_fields(l)["q4"] for l in _plan_lines(20, 1, 84, {"OCL_WGRAD_Q": "2"}) if " wgrad " in l)   # (2 lifts the size gate)
