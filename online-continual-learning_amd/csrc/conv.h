@@ -198,6 +198,7 @@ struct WgradArgs {
     const float* xf_invstd;
     const float* xf_gamma;
     const float* xf_beta;
+    unsigned long long* trace;  // measurement only (kbench wgradtrace): per workgroup 64 s_memtime stamps of thread 0 at the phase boundaries
 };
 struct WgradPlan {
     WgradArgs a;

@@ -2361,7 +2361,10 @@ struct WTile {
 // thread keeps per unit a constant byte offset, an LDS address and a packed (row, patch row, image) word, and a tile costs an add,
 // two compares and a select per load.  Units that lie outside the tile or the patch for good store into a 16-byte dummy slot in
 // front of the pixel table instead of branching around the store.  Same values into the same LDS cells: bit-identical results.
-template <int MTW, int NTW, int PF, int RGW = 0, int TAB = 0>
+// TRACE = 1 (measurement build, kbench `wgradtrace`): s_memtime stamps of thread 0 at the phase boundaries into WgradArgs::trace,
+// 64 slots per workgroup: start | prologue done | per tile: passed barrier 1, tile stored, passed barrier 2, next tile's loads issued,
+// K loop done | ... | slab written.
+template <int MTW, int NTW, int PF, int RGW = 0, int TAB = 0, int TRACE = 0>
 __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     int* pixoff = (int*)lds_raw + 4;                // [KP]   (in front of it: the dummy slot of the TAB form)
@@ -2630,23 +2633,35 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
         }
     };
 
+    int tr_n = 0;
+    auto stamp = [&]() __attribute__((always_inline)) {
+        if constexpr (TRACE) {
+            if (tid == 0 && tr_n < 64) a.trace[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 64 + tr_n++] = __builtin_amdgcn_s_memtime();
+        }
+    };
+    stamp();
     int tile = blockIdx.x;
     WTile cur = geom(tile);
     if (tile < a.total_tiles) {
         if constexpr (TAB) load_tile_t(cur);
         else load_tile(cur);
     }
+    stamp();
     for (; tile < a.total_tiles; tile += a.S) {
         __syncthreads();  // previous tile consumed
+        stamp();
         if constexpr (TAB) store_tile_t(cur);
         else store_tile(cur);
+        stamp();
         __syncthreads();
+        stamp();
         const int next = tile + a.S;
         if (next < a.total_tiles) {
             cur = geom(next);
             if constexpr (TAB) load_tile_t(cur);
             else load_tile(cur);
         }
+        stamp();
         if constexpr (RGW > 0) {   // 16 pixels per step (KP is a multiple of 16 in this form); operands of step g + 1 are read while the MFMAs of step g issue
             const float* dq = dyt + (size_t)(lane >> 2) * a.DP + (lane & 3);
             const int* pq = pixoff + (lane >> 2);
@@ -2690,6 +2705,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
                 for (int s = 0; s < kQBlocks; ++s)
 #pragma unroll
                     for (int k = 0; k < 4; ++k) asm volatile("" : "+a"(qacc[r][s][k]));
+            stamp();
             continue;
         }
         const float* pb = dyt + (size_t)g * a.DP + r16;
@@ -2722,6 +2738,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
         int s = 0;
         for (; s + 16 <= a.KP; s += 16) ksteps(s, std::integral_constant<int, 4>());
         for (; s < a.KP; s += 4) ksteps(s, std::integral_constant<int, 1>());
+        stamp();
     }
     // partial tile out: rows (chunk, mblock, m), cols co
     const int mrows_chunk = a.mblocks_per_chunk * 64 * MTW;
@@ -2761,6 +2778,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
                     x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x118, 0xf, 0xf, true));   // row_shr:8
                     if (rowoff[r] >= 0 && 4 * s + (lane & 3) < a.Cout) dst[rowoff[r] + k * a.CoutP + 4 * s] = x;
                 }
+        stamp();
         return;
     }
 #pragma unroll
@@ -2774,6 +2792,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
             for (int nt = 0; nt < NTW; ++nt)
                 if (n0 + nt * 16 + r16 < a.Cout) dst[(int64_t)row * a.CoutP + n0 + nt * 16 + r16] = acc[mt][nt][reg];
         }
+    stamp();
 }
 
 typedef void (*wgrad_fn_t)(const WgradArgs);
@@ -2797,6 +2816,16 @@ static wgrad_fn_t wgrad_q_fn(int rgw, int PF, int tab) {
                    : (PF == 4 ? conv_wgrad_kernel<1, 1, 4, R, 0> : conv_wgrad_kernel<1, 1, 8, R, 0>);
     OCL_CASE(1) OCL_CASE(2) OCL_CASE(3)
 #undef OCL_CASE
+    return nullptr;
+}
+// measurement builds (TRACE) of the forms the SCR pass runs most
+static wgrad_fn_t wgrad_trace_fn(int M, int N, int PF, int rgw, int tab) {
+    if (!tab || PF != 8) return nullptr;
+    if (rgw == 3) return conv_wgrad_kernel<1, 1, 8, 3, 1, 1>;
+    if (rgw) return nullptr;
+    if (M == 2 && N == 3) return conv_wgrad_kernel<2, 3, 8, 0, 1, 1>;
+    if (M == 3 && N == 2) return conv_wgrad_kernel<3, 2, 8, 0, 1, 1>;
+    if (M == 1 && N == 3) return conv_wgrad_kernel<1, 3, 8, 0, 1, 1>;
     return nullptr;
 }
 static int wgrad_pf_for(int units) { return units <= 1024 ? 4 : 8; }
@@ -3006,6 +3035,14 @@ int plan_wgrad(int N, int Hin, int Win, int Cin, int Ho, int Wo, int Cout, int k
 int launch_wgrad(const WgradPlan& p, hipStream_t s) {
     const int pf = wgrad_pf_for(p.a.imgs * p.a.PR * p.a.PC * (p.a.KC / 4));
     wgrad_fn_t fn = p.q_rgw ? wgrad_q_fn(p.q_rgw, pf, p.tab) : wgrad_fn(p.MTW, p.NTW, pf, p.tab);
+    if (p.a.trace) {
+        fn = wgrad_trace_fn(p.MTW, p.NTW, pf, p.q_rgw, p.tab);
+        if (!fn) {
+            set_error("launch_wgrad: no trace build for MTW=%d NTW=%d PF=%d rgw=%d tab=%d", p.MTW, p.NTW, pf, p.q_rgw, p.tab);
+            return OCL_ERR_UNSUPPORTED;
+        }
+        OCL_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+    }
     if (!fn) {
         set_error("launch_wgrad: no kernel for MTW=%d NTW=%d", p.MTW, p.NTW);
         return OCL_ERR_STATE;

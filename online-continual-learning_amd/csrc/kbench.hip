@@ -923,6 +923,56 @@ int main(int argc, char** argv) {
             (void)tot_auto;
         }
     }
+    if (mode == "wgradtrace") {   // where a pixel tile's time goes: s_memtime stamps of thread 0 of every workgroup (measurement builds of the hot forms)
+        float* partial = nullptr;
+        size_t pf = 0;
+        for (auto& l : layers) {
+            WgradPlan wp;
+            OK(plan_wgrad(N, l.s.Hin, l.s.Win, l.s.CinT, l.s.Ho, l.s.Wo, l.s.Cout, l.s.k, l.s.stride, &wp));
+            pf = std::max(pf, wp.partial_floats);
+        }
+        CK(hipMalloc(&partial, pf * 4 + 4096));
+        for (auto& l : layers) {
+            const ConvShape& c = l.s;
+            WgradPlan wp;
+            OK(plan_wgrad(N, c.Hin, c.Win, c.CinT, c.Ho, c.Wo, c.Cout, c.k, c.stride, &wp));
+            wp.a.x = bufA; wp.a.dy = bufB; wp.a.partial = partial;
+            const int nwg = wp.grid_x * wp.grid_y;
+            unsigned long long* tr;
+            CK(hipMalloc(&tr, (size_t)nwg * 64 * 8));
+            CK(hipMemset(tr, 0, (size_t)nwg * 64 * 8));
+            wp.a.trace = tr;
+            if (launch_wgrad(wp, 0) != OCL_OK) { printf("%-20s (no trace build: %s)\n", l.name.c_str(), ocl_last_error()); CK(hipFree(tr)); continue; }
+            OK(launch_wgrad(wp, 0));   // (second launch: warm caches; the stamps of this one are read)
+            CK(hipDeviceSynchronize());
+            std::vector<unsigned long long> h((size_t)nwg * 64);
+            CK(hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost));
+            // mean over workgroups and tiles of each phase (ticks of s_memtime)
+            double ph[5] = {0, 0, 0, 0, 0}, pro = 0, epi = 0, life = 0;
+            long ntile = 0;
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (int w = 0; w < nwg; ++w) {
+                const unsigned long long* r = &h[(size_t)w * 64];
+                int last = 0;
+                while (last + 1 < 64 && r[last + 1]) ++last;
+                t0 = std::min(t0, r[0]); t1 = std::max(t1, r[last]);
+                pro += (double)(r[1] - r[0]);
+                life += (double)(r[last] - r[0]);
+                int e = 1;
+                for (; e + 5 <= last; e += 5) {
+                    for (int k = 0; k < 5; ++k) ph[k] += (double)(r[e + k + 1] - r[e + k]);
+                    ++ntile;
+                }
+                if (e < last) epi += (double)(r[last] - r[e]);
+            }
+            printf("%-20s MTW=%d NTW=%d q4=%d grid=%4dx%d tiles/wg=%.1f  span %6llu | per workgroup: prologue %6.0f  lifetime %7.0f  epilogue %6.0f | per tile: barrier1 %5.0f  store %5.0f  barrier2 %5.0f  next-load issue %5.0f  K loop %6.0f  (sum %6.0f ticks)\n",
+                   l.name.c_str(), wp.MTW, wp.NTW, wp.q_rgw, wp.grid_x, wp.grid_y, (double)ntile / nwg, t1 - t0, pro / nwg, life / nwg, epi / nwg,
+                   ph[0] / ntile, ph[1] / ntile, ph[2] / ntile, ph[3] / ntile, ph[4] / ntile, (ph[0] + ph[1] + ph[2] + ph[3] + ph[4]) / ntile);
+            CK(hipFree(tr));
+        }
+        CK(hipFree(partial));
+        return 0;
+    }
     if (mode == "all" || mode == "wgrad") {
         float* partial = nullptr;
         size_t pf = 0;
