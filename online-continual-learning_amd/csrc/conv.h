@@ -198,6 +198,7 @@ struct WgradArgs {
     const float* xf_invstd;
     const float* xf_gamma;
     const float* xf_beta;
+    int xcd_by;                 // > 0: one-dimensional launch of S * xcd_by workgroups in the XCD-aware order (conv_wgrad_kernel), = grid_y of the plan
     unsigned long long* trace;  // measurement only (kbench wgradtrace): per workgroup 64 s_memtime stamps of thread 0 at the phase boundaries
 };
 struct WgradPlan {

@@ -2377,7 +2377,23 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, g = lane >> 4;
-    const int by = blockIdx.y;
+    // (pixel split bx, output block by) of this workgroup.  xcd_by > 0 (OCL_WGRAD_XCD=1, a one-dimensional launch of S * by workgroups):
+    // the `by` workgroups that read the SAME pixel tiles get linear ids that agree modulo 8 and lie within 8 * by of each other --
+    // workgroup b is observed to run on XCD b % 8, so they share one L2 (4 MB per XCD, not coherent across XCDs) at about the same
+    // time, instead of fetching every tile once per output block from memory.  The last S % 8 splits keep the plain order.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (a.xcd_by > 0) {
+        const int id = blockIdx.x, per = 8 * a.xcd_by, full = (a.S >> 3) * per;
+        if (id < full) {
+            const int grp = id / per, rem = id - grp * per;
+            by = rem >> 3;
+            bx = grp * 8 + (rem & 7);
+        } else {
+            const int r = a.S & 7, t = id - full;
+            by = t / r;
+            bx = (a.S & ~7) + (t - by * r);
+        }
+    }
     const int nb = by % a.nblocks;
     const int t1 = by / a.nblocks;
     const int mb = t1 % a.mblocks_per_chunk;
@@ -2407,7 +2423,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
         const int qk4 = a.KC >> 2, units = a.ntaps * qk4;
 #pragma unroll
         for (int r = 0; r < RG; ++r) {
-            const int u = (((int)blockIdx.y * 4 + wave) * RG + r) * 4 + (lane & 3);
+            const int u = ((by * 4 + wave) * RG + r) * 4 + (lane & 3);
             int c4;
             const int t = fdiv(min(u, units - 1), qk4, 1.0f / (float)qk4, c4);
             qoff[r] = u < units ? ((tap_sel(a.tdy, t) - a.min_dy) * a.PC + (tap_sel(a.tdx, t) - a.min_dx)) * a.CP + c4 * 4 : 0;
@@ -2636,11 +2652,11 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
     int tr_n = 0;
     auto stamp = [&]() __attribute__((always_inline)) {
         if constexpr (TRACE) {
-            if (tid == 0 && tr_n < 64) a.trace[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 64 + tr_n++] = __builtin_amdgcn_s_memtime();
+            if (tid == 0 && tr_n < 64) a.trace[(size_t)(by * a.S + bx) * 64 + tr_n++] = __builtin_amdgcn_s_memtime();
         }
     };
     stamp();
-    int tile = blockIdx.x;
+    int tile = bx;
     WTile cur = geom(tile);
     if (tile < a.total_tiles) {
         if constexpr (TAB) load_tile_t(cur);
@@ -2742,7 +2758,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
     }
     // partial tile out: rows (chunk, mblock, m), cols co
     const int mrows_chunk = a.mblocks_per_chunk * 64 * MTW;
-    float* dst = a.partial + (int64_t)blockIdx.x * a.Mrows_total * a.CoutP;
+    float* dst = a.partial + (int64_t)bx * a.Mrows_total * a.CoutP;
     if constexpr (RGW > 0) {
         // Sum over the sixteen blocks (lanes 4b + j, b = 0..15), in a fixed order.  The four registers e of an accumulator are four rows
         // of the gradient, and the wave has four DPP rows: two v_permlane16_swap + one v_permlane32_swap (gfx950: exchanges of whole
@@ -2753,7 +2769,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
         int rowoff[RG];   // slab offset of (row of unit 4 * rowgroup + DPP row, channel 0) + column j, -1: past the last unit / not a storing lane
 #pragma unroll
         for (int r = 0; r < RG; ++r) {
-            const int u = (((int)blockIdx.y * 4 + wave) * RG + r) * 4 + (lane >> 4);
+            const int u = ((by * 4 + wave) * RG + r) * 4 + (lane >> 4);
             int c4;
             const int t = fdiv(min(u, units - 1), qk4, 1.0f / (float)qk4, c4);
             rowoff[r] = (u < units && (lane & 12) == 12) ? (t * a.KC + c4 * 4) * a.CoutP + (lane & 3) : -1;
@@ -3029,6 +3045,9 @@ int plan_wgrad(int N, int Hin, int Win, int Cin, int Ho, int Wo, int Cout, int k
         p->grid_x = S; p->grid_y = qby;
         p->partial_floats = (size_t)S * a.Mrows_total * a.CoutP;
     }
+    // XCD-aware order of the workgroups (conv_wgrad_kernel: bx / by); written at the end of round 4, not yet measured: default off
+    static const int env_xcd = [] { const char* e = getenv("OCL_WGRAD_XCD"); return e ? atoi(e) : 0; }();
+    a.xcd_by = (env_xcd && p->grid_y > 1 && a.S >= 8) ? p->grid_y : 0;
     return OCL_OK;
 }
 
@@ -3048,7 +3067,7 @@ int launch_wgrad(const WgradPlan& p, hipStream_t s) {
         return OCL_ERR_STATE;
     }
     ProfScope ps(PROF_WGRAD, s);
-    hipLaunchKernelGGL(fn, dim3(p.grid_x, p.grid_y), dim3(256), p.lds_bytes, s, p.a);
+    hipLaunchKernelGGL(fn, p.a.xcd_by > 0 ? dim3(p.grid_x * p.grid_y, 1) : dim3(p.grid_x, p.grid_y), dim3(256), p.lds_bytes, s, p.a);
     OCL_LAUNCH_CHECK();
     return OCL_OK;
 }
