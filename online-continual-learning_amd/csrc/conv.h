@@ -349,6 +349,7 @@ int launch_colsum(const float* m, int rows, int cols, float* out, int accumulate
 int launch_fill(float* p, int64_t n, float v, hipStream_t s);
 
 int conv_kernels_init();
+int wgrad_kernels_init();   // wgrad.hip; called by conv_kernels_init
 // batch sums as order-independent integers (1) or fp64 atomics (0, default): see StatCell.  Synchronises the device.
 int set_deterministic_sums(int on);
 

@@ -1,6 +1,6 @@
 """CPU: the hot kernels must not use scratch (a private segment is paid at wave launch: profiles/r3_conv_s_ab.md -- a conv_s_kernel build
-with 10 spilled VGPRs was 1 - 4 us per launch slower than the build before it, with a faster loop).  Compiles conv.hip for gfx950 with
-the compiler's resource remarks (no GPU needed) and reads ScratchSize per kernel."""
+with 10 spilled VGPRs was 1 - 4 us per launch slower than the build before it, with a faster loop).  Compiles conv.hip and wgrad.hip for
+gfx950 with the compiler's resource remarks (no GPU needed; the two files side by side) and reads ScratchSize per kernel."""
 import re
 import shutil
 import subprocess
@@ -10,7 +10,7 @@ import pytest
 from conftest import ROOT
 
 HIPCC = "/opt/rocm/bin/hipcc"
-SRC = ROOT + "/online-continual-learning_amd/csrc/conv.hip"
+SRCS = [ROOT + "/online-continual-learning_amd/csrc/" + f for f in ("conv.hip", "wgrad.hip")]
 
 # the kernels a training / eval step launches (templates: the instantiations the planner picks at the BASELINE sizes)
 HOT = [
@@ -29,11 +29,15 @@ HOT = [
 
 @pytest.mark.skipif(not shutil.which(HIPCC), reason="hipcc not installed")
 def test_hot_kernels_use_no_scratch():
-    r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", SRC, "-o", "/dev/null",
-                        "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stderr[-2000:]
+    procs = [subprocess.Popen([HIPCC, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", "/dev/null",
+                               "-Rpass-analysis=kernel-resource-usage"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True) for src in SRCS]
+    remarks = ""
+    for p in procs:
+        _, err = p.communicate(timeout=900)
+        assert p.returncode == 0, err[-2000:]
+        remarks += err
     scratch, cur = {}, None
-    for line in r.stderr.splitlines():
+    for line in remarks.splitlines():
         m = re.search(r"remark:\s+(.*?) \[-Rpass", line)
         if not m:
             continue

@@ -1,4 +1,4 @@
-"""CPU: the convolution / weight-gradient planner (host code of csrc/conv.hip) through `kbench ... plan`, which needs no GPU.
+"""CPU: the convolution / weight-gradient planner (host code of csrc/conv.hip and csrc/wgrad.hip) through `kbench ... plan`, which needs no GPU.
 
 Every layer of Reduced-ResNet18 at the batch sizes the path uses (replay-sized, the SCR step's 220 views, the 410-image eval-mode
 pass, mini-ImageNet's 84x84) must get a tiling that fits the LDS; the experimental three-buffer weight ring (OCL_CONV_PIPE=1,
