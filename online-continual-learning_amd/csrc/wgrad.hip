@@ -44,7 +44,10 @@ struct WTile {
 // TRACE = 1 (measurement build, kbench `wgradtrace`): s_memtime stamps of thread 0 at the phase boundaries into WgradArgs::trace,
 // 64 slots per workgroup: start | prologue done | per tile: passed barrier 1, tile stored, passed barrier 2, next tile's loads issued,
 // K loop done | ... | slab written.
-template <int MTW, int NTW, int PF, int RGW = 0, int TAB = 0, int TRACE = 0>
+// PD = 2 (with TAB; OCL_WGRAD_PD=2, written at the end of round 4, not yet measured): prefetch distance of TWO pixel tiles -- a second set
+// of prefetch registers (the table form freed them), the tile loop unrolled by two, every global load gets two tiles' worth of
+// store + K loop to land instead of one.
+template <int MTW, int NTW, int PF, int RGW = 0, int TAB = 0, int TRACE = 0, int PD = 1>
 __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     int* pixoff = (int*)lds_raw + 4;                // [KP]   (in front of it: the dummy slot of the TAB form)
@@ -277,7 +280,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
             p_lds[i] = (inside ? (int)((patch - (float*)lds_raw) + (row * a.PC + pc) * a.CP + c4 * 4) * 4 : 0) | (c4 << 24);
         }
     }
-    auto load_tile_t = [&](const WTile& t) __attribute__((always_inline)) {
+    auto load_tile_ts = [&](const WTile& t, auto& dv, auto& pv, unsigned& okm, int& pxo) __attribute__((always_inline)) {
         const int dbase = (t.img0 * LP + t.p0) * a.Cout * 4;
         const int ox0 = t.p0 - t.oy0 * a.Wo;
 #pragma unroll
@@ -307,7 +310,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
             okm |= ok ? (1u << i) : 0u;
         }
     };
-    auto store_tile_t = [&](const WTile& t) __attribute__((always_inline)) {
+    auto store_tile_ts = [&](const WTile& t, auto& dv, auto& pv, unsigned& okm, int& pxo) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < TDPF; ++i) *(float4*)(dyt + d_lds[i]) = dv[i];
         pixoff[px_idx] = pxo;
@@ -328,6 +331,13 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
             *(float2*)(d + 2) = make_float2(v.z, v.w);
         }
     };
+    auto load_tile_t = [&](const WTile& t) __attribute__((always_inline)) { load_tile_ts(t, dv, pv, okm, pxo); };
+    auto store_tile_t = [&](const WTile& t) __attribute__((always_inline)) { store_tile_ts(t, dv, pv, okm, pxo); };
+    // second register set of the PD = 2 form
+    constexpr int T2DPF = (TAB && PD == 2) ? DPF : 1, T2PF = (TAB && PD == 2) ? PF : 1;
+    float4 dv2[T2DPF], pv2[T2PF];
+    unsigned okm2 = 0;
+    int pxo2 = 0;
 
     int tr_n = 0;
     auto stamp = [&]() __attribute__((always_inline)) {
@@ -335,29 +345,8 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
             if (tid == 0 && tr_n < 64) a.trace[(size_t)(by * a.S + bx) * 64 + tr_n++] = __builtin_amdgcn_s_memtime();
         }
     };
-    stamp();
-    int tile = bx;
-    WTile cur = geom(tile);
-    if (tile < a.total_tiles) {
-        if constexpr (TAB) load_tile_t(cur);
-        else load_tile(cur);
-    }
-    stamp();
-    for (; tile < a.total_tiles; tile += a.S) {
-        __syncthreads();  // previous tile consumed
-        stamp();
-        if constexpr (TAB) store_tile_t(cur);
-        else store_tile(cur);
-        stamp();
-        __syncthreads();
-        stamp();
-        const int next = tile + a.S;
-        if (next < a.total_tiles) {
-            cur = geom(next);
-            if constexpr (TAB) load_tile_t(cur);
-            else load_tile(cur);
-        }
-        stamp();
+    // the K loop of the tile that sits in LDS
+    auto compute_tile = [&]() __attribute__((always_inline)) {
         if constexpr (RGW > 0) {   // 16 pixels per step (KP is a multiple of 16 in this form); operands of step g + 1 are read while the MFMAs of step g issue
             const float* dq = dyt + (size_t)(lane >> 2) * a.DP + (lane & 3);
             const int* pq = pixoff + (lane >> 2);
@@ -402,7 +391,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
                     for (int k = 0; k < 4; ++k) asm volatile("" : "+a"(qacc[r][s][k]));
             stamp();
-            continue;
+            return;
         }
         const float* pb = dyt + (size_t)g * a.DP + r16;
         // (A hand-pipelined form of this loop -- two operand register sets, the reads of iteration i + 1 issued in front of the MFMAs of
@@ -435,6 +424,66 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
         for (; s + 16 <= a.KP; s += 16) ksteps(s, std::integral_constant<int, 4>());
         for (; s < a.KP; s += 4) ksteps(s, std::integral_constant<int, 1>());
         stamp();
+    
+    };
+    stamp();
+    int tile = bx;
+    WTile cur = geom(tile);
+    if constexpr (TAB && PD == 2) {
+        WTile cur2 = geom(tile + a.S);
+        if (tile < a.total_tiles) load_tile_ts(cur, dv, pv, okm, pxo);
+        if (tile + a.S < a.total_tiles) load_tile_ts(cur2, dv2, pv2, okm2, pxo2);
+        stamp();
+        for (; tile < a.total_tiles; tile += 2 * a.S) {
+            __syncthreads();  // previous tile consumed
+            stamp();
+            store_tile_ts(cur, dv, pv, okm, pxo);
+            stamp();
+            __syncthreads();
+            stamp();
+            if (tile + 2 * a.S < a.total_tiles) {
+                cur = geom(tile + 2 * a.S);
+                load_tile_ts(cur, dv, pv, okm, pxo);
+            }
+            stamp();
+            compute_tile();
+            if (tile + a.S >= a.total_tiles) break;
+            __syncthreads();
+            stamp();
+            store_tile_ts(cur2, dv2, pv2, okm2, pxo2);
+            stamp();
+            __syncthreads();
+            stamp();
+            if (tile + 3 * a.S < a.total_tiles) {
+                cur2 = geom(tile + 3 * a.S);
+                load_tile_ts(cur2, dv2, pv2, okm2, pxo2);
+            }
+            stamp();
+            compute_tile();
+        }
+    } else {
+        if (tile < a.total_tiles) {
+            if constexpr (TAB) load_tile_t(cur);
+            else load_tile(cur);
+        }
+        stamp();
+        for (; tile < a.total_tiles; tile += a.S) {
+            __syncthreads();  // previous tile consumed
+            stamp();
+            if constexpr (TAB) store_tile_t(cur);
+            else store_tile(cur);
+            stamp();
+            __syncthreads();
+            stamp();
+            const int next = tile + a.S;
+            if (next < a.total_tiles) {
+                cur = geom(next);
+                if constexpr (TAB) load_tile_t(cur);
+                else load_tile(cur);
+            }
+            stamp();
+            compute_tile();
+        }
     }
     // partial tile out: rows (chunk, mblock, m), cols co
     const int mrows_chunk = a.mblocks_per_chunk * 64 * MTW;
@@ -522,6 +571,17 @@ static wgrad_fn_t wgrad_trace_fn(int M, int N, int PF, int rgw, int tab) {
     if (M == 2 && N == 3) return conv_wgrad_kernel<2, 3, 8, 0, 1, 1>;
     if (M == 3 && N == 2) return conv_wgrad_kernel<3, 2, 8, 0, 1, 1>;
     if (M == 1 && N == 3) return conv_wgrad_kernel<1, 3, 8, 0, 1, 1>;
+    return nullptr;
+}
+// prefetch distance 2 (PD = 2, OCL_WGRAD_PD=2): the forms the 220-view pass runs most; everything else keeps PD = 1
+static wgrad_fn_t wgrad_pd2_fn(int M, int N, int PF, int rgw, int tab) {
+    if (!tab || PF != 8) return nullptr;
+    if (rgw == 3) return conv_wgrad_kernel<1, 1, 8, 3, 1, 0, 2>;
+    if (rgw) return nullptr;
+    if (M == 2 && N == 3) return conv_wgrad_kernel<2, 3, 8, 0, 1, 0, 2>;
+    if (M == 3 && N == 2) return conv_wgrad_kernel<3, 2, 8, 0, 1, 0, 2>;
+    if (M == 1 && N == 3) return conv_wgrad_kernel<1, 3, 8, 0, 1, 0, 2>;
+    if (M == 1 && N == 2) return conv_wgrad_kernel<1, 2, 8, 0, 1, 0, 2>;
     return nullptr;
 }
 static int wgrad_pf_for(int units) { return units <= 1024 ? 4 : 8; }
@@ -725,6 +785,8 @@ int plan_wgrad(int N, int Hin, int Win, int Cin, int Ho, int Wo, int Cout, int k
         p->grid_x = S; p->grid_y = qby;
         p->partial_floats = (size_t)S * a.Mrows_total * a.CoutP;
     }
+    static const int env_pd = [] { const char* e = getenv("OCL_WGRAD_PD"); return e ? atoi(e) : 1; }();   // prefetch distance in pixel tiles (2: the hot forms only; not yet measured)
+    p->pd = env_pd == 2 ? 2 : 1;
     // XCD-aware order of the workgroups (conv_wgrad_kernel: bx / by); written at the end of round 4, not yet measured: default off
     static const int env_xcd = [] { const char* e = getenv("OCL_WGRAD_XCD"); return e ? atoi(e) : 0; }();
     a.xcd_by = (env_xcd && p->grid_y > 1 && a.S >= 8) ? p->grid_y : 0;
@@ -734,6 +796,8 @@ int plan_wgrad(int N, int Hin, int Win, int Cin, int Ho, int Wo, int Cout, int k
 int launch_wgrad(const WgradPlan& p, hipStream_t s) {
     const int pf = wgrad_pf_for(p.a.imgs * p.a.PR * p.a.PC * (p.a.KC / 4));
     wgrad_fn_t fn = p.q_rgw ? wgrad_q_fn(p.q_rgw, pf, p.tab) : wgrad_fn(p.MTW, p.NTW, pf, p.tab);
+    if (p.pd == 2 && !p.a.trace)
+        if (wgrad_fn_t f2 = wgrad_pd2_fn(p.MTW, p.NTW, pf, p.q_rgw, p.tab)) fn = f2;
     if (p.a.trace) {
         fn = wgrad_trace_fn(p.MTW, p.NTW, pf, p.q_rgw, p.tab);
         if (!fn) {
@@ -799,6 +863,10 @@ int wgrad_kernels_init() {
         for (int pf = 4; pf <= 8; pf += 4)
             for (int tab = 0; tab < 2; ++tab)
                 OCL_HIP(hipFuncSetAttribute((const void*)wgrad_q_fn(r, pf, tab), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+    for (int m = 1; m <= 3; ++m)
+        for (int n = 2; n <= 3; ++n)
+            if (wgrad_fn_t f = wgrad_pd2_fn(m, n, 8, 0, 1)) OCL_HIP(hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+    OCL_HIP(hipFuncSetAttribute((const void*)wgrad_pd2_fn(1, 1, 8, 3, 1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     return OCL_OK;
 }
 
