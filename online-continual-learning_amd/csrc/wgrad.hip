@@ -25,7 +25,7 @@ struct WTile {
 
 //
 // RGW > 0 selects the 4x4x1 form of the product for layers with at most 20 output channels and one channel chunk (stem, layer 1;
-// EXPERIMENTAL, OCL_WGRAD_Q=1, see plan_wgrad).  The 16x16x4 tiles pad layer 1's 180 x 20 gradient to 192 x 32: 41 % of the issued
+// OCL_WGRAD_Q=1, see plan_wgrad).  The 16x16x4 tiles pad layer 1's 180 x 20 gradient to 192 x 32: 41 % of the issued
 // MFMAs multiply zeros, and by the probes of round 3 the kernel is bound by the MFMAs it issues.  With v_mfma_f32_4x4x1_16b_f32 the
 // sixteen blocks of an instruction are sixteen PIXELS (the reduction dimension), and nothing is padded beyond quads:
 //   block b = pixel s0 + b of the tile;   A: lane 4b + i holds the 16-byte unit u = 4 * rowgroup + i = (tap, channel quad) of that
@@ -751,8 +751,8 @@ int plan_wgrad(int N, int Hin, int Win, int Cin, int Ho, int Wo, int Cout, int k
     // units per tile (bit-identical results: scripts/gpu_r4z3.sh, profiles/r4_wgrad_tab_ab.txt)
     static const int env_tab = [] { const char* e = getenv("OCL_WGRAD_TAB"); return e ? atoi(e) : 1; }();
     p->tab = env_tab ? 1 : 0;
-    // EXPERIMENTAL (OCL_WGRAD_Q=1, default off: written at the end of round 4 without GPU time left to validate it): the 4x4x1 form for
-    // <= 20 output channels and a single channel chunk -- stem and layer 1, the two largest pixel counts of the network.
+    // The 4x4x1 form (OCL_WGRAD_Q=1; validated per layer and through the whole pass -- tests/test_gpu_netcheck.py -- but off by default
+    // until the full GPU suite has run with it) for <= 20 output channels and a single channel chunk: layer 1's 3x3 convolutions.
     //   OCL_WGRAD_Q_RGW     row groups (16 gradient rows) per wave, 1..3 (default: the smallest count that covers the rows with one
     //                       row block, i.e. the patch is staged once per pixel tile)
     //   OCL_WGRAD_Q_TARGET  workgroups aimed at by the pixel split (default 256: the block sums of the epilogue cost about one pixel
