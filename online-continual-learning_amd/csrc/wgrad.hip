@@ -24,9 +24,9 @@ struct WTile {
 };
 
 //
-// RGW > 0 selects the 4x4x1 form of the product for layers with at most 20 output channels and one channel chunk (stem, layer 1;
-// OCL_WGRAD_Q=1, see plan_wgrad).  The 16x16x4 tiles pad layer 1's 180 x 20 gradient to 192 x 32: 41 % of the issued
-// MFMAs multiply zeros, and by the probes of round 3 the kernel is bound by the MFMAs it issues.  With v_mfma_f32_4x4x1_16b_f32 the
+// RGW > 0 selects the 4x4x1 form of the product for layers with at most 20 output channels and one channel chunk (layer 1's 3x3
+// convolutions; OCL_WGRAD_Q=1, see plan_wgrad).  The 16x16x4 tiles pad layer 1's 180 x 20 gradient to 192 x 32: 41 % of the issued
+// MFMAs multiply zeros (and the slabs are 32 columns wide for 20 channels).  With v_mfma_f32_4x4x1_16b_f32 the
 // sixteen blocks of an instruction are sixteen PIXELS (the reduction dimension), and nothing is padded beyond quads:
 //   block b = pixel s0 + b of the tile;   A: lane 4b + i holds the 16-byte unit u = 4 * rowgroup + i = (tap, channel quad) of that
 //   pixel's patch (one ds_read_b128 feeds four MFMAs, k = channel inside the quad);   B: lane 4b + j holds dy[pixel][4s + j];
