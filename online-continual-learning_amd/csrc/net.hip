@@ -1083,6 +1083,14 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
     (void)two_streams_arg;
     WgradReduceMulti rm;
     rm.partial = partial; rm.grads = Gr; rm.accumulate = accumulate; rm.n = 0;
+    // Large passes reduce layer by layer (20 launches of 4 - 6 us on the weight-gradient stream).  OCL_REDUCE_GROUP=k (2..4; written at the end
+    // of round 4, not yet measured, default off): k layers write their slabs into regions of 12 MB side by side -- plan_wgrad caps a layer's
+    // split at that -- and ONE launch reduces them; the stem's region (see below) moves behind them.  Same reduction body: same bits.
+    static const int env_group = [] { const char* e = getenv("OCL_REDUCE_GROUP"); return e ? atoi(e) : 0; }();
+    constexpr int64_t kGroupRegion = 12ll << 20;
+    const int group_k = std::min(std::max(env_group, 0), 4);
+    const bool grouped = !batched && group_k >= 2 && n->dbg_stop < 0 && (int64_t)(group_k + 1) * kGroupRegion <= n->partial_floats * 4;
+    const int64_t stem_region = grouped ? (int64_t)group_k * kGroupRegion : (16ll << 20);   // bytes from `partial`
     // xf_conv >= 0: xin is the RAW output of that convolution; its BatchNorm + ReLU is applied while the kernel stages its patches
     auto wgrad = [&](int conv_i, const float* xin, const float* dy, int xf_conv = -1) -> int {   // on the weight-gradient stream
         WgradPlan wp = ps->wgrad[conv_i];
@@ -1097,6 +1105,20 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
             wp.a.xf_invstd = S + b1.save_off + (int64_t)kGmax * b1.C;
             wp.a.xf_gamma = T(b1.gamma_t);
             wp.a.xf_beta = T(b1.beta_t);
+        }
+        if (grouped) {   // (OCL_REDUCE_GROUP=k) slab regions of kGroupRegion bytes side by side, one reduction launch per k layers
+            if ((int64_t)wp.partial_floats * 4 > kGroupRegion || rm.n >= group_k) {
+                if (rm.n > 0 && (rc = launch_wgrad_reduce_multi(rm, sw))) return rc;
+                rm.n = 0;
+            }
+            if ((int64_t)wp.partial_floats * 4 <= kGroupRegion) {
+                const int64_t off = (int64_t)rm.n * (kGroupRegion / 4);
+                wp.a.partial = partial + off;
+                int r = launch_wgrad(wp, sw);
+                if (r) return r;
+                wgrad_reduce_layer(wp, off, n->tensors[n->convs[conv_i].w_t].off, &rm.L[rm.n++]);
+                return OCL_OK;
+            }
         }
         wp.a.partial = batched ? partial + ps->partial_off[conv_i] : partial;
         int r = launch_wgrad(wp, sw);
@@ -1237,15 +1259,19 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
         return OCL_OK;
     }
     if (two_streams) {
+        if (grouped && rm.n > 0) {   // the layers still waiting for their reduction
+            if ((rc = launch_wgrad_reduce_multi(rm, sw))) return rc;
+            rm.n = 0;
+        }
         WgradPlan wp = ps->wgrad[0];
         wp.a.x = S + n->x4_off + (int64_t)img0 * n->d.in_h * n->d.in_w * 4;
         wp.a.dy = gS;
-        wp.a.partial = partial + (int64_t)(16ll << 20) / 4;
-        if ((int64_t)(16ll << 20) / 4 + (int64_t)wp.partial_floats > n->partial_floats) wp.a.partial = nullptr;   // (workspace too small: after the join)
+        wp.a.partial = partial + stem_region / 4;
+        if (stem_region / 4 + (int64_t)wp.partial_floats > n->partial_floats) wp.a.partial = nullptr;   // (workspace too small: after the join)
         // the side stream's slabs start at `partial`: the stem's region is only free beside them while every other layer's slabs end
         // below it (plan_wgrad caps a split at 12 MB, but a single slab of a wider net may exceed that)
         for (size_t i = 1; i < ps->wgrad.size(); ++i)
-            if ((int64_t)ps->wgrad[i].partial_floats * 4 > (16ll << 20)) wp.a.partial = nullptr;
+            if ((int64_t)ps->wgrad[i].partial_floats * 4 > (grouped ? kGroupRegion : (16ll << 20))) wp.a.partial = nullptr;
         if (wp.a.partial) {
             if ((rc = launch_wgrad(wp, s))) return rc;
             if ((rc = launch_wgrad_reduce(wp, GT(n->convs[0].w_t), accumulate, s))) return rc;
@@ -1257,7 +1283,7 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
         if (wp.a.partial) return OCL_OK;
     }
     if ((rc = wgrad(0, S + n->x4_off + (int64_t)img0 * n->d.in_h * n->d.in_w * 4, gS))) return rc;
-    if (batched && rm.n > 0 && (rc = launch_wgrad_reduce_multi(rm, s))) return rc;
+    if ((batched || grouped) && rm.n > 0 && (rc = launch_wgrad_reduce_multi(rm, s))) return rc;
     return OCL_OK;
 }
 

@@ -21,7 +21,9 @@ O=../../gpurun_out/${T}_wgrad.txt
     OCL_DETERMINISTIC=1 OCL_WGRAD_PD=2 timeout 60 ./netcheck $cfg compare /tmp/ref.bin
     echo "# pass time, default sums: default / XCD / PD=2 / both"
     timeout 60 ./netcheck $cfg write /tmp/ref2.bin | head -1
-    for E in "OCL_WGRAD_XCD=1" "OCL_WGRAD_PD=2" "OCL_WGRAD_XCD=1 OCL_WGRAD_PD=2"; do env $E timeout 60 ./netcheck $cfg compare /tmp/ref2.bin | grep -E "netcheck|beyond"; done
+    for E in "OCL_WGRAD_XCD=1" "OCL_WGRAD_PD=2" "OCL_WGRAD_XCD=1 OCL_WGRAD_PD=2" "OCL_REDUCE_GROUP=4" "OCL_REDUCE_GROUP=2"; do echo -n "[$E] "; env $E timeout 60 ./netcheck $cfg compare /tmp/ref2.bin | grep -E "netcheck|beyond" | tr '\n' ' '; echo; done
+    echo "# OCL_REDUCE_GROUP=4, order-independent sums: must be bit-identical"
+    OCL_DETERMINISTIC=1 OCL_REDUCE_GROUP=4 timeout 60 ./netcheck $cfg compare /tmp/ref.bin | tail -1
   done
 } > $O 2>&1
 cut -c1-260 $O
