@@ -129,3 +129,16 @@ def test_weight_gradient_forms_chosen_by_the_planner():
     for n, groups, hw in [(20, 1, 32), (20, 1, 84)]:
         assert not any(_fields(l)["q4"] for l in _plan_lines(n, groups, hw, {"OCL_WGRAD_Q": "1"}) if " wgrad " in l)
     assert any(_fields(l)["q4"] for l in _plan_lines(20, 1, 84, {"OCL_WGRAD_Q": "2"}) if " wgrad " in l)   # (2 lifts the size gate)
+
+
+def test_weight_gradient_schedule_switches_default_off_and_plan_consistent():
+    """OCL_WGRAD_XCD / OCL_WGRAD_PD (written at the end of round 4, not yet measured): off by default; the XCD-aware order is only planned for
+    launches with more than one output block and at least 8 pixel splits, and carries the plan's own block count."""
+    for l in [l for l in _plan_lines(220, 2, 32) if " wgrad " in l]:
+        f = _fields(l)
+        assert f["pd"] == 1 and f["xcd"] == 0
+    for l in [l for l in _plan_lines(220, 2, 32, {"OCL_WGRAD_XCD": "1", "OCL_WGRAD_PD": "2"}) if " wgrad " in l]:
+        f = _fields(l)
+        gx, gy = (int(v) for v in re.search(r"grid= *(\d+)x *(\d+)", l).groups())
+        assert f["pd"] == 2
+        assert f["xcd"] == (gy if gy > 1 and gx >= 8 else 0) and gx == f["S"]
