@@ -927,7 +927,10 @@ __global__ void __launch_bounds__(256, PIPE ? 1 : 2) conv_t_kernel(const ConvArg
 // The operand traffic per MFMA is what limits the form (the weights are re-read per 64-pixel set), hence NTQ >= 2 sets per wave and one
 // workgroups per CU kept at two by LDS and registers.  Weights are always resident (<= 14.4 KB); tables, patch staging, input transform and epilogue flags as in
 // conv_t_kernel.
-template <int NTQ, int PF, int STATS>   // 0: no sums; 1: forward batch statistics (EPI_STATS); 2: BatchNorm-backward sums (EPI_BNB)
+// TRACE = 1 (measurement build, launched when ConvArgs::trace is set: kbench KBENCH_TRACE): s_memtime stamps of thread 0 -- start |
+// tables + weight DMA + first patch landed | per tile: passed barrier 1, patch stored + next patch requested + passed barrier 2, K loop
+// done, epilogue done | statistics flushed.
+template <int NTQ, int PF, int STATS, int TRACE = 0>   // STATS 0: no sums; 1: forward batch statistics (EPI_STATS); 2: BatchNorm-backward sums (EPI_BNB)
 __global__ void __launch_bounds__(256, 2) conv_q_kernel(const ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     constexpr int MB = kQBlocks, COPW = 4 * MB;
@@ -945,6 +948,13 @@ __global__ void __launch_bounds__(256, 2) conv_q_kernel(const ConvArgs a) {
     const int t_begin = (int)(((int64_t)blockIdx.x * ntiles_all) / gridDim.x), t_end = (int)(((int64_t)(blockIdx.x + 1) * ntiles_all) / gridDim.x);
     const int nwt = t_end - t_begin;
     if (nwt <= 0) return;
+    int tr_n = 0;
+    auto stamp = [&]() __attribute__((always_inline)) {
+        if constexpr (TRACE) {
+            if (tid == 0 && tr_n < 64) a.trace[(size_t)blockIdx.x * 64 + tr_n++] = __builtin_amdgcn_s_memtime();
+        }
+    };
+    stamp();
     const int flags = STATS == 1 ? (a.flags & ~EPI_BNB) : STATS == 2 ? (a.flags & ~EPI_STATS) : (a.flags & ~(EPI_STATS | EPI_BNB));   // (instantiated without the statistics: no partial sums in registers)
     // ---- plan tables (conv_plan_tables) ----------------------------------------------------------------------------------------
     const int* __restrict__ blob = a.blob;
@@ -1074,6 +1084,7 @@ __global__ void __launch_bounds__(256, 2) conv_q_kernel(const ConvArgs a) {
         __syncthreads();
     };
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own weight DMA (and the first patch) landed; the tile loop's barriers publish
+    stamp();
     const float* wlane = wl + (size_t)(lane & 3) * 4;
     for (int k = 0; k < nwt; ++k) {
         const int4 d0 = *(const int4*)(tdesc + k * 8);
@@ -1112,9 +1123,11 @@ __global__ void __launch_bounds__(256, 2) conv_q_kernel(const ConvArgs a) {
 #pragma unroll
             for (int nt = 0; nt < NTQ; ++nt) acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         __syncthreads();   // consumers of the previous patch are done
+        stamp();
         store_patch(d0.z, d1.y);
         if (k + 1 < nwt) load_patch_d(*(const int4*)(tdesc + (k + 1) * 8));
         __syncthreads();   // patch (and, the first time, the weights and the transform table) visible
+        stamp();
         {   // K loop: one (tap, channel quad) group per step, operands of group q + 1 read while the MFMAs of group q issue
             const int nq = a.Qc;
             float4 bv[2][NTQ], av[2][MB];
@@ -1150,6 +1163,7 @@ __global__ void __launch_bounds__(256, 2) conv_q_kernel(const ConvArgs a) {
             }
             if (q < nq) fma(0);
         }
+        stamp();
         if (STATS == 1 && (flags & EPI_STATS)) {   // this tile's sums over the wave's pixels -> the wave's accumulator slot
             float* rw = qrows + (size_t)(wave * 4 + (lane >> 4)) * 2 * COPW;
 #pragma unroll
@@ -1237,8 +1251,10 @@ __global__ void __launch_bounds__(256, 2) conv_q_kernel(const ConvArgs a) {
 #pragma unroll
                 for (int m = 0; m < MB; ++m) epi_one(nt, m, nb1, nb2);
         }
+        stamp();
     }
     if ((flags & (EPI_STATS | EPI_BNB)) && run_grp >= 0) flush_stats();
+    stamp();
 }
 
 
@@ -2237,6 +2253,10 @@ void geom_dgrad(const ConvShape& c, int N, std::vector<ConvGeomDesc>* out, bool 
     }
 }
 
+static conv_fn_t convq_trace_fn(int ntq, int pf, int stats) {   // measurement builds: the 220-view plans of layer 1
+    if (ntq != 2 || pf != 12) return nullptr;
+    return stats == 2 ? conv_q_kernel<2, 12, 2, 1> : stats == 1 ? conv_q_kernel<2, 12, 1, 1> : conv_q_kernel<2, 12, 0, 1>;
+}
 static conv_fn_t convq_fn(int ntq, int pf, int stats) {   // stats: 0 none, 1 EPI_STATS, 2 EPI_BNB
 #define OCL_CASE(N, P)                                                                                                         \
     if (ntq == N && pf == P) return stats == 2 ? conv_q_kernel<N, P, 2> : stats == 1 ? conv_q_kernel<N, P, 1> : conv_q_kernel<N, P, 0>;
@@ -2259,6 +2279,11 @@ int launch_conv(const ConvPlan& p, hipStream_t s) {
     }
     if (p.q4) {
         conv_fn_t fq = convq_fn(p.q4, (p.a.off_loc - p.a.off_pu) / (3 * 256), (p.a.flags & EPI_BNB) ? 2 : (p.a.flags & EPI_STATS) ? 1 : 0);
+        if (p.a.trace)
+            if (conv_fn_t ft = convq_trace_fn(p.q4, (p.a.off_loc - p.a.off_pu) / (3 * 256), (p.a.flags & EPI_BNB) ? 2 : (p.a.flags & EPI_STATS) ? 1 : 0)) {
+                fq = ft;
+                OCL_HIP(hipFuncSetAttribute((const void*)fq, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+            }
         if (!fq || !p.a.blob) {
             set_error("launch_conv: no conv_q_kernel for q4=%d / plan without device tables", p.q4);
             return OCL_ERR_STATE;

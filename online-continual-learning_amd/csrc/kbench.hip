@@ -306,7 +306,50 @@ static void bench_geom(const char* lname, const char* kind, ConvGeomDesc g, cons
                     }
                     CK(hipFree(tr));
                 }
-                if (mt == 0 && !pt.cs && pt.a.wres && getenv("KBENCH_TRACE")) {   // phase timeline of wave 0 of a few workgroups (s_memtime cycles)
+                if (mt == 0 && pt.q4 == 2 && getenv("KBENCH_TRACE")) {   // conv_q_kernel<2, 12, *>: mean phase lengths over the workgroups (s_memtime ticks)
+                    const int nwg = pt.grid_x * pt.grid_y;
+                    unsigned long long* tr;
+                    CK(hipMalloc(&tr, (size_t)nwg * 64 * 8));
+                    CK(hipMemset(tr, 0, (size_t)nwg * 64 * 8));
+                    ConvPlan ptt = pt;
+                    ptt.a.trace = tr;
+                    stats = stats2;
+                    run(ptt, out);
+                    CK(hipMemset(tr, 0, (size_t)nwg * 64 * 8));
+                    run(ptt, out);   // (second launch: warm caches)
+                    stats = keep2;
+                    CK(hipDeviceSynchronize());
+                    std::vector<unsigned long long> h((size_t)nwg * 64);
+                    CK(hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost));
+                    double pro = 0, ph[4] = {0, 0, 0, 0}, fl = 0, life = 0;
+                    long ntile = 0;
+                    int nlive = 0;
+                    unsigned long long t0 = ~0ull, t1 = 0;
+                    for (int w = 0; w < nwg; ++w) {
+                        const unsigned long long* r = &h[(size_t)w * 64];
+                        if (!r[0]) continue;   // (a workgroup without tiles, or not a trace build)
+                        int last = 0;
+                        while (last + 1 < 64 && r[last + 1]) ++last;
+                        if (last < 2) continue;
+                        ++nlive;
+                        t0 = std::min(t0, r[0]); t1 = std::max(t1, r[last]);
+                        pro += (double)(r[1] - r[0]);
+                        life += (double)(r[last] - r[0]);
+                        int e = 1;
+                        for (; e + 4 <= last; e += 4) {
+                            for (int k = 0; k < 4; ++k) ph[k] += (double)(r[e + k + 1] - r[e + k]);
+                            ++ntile;
+                        }
+                        if (e < last) fl += (double)(r[last] - r[e]);
+                    }
+                    if (nlive && ntile)
+                        printf("      trace conv_q: %d workgroups, %.1f tiles each, span %llu | prologue (tables, weights, first patch) %6.0f  lifetime %7.0f  flush %5.0f | per tile: barrier1 %5.0f  store + next request + barrier2 %5.0f  K loop %6.0f  epilogue %6.0f\n",
+                               nlive, (double)ntile / nlive, t1 - t0, pro / nlive, life / nlive, fl / nlive, ph[0] / ntile, ph[1] / ntile, ph[2] / ntile, ph[3] / ntile);
+                    else
+                        printf("      trace conv_q: no stamps (not a trace build of this plan)\n");
+                    CK(hipFree(tr));
+                }
+                if (mt == 0 && !pt.cs && !pt.q4 && pt.a.wres && getenv("KBENCH_TRACE")) {   // phase timeline of wave 0 of a few workgroups (s_memtime cycles)
                     const int nwg = pt.grid_x * pt.grid_y;
                     unsigned long long* tr;
                     CK(hipMalloc(&tr, (size_t)nwg * 64 * 8));

@@ -25,5 +25,7 @@ O=../../gpurun_out/${T}_wgrad.txt
     echo "# OCL_REDUCE_GROUP=4, order-independent sums: must be bit-identical"
     OCL_DETERMINISTIC=1 OCL_REDUCE_GROUP=4 timeout 60 ./netcheck $cfg compare /tmp/ref.bin | tail -1
   done
+  echo "### conv_q_kernel<2,12,*> (layer 1 at 220 views): phase timeline, KBENCH_TRACE=1 kbench 220 2 32 conv 0"
+  KBENCH_TRACE=1 timeout 90 ./kbench 220 2 32 conv 0 2>&1 | grep -E "^conv1|^layer1|trace conv_q|conv_q "
 } > $O 2>&1
 cut -c1-260 $O

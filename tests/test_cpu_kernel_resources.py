@@ -15,7 +15,7 @@ SRCS = [ROOT + "/online-continual-learning_amd/csrc/" + f for f in ("conv.hip", 
 # the kernels a training / eval step launches (templates: the instantiations the planner picks at the BASELINE sizes)
 HOT = [
     r"conv_s_kernel<1, false, (true|false), false>", r"conv_s_kernel<2, false, (true|false), false>",   # (the deterministic-mode instantiations <..., true> spill 4 VGPRs: that mode costs 12 % anyway)
-    r"conv_q_kernel<2, 4, [012]>", r"conv_q_kernel<2, 12, [012]>", r"conv_q_kernel<1, 12, [012]>",
+    r"conv_q_kernel<2, 4, [012], 0>", r"conv_q_kernel<2, 12, [012], 0>", r"conv_q_kernel<1, 12, [012], 0>",
     r"conv_t_kernel<3, 1, 8, true, false, false, (true|false)>", r"conv_t_kernel<5, 1, 8, false, false, true, (true|false)>",
     r"conv_t_kernel<3, 1, 8, false, false, true, (true|false)>",
     r"conv_t_kernel<1, 1, 8, (true|false), (true|false), (true|false), false>", r"conv_t_kernel<2, 1, 4, true, (true|false), false, false>",
