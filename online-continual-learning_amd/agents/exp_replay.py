@@ -122,8 +122,7 @@ class ExperienceReplay(ContinualLearner):
         aser = self.params.update == 'ASER' or self.params.retrieve == 'ASER'
         # Random retrieval reads neither the model nor its gradients and nothing between the batch forward and the retrieval draws
         # from an RNG, so retrieving first leaves every RNG stream as the reference's order does.
-        merge = (self.params.retrieve == 'random' and not aser and not trick['kd_trick'] and not trick['kd_trick_star']
-                 and os.environ.get("OCL_ER_MERGE", "1") != "0")
+        merge = self.params.retrieve == 'random' and not aser and not trick['kd_trick'] and not trick['kd_trick_star']
 
         # ASER update: its host half (wait for the ranking, class-table bookkeeping, row moves) leaves the GPU idle, and the first
         # forward of the NEXT iteration (batch pass: reads the weights, which are final after opt.step, and updates the running

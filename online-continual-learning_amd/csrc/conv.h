@@ -204,9 +204,7 @@ struct WgradArgs {
 struct WgradPlan {
     WgradArgs a;
     int MTW, NTW;
-    int pd;                     // prefetch distance in pixel tiles: 1, or 2 (OCL_WGRAD_PD=2; conv_wgrad_kernel<..., PD = 2>, the hot forms only)
-    int tab;                    // 1: tile-invariant staging tables in registers (conv_wgrad_kernel<..., TAB = 1>); OCL_WGRAD_TAB
-    int q_rgw;                  // > 0: the 4x4x1 form (conv_wgrad_kernel<1, 1, PF, q_rgw>: row groups per wave); experimental, OCL_WGRAD_Q=1
+    int q_rgw;                  // > 0: the 4x4x1 form (conv_wgrad_kernel<1, 1, PF, q_rgw>: row groups per wave), layer 1 of the large passes
     int grid_x, grid_y;
     size_t lds_bytes;
     size_t partial_floats;

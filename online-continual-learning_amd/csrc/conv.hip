@@ -1657,8 +1657,7 @@ static size_t convt_layout(const ConvGeomDesc& g, ConvArgs& a, int MT, int NT, b
             a.Qpad = 0;   // every class's groups are padded to whole rounds of 4
             for (int c = 0; c < std::max(1, g.ncls); ++c) a.Qpad += (int)round_up((g.ncls > 1 ? g.cls_ntaps[c] : g.ntaps) * (KC / 4), 4);
             const size_t w_all = (size_t)a.Qpad * COPW * 16;
-            static const size_t res_limit = [] { const char* e = getenv("OCL_RES_KB"); return e ? (size_t)atoi(e) * 1024 : kResidentBytes; }();   // (measurement knob)
-            a.wres = (KC == g.Cin && w_all <= res_limit) ? 1 : 0;
+            a.wres = (KC == g.Cin && w_all <= kResidentBytes) ? 1 : 0;
             a.pipe = (pipe && !a.wres && NT == 1) ? 1 : 0;   // ring of three stage buffers of pipe_qs(MT) groups (conv_t_kernel<..., PIPE>)
             a.QS = a.wres ? a.Qpad : a.pipe ? pipe_qs(MT) : std::min(a.Qpad, ((256 * kWPF) / COPW) & ~3);
             a.nstage = cdiv(a.Qpad, a.QS);
@@ -1815,8 +1814,7 @@ static int plan_conv_s_nt(const ConvGeomDesc& g, ConvPlan* p, int NT) {
     // every wave) at any batch size; larger lattices (layer 3) below 1000 units of conv_t_kernel work (< 200 images), where that
     // kernel's resident-weight plan takes over (26.9 vs 30.2 us at 220 images).
     const int64_t tiles64 = (int64_t)g.groups * (LP >= 64 ? (int64_t)a.group_size * cdiv(LP, 64) : cdiv(a.group_size, std::max(1, 64 / LP)));
-    static const int env_units = [] { const char* e = getenv("OCL_CONV_S_UNITS"); return e ? atoi(e) : 1000; }();   // measurement knob
-    if (g.force_cs <= 0 && ((LP > 16 && tiles64 * cdiv(g.Cout, 16) >= env_units) || a.Qc <= 36)) return OCL_ERR_ARG;
+    if (g.force_cs <= 0 && ((LP > 16 && tiles64 * cdiv(g.Cout, 16) >= 1000) || a.Qc <= 36)) return OCL_ERR_ARG;
     a.cls_pack = 1 | (g.ntaps << 4);
     a.cls_oyx = 0;
     p->cs = 1; p->q4 = 0; p->MT = 1; p->NT = NT;
@@ -2846,7 +2844,8 @@ __global__ void __launch_bounds__(kBnFusedThreads) bn_bwd_fused_kernel(const BnB
 static int g_bn_bwd_cap = 0, g_bn_bwd_unroll = 0, g_bn_bwd_phase = 0;   // micro-benchmark overrides (kbench)
 void bn_bwd_tune(int cap, int unroll, int phase) { g_bn_bwd_cap = cap; g_bn_bwd_unroll = unroll; g_bn_bwd_phase = phase; }
 
-static int g_bn_fused = -1;   // -1: environment (OCL_BN_FUSED, default on)
+static int g_bn_fused = -1;   // -1: environment (OCL_BN_FUSED, default on; 0 = the reduce + apply pair that passes of > 2 groups use anyway: the way out when a
+                              // shared GPU cannot hold the one-pass kernel's grid-wide arrival, see check_async_error; tests/test_gpu_ring.py)
 static int g_num_cus = 0;
 void bn_bwd_fused_enable(int on) { g_bn_fused = on; }
 

@@ -844,9 +844,9 @@ int main(int argc, char** argv) {
             }
             WgradPlan wp;
             OK(plan_wgrad(N, c.Hin, c.Win, c.CinT, c.Ho, c.Wo, c.Cout, c.k, c.stride, &wp));
-            printf("%-20s wgrad  M=%4d N=%3d K=%7d  MTW=%d NTW=%d grid=%4dx%3d lds=%6zu KC=%3d CP=%3d S=%4d tiles=%d KP=%d tab=%d q4=%d pd=%d xcd=%d partial=%6.2f MB\n", l.name.c_str(),
+            printf("%-20s wgrad  M=%4d N=%3d K=%7d  MTW=%d NTW=%d grid=%4dx%3d lds=%6zu KC=%3d CP=%3d S=%4d tiles=%d KP=%d q4=%d xcd=%d partial=%6.2f MB\n", l.name.c_str(),
                    c.k * c.k * c.CinT, c.Cout, N * c.Ho * c.Wo, wp.MTW, wp.NTW, wp.grid_x, wp.grid_y, wp.lds_bytes, wp.a.KC, wp.a.CP, wp.a.S,
-                   wp.a.total_tiles, wp.a.KP, wp.tab, wp.q_rgw, wp.pd, wp.a.xcd_by, wp.partial_floats * 4e-6);
+                   wp.a.total_tiles, wp.a.KP, wp.q_rgw, wp.a.xcd_by, wp.partial_floats * 4e-6);
         }
         return 0;
     }

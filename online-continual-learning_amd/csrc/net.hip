@@ -124,7 +124,9 @@ struct ocl_net {
     struct GraphKey {
         int kind, N, G, slot, a, b, c;
         uint64_t p;
-        bool operator<(const GraphKey& o) const { return memcmp(this, &o, sizeof(GraphKey)) < 0; }
+        bool operator<(const GraphKey& o) const {   // field by field: the struct has padding bytes a copy need not preserve
+            return std::tie(kind, N, G, slot, a, b, c, p) < std::tie(o.kind, o.N, o.G, o.slot, o.a, o.b, o.c, o.p);
+        }
     };
     struct GraphSlot {
         hipGraphExec_t exec = nullptr;
@@ -354,6 +356,11 @@ static int build_layout(ocl_net* n) {
     return OCL_OK;
 }
 
+// Stage 2 of the BatchNorm-backward epilogue (the stem's BatchNorm and layer1.0.bn2 through the data gradient that completes their dL/dz)
+// pays on passes of up to ~160 x 32 x 32 input pixels (20 images: -20 us per pass, 20 x 84 x 84: -10 us) and loses at SCR's 220 views
+// (+17 us: the epilogue's y / mask loads on 18 MB tensors are exposed once per launch): profiles/r5_switches_netcheck.txt
+static const int64_t kBnbEpi2MaxPix = 160 * 1024;
+
 static int get_plans(ocl_net* n, int N, int groups, PlanSet** out) {
     auto key = std::make_pair(N, groups);
     auto it = n->plans.find(key);
@@ -378,15 +385,15 @@ static int get_plans(ocl_net* n, int N, int groups, PlanSet** out) {
         if (rc != OCL_OK) return rc;
         n->pack_need_fwd |= PACK_TF;
         if (c.Cin != 3) {
-            // stride-2 3x3: the four parity classes as one launch where conv_t_kernel can take them (OCL_DGRAD_MERGE=0: four launches)
-            static const bool merge = [] { const char* e = getenv("OCL_DGRAD_MERGE"); return !(e && e[0] == '0'); }();
+            // stride-2 3x3: the four parity classes as one launch where conv_t_kernel can take them (else four launches)
+            const bool merge = true;
             std::vector<ConvGeomDesc> dg;
-            // (stage 2, OCL_BNB_EPI2=1, written at the end of round 4 and NOT yet run on a GPU: the data gradient of conv1 of an identity
-            // block completes dL/dz of the block in front of it -- or of the stem -- and carries the reduction half of THAT BatchNorm's
-            // backward (bn2 of a block without a projection shortcut, the stem's) the same way; see trunk_backward)
-            static const bool env_bnb2 = [] { const char* e = getenv("OCL_BNB_EPI2"); return e && e[0] == '1'; }();
+            // (stage 2, passes up to kBnbEpi2MaxPix: the data gradient of conv1 of an identity block completes dL/dz of the block in front
+            // of it -- or of the stem -- and carries the reduction half of THAT BatchNorm's backward (bn2 of a block without a projection
+            // shortcut, the stem's) the same way; see trunk_backward)
+            const bool size_bnb2 = (int64_t)N * n->d.in_h * n->d.in_w <= kBnbEpi2MaxPix;
             bool bnb2 = false;
-            if (env_bnb && env_bnb2 && c.stride == 1 && groups <= 2)
+            if (env_bnb && size_bnb2 && c.stride == 1 && groups <= 2)
                 for (size_t k = 0; k < n->blocks.size(); ++k)
                     if (n->blocks[k].conv1 == (int)i && n->blocks[k].convs < 0 && (k == 0 || n->blocks[k - 1].convs < 0)) bnb2 = true;
             const bool bnb = (env_bnb && c.xf_src >= 0 && c.stride == 1 && groups <= 2) || bnb2;   // conv2 of a block: its data gradient enters bn1's backward
@@ -564,11 +571,10 @@ static const int kSideExtraMinBatch = 96;   // projection shortcut / head weight
 static int ensure_side_stream(ocl_net* n) {
     if (n->s2) return OCL_OK;
     {   // the weight gradients are needed by nobody until the optimiser step: their stream yields to the dependent chain when both
-        // have workgroups to place (OCL_SIDE_PRIO=0: same priority)
+        // have workgroups to place
         int lo = 0, hi = 0;
         OCL_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lo = least urgent (numerically greatest)
-        static const bool env_noprio = [] { const char* e = getenv("OCL_SIDE_PRIO"); return e && e[0] == '0'; }();
-        OCL_HIP(hipStreamCreateWithPriority(&n->s2, hipStreamNonBlocking, env_noprio ? 0 : lo));
+        OCL_HIP(hipStreamCreateWithPriority(&n->s2, hipStreamNonBlocking, lo));
     }
     for (int i = 0; i < ocl_net::kDyRing; ++i) OCL_HIP(hipEventCreateWithFlags(&n->ev_done[i], hipEventDisableTiming));
     OCL_HIP(hipEventCreateWithFlags(&n->ev_join, hipEventDisableTiming));
@@ -735,6 +741,10 @@ int ocl_net_bind(ocl_net* net, float* params, float* grads, float* running, int6
     net->descs_uploaded = false;
     net->pack_src = nullptr;
     for (size_t i = 0; i < net->slot_valid.size(); ++i) net->slot_valid[i] = false;
+    // captured launch sequences hold the previous binding's workspace / gradient / statistics pointers
+    for (auto& kv : net->graphs)
+        if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
+    net->graphs.clear();
     return OCL_OK;
 }
 
@@ -900,14 +910,11 @@ int ocl_net_forward_segments(ocl_net* n, const float* const* xs, const int32_t* 
     float* feat = feat_direct ? feat_out : S + n->feat_off;
     const bool upd = (flags & OCL_FWD_UPDATE_RUNNING) != 0;
     static const bool env_single = [] { const char* e = getenv("OCL_SINGLE_STREAM"); return e && e[0] == '1'; }();
-    static const bool env_noextra = [] { const char* e = getenv("OCL_SIDE_EXTRA"); return e && e[0] == '0'; }();
-    static const bool env_nofuse = [] { const char* e = getenv("OCL_BN1_FUSE"); return e && e[0] == '0'; }();
-    // (threshold in images x input pixels: MIR's 50-image 84 x 84 passes qualify, 5.05 -> 4.99 ms per step; OCL_SIDE_EXTRA_MIN_PIX overrides)
-    static const int64_t env_side_pix = [] { const char* e = getenv("OCL_SIDE_EXTRA_MIN_PIX"); return e ? (int64_t)atoll(e) : (int64_t)kSideExtraMinBatch * 1024; }();
-    const bool side_big = (int64_t)N * n->d.in_h * n->d.in_w >= env_side_pix;
-    const bool side = train && n->dbg_stop < 0 && side_big && !prof_on() && !env_single && !env_noextra;
+    // (threshold in images x input pixels: MIR's 50-image 84 x 84 passes qualify, 5.05 -> 4.99 ms per step)
+    const bool side_big = (int64_t)N * n->d.in_h * n->d.in_w >= (int64_t)kSideExtraMinBatch * 1024;
+    const bool side = train && n->dbg_stop < 0 && side_big && !prof_on() && !env_single;
     if (side && (rc = ensure_side_stream(n))) return rc;
-    const bool fused = train && !frozen && !env_nofuse;
+    const bool fused = train && !frozen;
     const bool want_head = out || (flags & OCL_FWD_SAVE_TAPE);
     float* head_out2 = replay ? nullptr : out;   // the head's last kernel writes the caller's array as well (not when replayed)
     bool wrote = false;
@@ -996,7 +1003,6 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
     float* partial = n->partialbuf();
     StatCell* bsums = n->bsumsbuf();
     int rc = OCL_OK;
-    const bool two_streams_arg = side != nullptr;
     if (!n->bsums_clean) OCL_HIP(hipMemsetAsync(bsums, 0, n->bsums_doubles * sizeof(StatCell), s));   // a second backward since the last forward
     n->bsums_clean = false;
     auto T = [&](int t) { return P + n->tensors[t].off; };
@@ -1076,20 +1082,17 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
     };
     // one stream (replay-sized batches: bound by the number of dependent launches): every layer writes its slabs into its own region
     // and ONE launch at the end of the backward reduces them all
-    static const bool env_noreduce = [] { const char* e = getenv("OCL_BATCHED_REDUCE"); return e && e[0] == '0'; }();
     // (with a side stream too: the small launches of a replay-sized backward leave most of the machine idle, so the weight gradients
     // run BESIDE the dependent chain there, each layer into its own slab region, and one launch at the end reduces them all)
-    const bool batched = Nc < kTwoStreamMinBatch && ps->batched_reduce && !env_noreduce && n->dbg_stop < 0;
-    (void)two_streams_arg;
+    const bool batched = Nc < kTwoStreamMinBatch && ps->batched_reduce && n->dbg_stop < 0;
     WgradReduceMulti rm;
     rm.partial = partial; rm.grads = Gr; rm.accumulate = accumulate; rm.n = 0;
-    // Large passes reduce layer by layer (20 launches of 4 - 6 us on the weight-gradient stream).  OCL_REDUCE_GROUP=k (2..4; written at the end
-    // of round 4, not yet measured, default off): k layers write their slabs into regions of 12 MB side by side -- plan_wgrad caps a layer's
-    // split at that -- and ONE launch reduces them; the stem's region (see below) moves behind them.  Same reduction body: same bits.
-    static const int env_group = [] { const char* e = getenv("OCL_REDUCE_GROUP"); return e ? atoi(e) : 0; }();
+    // Large passes: four layers write their slabs into regions of 12 MB side by side -- plan_wgrad caps a layer's split at that -- and ONE
+    // launch reduces them (20 reductions of 4 - 6 us on the weight-gradient stream -> 5; same reduction body: same bits; the 220-view
+    // pass 1978 -> 1953 us, groups of two 1965: profiles/r5_wgrad_switches.txt); the stem's region (see below) lies behind them.
     constexpr int64_t kGroupRegion = 12ll << 20;
-    const int group_k = std::min(std::max(env_group, 0), 4);
-    const bool grouped = !batched && group_k >= 2 && n->dbg_stop < 0 && (int64_t)(group_k + 1) * kGroupRegion <= n->partial_floats * 4;
+    constexpr int group_k = 4;
+    const bool grouped = !batched && n->dbg_stop < 0 && (int64_t)(group_k + 1) * kGroupRegion <= n->partial_floats * 4;
     const int64_t stem_region = grouped ? (int64_t)group_k * kGroupRegion : (16ll << 20);   // bytes from `partial`
     // xf_conv >= 0: xin is the RAW output of that convolution; its BatchNorm + ReLU is applied while the kernel stages its patches
     auto wgrad = [&](int conv_i, const float* xin, const float* dy, int xf_conv = -1) -> int {   // on the weight-gradient stream
@@ -1106,7 +1109,7 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
             wp.a.xf_gamma = T(b1.gamma_t);
             wp.a.xf_beta = T(b1.beta_t);
         }
-        if (grouped) {   // (OCL_REDUCE_GROUP=k) slab regions of kGroupRegion bytes side by side, one reduction launch per k layers
+        if (grouped) {   // slab regions of kGroupRegion bytes side by side, one reduction launch per group_k layers
             if ((int64_t)wp.partial_floats * 4 > kGroupRegion || rm.n >= group_k) {
                 if (rm.n > 0 && (rc = launch_wgrad_reduce_multi(rm, sw))) return rc;
                 rm.n = 0;
@@ -1226,7 +1229,7 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
             if (stop_here(bi, 4)) return OCL_OK;
             if ((rc = dgrad(b.convs, gC, gE, nullptr, nullptr, EPI_ACCUM))) return rc;
         } else {
-            // + identity shortcut: dz * (z>0).  Stage 2 (OCL_BNB_EPI2=1): this launch completes dL/dz of the block in front (of the stem for
+            // + identity shortcut: dz * (z>0).  Stage 2 (small passes, get_plans): this launch completes dL/dz of the block in front (of the stem for
             // block 0), so its epilogue also masks that gradient with (xin > 0) and sums it for the BatchNorm behind xin
             const bool single_target = bi == 0 || n->blocks[bi - 1].convs < 0;
             const bool epi2 = ps->dgrad_bnb[b.conv1] && single_target && !frozen && G <= 2 && n->dbg_stop < 0;
@@ -1336,16 +1339,13 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
     // 10-20 images are latency-bound: the event traffic costs more than the overlap returns there.  Debug stops and measurement
     // runs (ocl_prof_enable, OCL_SINGLE_STREAM=1: per-kernel durations of the kernel alone) stay on one stream as well.
     static const bool env_single = [] { const char* e = getenv("OCL_SINGLE_STREAM"); return e && e[0] == '1'; }();
-    // OCL_TWO_STREAM_MIN_PIX: smallest pass (images x input pixels) whose weight gradients leave the caller's stream
-    static const int64_t env_min_pix = [] { const char* e = getenv("OCL_TWO_STREAM_MIN_PIX"); return e ? (int64_t)atoll(e) : (int64_t)kTwoStreamMinBatch * 1024; }();
-    const bool two_streams = n->dbg_stop < 0 && (int64_t)N * n->d.in_h * n->d.in_w >= env_min_pix && !prof_on() && !env_single;
+    // kTwoStreamMinBatch x 32 x 32 input pixels: the smallest pass whose weight gradients leave the caller's stream
+    const bool two_streams = n->dbg_stop < 0 && (int64_t)N * n->d.in_h * n->d.in_w >= (int64_t)kTwoStreamMinBatch * 1024 && !prof_on() && !env_single;
     if (two_streams && (rc = ensure_side_stream(n))) return rc;
     auto lin_bwd = [&](const float* dy, int ncol, const float* xin, int kin, int tw, int tb, float* dx) -> int {
         // y = x W^T + b, W [ncol, kin]
-        static const bool env_noextra = [] { const char* e = getenv("OCL_SIDE_EXTRA"); return e && e[0] == '0'; }();
-        static const int64_t env_side_pix = [] { const char* e = getenv("OCL_SIDE_EXTRA_MIN_PIX"); return e ? (int64_t)atoll(e) : (int64_t)kSideExtraMinBatch * 1024; }();
-        const bool hs_big = (int64_t)N * n->d.in_h * n->d.in_w >= env_side_pix;
-        const bool hs = two_streams && hs_big && !env_noextra;
+        const bool hs_big = (int64_t)N * n->d.in_h * n->d.in_w >= (int64_t)kSideExtraMinBatch * 1024;
+        const bool hs = two_streams && hs_big;
         hipStream_t sw = hs ? n->s2 : s;
         int r = hs ? side_wait(n, s) : OCL_OK;   // dy is complete
         if (r) return r;

@@ -25,7 +25,7 @@ struct WTile {
 
 //
 // RGW > 0 selects the 4x4x1 form of the product for layers with at most 20 output channels and one channel chunk (layer 1's 3x3
-// convolutions; OCL_WGRAD_Q=1, see plan_wgrad).  The 16x16x4 tiles pad layer 1's 180 x 20 gradient to 192 x 32: 41 % of the issued
+// convolutions, see plan_wgrad).  The 16x16x4 tiles pad layer 1's 180 x 20 gradient to 192 x 32: 41 % of the issued
 // MFMAs multiply zeros (and the slabs are 32 columns wide for 20 channels).  With v_mfma_f32_4x4x1_16b_f32 the
 // sixteen blocks of an instruction are sixteen PIXELS (the reduction dimension), and nothing is padded beyond quads:
 //   block b = pixel s0 + b of the tile;   A: lane 4b + i holds the 16-byte unit u = 4 * rowgroup + i = (tap, channel quad) of that
@@ -35,22 +35,19 @@ struct WTile {
 // per 16 pixels, and the sixteen per-block partial sums are combined once, at the end (two DPP row shifts, two cross-row shuffles),
 // in a fixed order.  The slab format is the 16x16x4 form's: the reduction kernels do not know which form wrote it.
 //
-// TAB = 1: the staging of a pixel tile with its tile-invariant half precomputed.  Which pixel slot / channel quad / patch position a
-// thread's units are does not change from tile to tile; only the tile's base addresses and its validity limits do.  The TAB = 0 form
-// re-derives everything per tile from packed positions (~1100 instructions per tile and wave around ~600 of the K loop); here the
-// thread keeps per unit a constant byte offset, an LDS address and a packed (row, patch row, image) word, and a tile costs an add,
-// two compares and a select per load.  Units that lie outside the tile or the patch for good store into a 16-byte dummy slot in
-// front of the pixel table instead of branching around the store.  Same values into the same LDS cells: bit-identical results.
+// Staging of a pixel tile: which pixel slot / channel quad / patch position a thread's units are does not change from tile to tile;
+// only the tile's base addresses and its validity limits do.  The thread keeps per unit a constant byte offset, an LDS address and a
+// packed (row, patch row, image) word, and a tile costs an add, two compares and a select per load (round 4; the form that re-derived
+// everything per tile from packed positions spent ~1100 instructions per tile and wave around ~600 of the K loop and is gone:
+// profiles/r4_wgrad_tab_ab.txt).  Units that lie outside the tile or the patch for good store into a 16-byte dummy slot in front of
+// the pixel table instead of branching around the store.
 // TRACE = 1 (measurement build, kbench `wgradtrace`): s_memtime stamps of thread 0 at the phase boundaries into WgradArgs::trace,
 // 64 slots per workgroup: start | prologue done | per tile: passed barrier 1, tile stored, passed barrier 2, next tile's loads issued,
 // K loop done | ... | slab written.
-// PD = 2 (with TAB; OCL_WGRAD_PD=2, written at the end of round 4, not yet measured): prefetch distance of TWO pixel tiles -- a second set
-// of prefetch registers (the table form freed them), the tile loop unrolled by two, every global load gets two tiles' worth of
-// store + K loop to land instead of one.
-template <int MTW, int NTW, int PF, int RGW = 0, int TAB = 0, int TRACE = 0, int PD = 1>
+template <int MTW, int NTW, int PF, int RGW = 0, int TRACE = 0>
 __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    int* pixoff = (int*)lds_raw + 4;                // [KP]   (in front of it: the dummy slot of the TAB form)
+    int* pixoff = (int*)lds_raw + 4;                // [KP]   (in front of it: the staging's dummy slot)
     float* dyt = (float*)(pixoff + a.KP);           // [KP][DP]
     float* patch = dyt + (size_t)a.KP * a.DP;       // [imgs][PR][PC][CP]
     float* xft = patch + (((size_t)a.imgs * a.PR * a.PC * a.CP + 3) & ~(size_t)3);   // input transform (WgradArgs::xf): [groups][Cin/4][2][4] scale / shift quads
@@ -60,7 +57,7 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r16 = lane & 15, g = lane >> 4;
-    // (pixel split bx, output block by) of this workgroup.  xcd_by > 0 (OCL_WGRAD_XCD=1, a one-dimensional launch of S * by workgroups):
+    // (pixel split bx, output block by) of this workgroup.  xcd_by > 0 (a one-dimensional launch of S * by workgroups):
     // the `by` workgroups that read the SAME pixel tiles get linear ids that agree modulo 8 and lie within 8 * by of each other --
     // workgroup b is observed to run on XCD b % 8, so they share one L2 (4 MB per XCD, not coherent across XCDs) at about the same
     // time, instead of fetching every tile once per output block from memory.  The last S % 8 splits keep the plain order.
@@ -135,36 +132,8 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
     };
 
     // ---- per-thread unit bookkeeping (identical for every tile) ----------------------------------------------------
-    // dy units: u = tid + i*256 -> (pixel slot q, float4 column c4); packed q << 8 | c4, -1 past the tile
     const int kc4 = a.KC >> 2;
     const float inv_ppi = 1.0f / (float)a.ppi, inv_wo = 1.0f / (float)a.Wo;
-    int du_pos[DPF];
-#pragma unroll
-    for (int i = 0; i < DPF; ++i) {
-        const int u = tid + i * 256;
-        int c4;
-        const int q = fdiv(u, Q, 1.0f / (float)Q, c4);
-        du_pos[i] = q < a.KP ? (q << 8) | c4 : -1;
-    }
-    // patch units: flat [row][pc][c4], packed il << 24 | pr << 16 | pc << 8 | c4
-    int pu_pos[PF];
-    {
-        int c4, pc;
-        const int pix = fdiv(tid, kc4, 1.0f / (float)kc4, c4);
-        int row = fdiv(pix, a.PC, 1.0f / (float)a.PC, pc);
-#pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            int il = 0, pr = row;
-            if (a.imgs > 1) il = fdiv(row, a.PR, a.inv_PR, pr);
-            pu_pos[i] = (il << 24) | (pr << 16) | (pc << 8) | c4;
-            if (il >= 128 || pr >= 256) pu_pos[i] = 0x7fff0000;   // past any tile's last row
-            c4 += a.d_c4;
-            pc += a.d_pc;
-            if (c4 >= kc4) { c4 -= kc4; pc += 1; }
-            row += a.d_row;
-            if (pc >= a.PC) { pc -= a.PC; row += 1; }
-        }
-    }
     float4 dv[DPF], pv[PF];
     unsigned okm = 0;   // bit i: patch unit i of the tile in flight lies inside the image (input transform: the others stay zero)
     if (a.xf) {   // x is a raw convolution output: its BatchNorm + ReLU is applied while the patch is staged (first barrier of the tile loop publishes the table)
@@ -179,71 +148,12 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
         }
     }
     const float inv_gs = a.xf ? 1.0f / (float)a.xf_group_size : 0.f;
-    int dpo[DPF];   // LDS patch offset of the pixel (units with c4 == 0 publish it), -1: unit not in this tile
     const __amdgpu_buffer_rsrc_t rs_x = make_rsrc(a.x), rs_dy = make_rsrc(a.dy);
-    auto load_tile = [&](const WTile& t) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < DPF; ++i) {
-            const int q = du_pos[i] >> 8, c4 = du_pos[i] & 255;
-            int pl, ox;
-            const int il = fdiv(q, a.ppi, inv_ppi, pl);
-            const int p = t.p0 + pl, n = t.img0 + il;
-            const int oy = fdiv(p, a.Wo, inv_wo, ox);
-            const bool in_tile = du_pos[i] >= 0;
-            const bool v = in_tile & (il < a.imgs) & (n < a.N) & (p < LP);
-            const int co = n0 + c4 * 4;
-            const bool ok = v & (co < a.Cout);
-            dv[i] = buf_load16(rs_dy, ok ? (((n * a.Ho + oy) * a.Wo + ox) * a.Cout + co) * 4 : kOob);   // zeros when masked
-            dpo[i] = in_tile ? (v ? ((il * a.PR + (oy - t.oy0) * a.stride) * a.PC + ox * a.stride) * a.CP : 0) : -1;
-        }
-        const int iy0 = t.oy0 * a.stride + a.min_dy;
-        const int base = (((t.img0 * a.Hin + iy0) * a.Win + a.min_dx) * a.Cin + c0) * 4;   // bytes; may be negative (halo)
-        okm = 0;
-#pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            const int il = pu_pos[i] >> 24, pr = (pu_pos[i] >> 16) & 255, pc = (pu_pos[i] >> 8) & 255, c4 = pu_pos[i] & 255;
-            const int iy = iy0 + pr, ix = a.min_dx + pc;
-            const bool ok = (il * a.PR + pr < t.nrows) & (iy >= 0) & (iy < a.Hin) & (ix >= 0) & (ix < a.Win);
-            pv[i] = buf_load16(rs_x, ok ? base + (((il * a.Hin + pr) * a.Win + pc) * a.Cin + c4 * 4) * 4 : kOob);
-            okm |= ok ? (1u << i) : 0u;
-        }
-    };
-    auto store_tile = [&](const WTile& t) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < DPF; ++i)
-            if (dpo[i] >= 0) {
-                const int q = du_pos[i] >> 8, c4 = du_pos[i] & 255;
-                if (c4 == 0) pixoff[q] = dpo[i];
-                *(float4*)(dyt + (size_t)q * a.DP + c4 * 4) = dv[i];
-            }
-#pragma unroll
-        for (int i = 0; i < PF; ++i) {
-            const int il = pu_pos[i] >> 24, pr = (pu_pos[i] >> 16) & 255, pc = (pu_pos[i] >> 8) & 255, c4 = pu_pos[i] & 255;
-            const int row = il * a.PR + pr;
-            if (row < t.nrows) {
-                float4 v = pv[i];
-                if (a.xf) {   // block-uniform
-                    int rem;
-                    const int gq = min(fdiv(t.img0 + il, a.xf_group_size, inv_gs, rem), a.xf_groups - 1);
-                    const float* tb = xft + (size_t)(gq * (a.Cin >> 2) + (c0 >> 2) + c4) * 8;
-                    const float4 sc = *(const float4*)tb, sh = *(const float4*)(tb + 4);
-                    v.x = fmaxf(__fmaf_rn(v.x, sc.x, sh.x), 0.f); v.y = fmaxf(__fmaf_rn(v.y, sc.y, sh.y), 0.f);
-                    v.z = fmaxf(__fmaf_rn(v.z, sc.z, sh.z), 0.f); v.w = fmaxf(__fmaf_rn(v.w, sc.w, sh.w), 0.f);
-                    if (!((okm >> i) & 1u)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
-                float* d = patch + (row * a.PC + pc) * a.CP + c4 * 4;
-                *(float2*)d = make_float2(v.x, v.y);
-                *(float2*)(d + 2) = make_float2(v.z, v.w);
-            }
-        }
-    };
-
-    // ---- TAB form of the same two steps -------------------------------------------------------------------------------
-    constexpr int TDPF = TAB ? DPF : 1, TPF = TAB ? PF : 1;
-    int d_pl[TDPF], d_il[TDPF], d_goff[TDPF], d_lds[TDPF];   // pixel inside its image (huge: never valid), image inside the tile, byte offset from the tile's dy base, LDS float offset of the quad (dummy slot when the unit is outside the tile)
+    // ---- per-unit constants ----------------------------------------------------------------------------------------------
+    int d_pl[DPF], d_il[DPF], d_goff[DPF], d_lds[DPF];   // pixel inside its image (huge: never valid), image inside the tile, byte offset from the tile's dy base, LDS float offset of the quad (dummy slot when the unit is outside the tile)
     int px_pl = 0, px_il = 0, px_idx = -4, pxo = 0;          // the pixel-table entry of pixel slot `tid` (threads past the tile write the dummy slot)
-    int p_word[TPF], p_goff[TPF], p_lds[TPF];   // row | patch row << 16 | image << 24 (row 0xffff: never loaded);  byte offset from the tile's x base;  LDS byte offset | channel quad << 24
-    if constexpr (TAB) {
+    int p_word[PF], p_goff[PF], p_lds[PF];   // row | patch row << 16 | image << 24 (row 0xffff: never loaded);  byte offset from the tile's x base;  LDS byte offset | channel quad << 24
+    {
         const int dummy_f = (int)((float*)lds_raw - dyt);   // float offset of the dummy slot relative to dyt (negative)
 #pragma unroll
         for (int i = 0; i < DPF; ++i) {
@@ -280,11 +190,11 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
             p_lds[i] = (inside ? (int)((patch - (float*)lds_raw) + (row * a.PC + pc) * a.CP + c4 * 4) * 4 : 0) | (c4 << 24);
         }
     }
-    auto load_tile_ts = [&](const WTile& t, auto& dv, auto& pv, unsigned& okm, int& pxo) __attribute__((always_inline)) {
+    auto load_tile = [&](const WTile& t) __attribute__((always_inline)) {
         const int dbase = (t.img0 * LP + t.p0) * a.Cout * 4;
         const int ox0 = t.p0 - t.oy0 * a.Wo;
 #pragma unroll
-        for (int i = 0; i < TDPF; ++i) {
+        for (int i = 0; i < DPF; ++i) {
             const int p = t.p0 + d_pl[i], n = t.img0 + d_il[i];
             const bool v = (p < LP) & (n < a.N);
             dv[i] = buf_load16(rs_dy, v ? dbase + d_goff[i] : kOob);   // zeros when masked
@@ -303,19 +213,19 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
         const int base = (((t.img0 * a.Hin + iy0) * a.Win + a.min_dx) * a.Cin + c0) * 4;   // bytes; may be negative (halo)
         okm = 0;
 #pragma unroll
-        for (int i = 0; i < TPF; ++i) {
+        for (int i = 0; i < PF; ++i) {
             const int row = p_word[i] & 0xffff, iy = iy0 + ((p_word[i] >> 16) & 255);
             const bool ok = (row < t.nrows) & (iy >= 0) & (iy < a.Hin);
             pv[i] = buf_load16(rs_x, ok ? base + p_goff[i] : kOob);
             okm |= ok ? (1u << i) : 0u;
         }
     };
-    auto store_tile_ts = [&](const WTile& t, auto& dv, auto& pv, unsigned& okm, int& pxo) __attribute__((always_inline)) {
+    auto store_tile = [&](const WTile& t) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < TDPF; ++i) *(float4*)(dyt + d_lds[i]) = dv[i];
+        for (int i = 0; i < DPF; ++i) *(float4*)(dyt + d_lds[i]) = dv[i];
         pixoff[px_idx] = pxo;
 #pragma unroll
-        for (int i = 0; i < TPF; ++i) {
+        for (int i = 0; i < PF; ++i) {
             float4 v = pv[i];
             if (a.xf) {   // block-uniform
                 int rem;
@@ -331,14 +241,6 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
             *(float2*)(d + 2) = make_float2(v.z, v.w);
         }
     };
-    auto load_tile_t = [&](const WTile& t) __attribute__((always_inline)) { load_tile_ts(t, dv, pv, okm, pxo); };
-    auto store_tile_t = [&](const WTile& t) __attribute__((always_inline)) { store_tile_ts(t, dv, pv, okm, pxo); };
-    // second register set of the PD = 2 form
-    constexpr int T2DPF = (TAB && PD == 2) ? DPF : 1, T2PF = (TAB && PD == 2) ? PF : 1;
-    float4 dv2[T2DPF], pv2[T2PF];
-    unsigned okm2 = 0;
-    int pxo2 = 0;
-
     int tr_n = 0;
     auto stamp = [&]() __attribute__((always_inline)) {
         if constexpr (TRACE) {
@@ -429,61 +331,22 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
     stamp();
     int tile = bx;
     WTile cur = geom(tile);
-    if constexpr (TAB && PD == 2) {
-        WTile cur2 = geom(tile + a.S);
-        if (tile < a.total_tiles) load_tile_ts(cur, dv, pv, okm, pxo);
-        if (tile + a.S < a.total_tiles) load_tile_ts(cur2, dv2, pv2, okm2, pxo2);
+    if (tile < a.total_tiles) load_tile(cur);
+    stamp();
+    for (; tile < a.total_tiles; tile += a.S) {
+        __syncthreads();  // previous tile consumed
         stamp();
-        for (; tile < a.total_tiles; tile += 2 * a.S) {
-            __syncthreads();  // previous tile consumed
-            stamp();
-            store_tile_ts(cur, dv, pv, okm, pxo);
-            stamp();
-            __syncthreads();
-            stamp();
-            if (tile + 2 * a.S < a.total_tiles) {
-                cur = geom(tile + 2 * a.S);
-                load_tile_ts(cur, dv, pv, okm, pxo);
-            }
-            stamp();
-            compute_tile();
-            if (tile + a.S >= a.total_tiles) break;
-            __syncthreads();
-            stamp();
-            store_tile_ts(cur2, dv2, pv2, okm2, pxo2);
-            stamp();
-            __syncthreads();
-            stamp();
-            if (tile + 3 * a.S < a.total_tiles) {
-                cur2 = geom(tile + 3 * a.S);
-                load_tile_ts(cur2, dv2, pv2, okm2, pxo2);
-            }
-            stamp();
-            compute_tile();
-        }
-    } else {
-        if (tile < a.total_tiles) {
-            if constexpr (TAB) load_tile_t(cur);
-            else load_tile(cur);
+        store_tile(cur);
+        stamp();
+        __syncthreads();
+        stamp();
+        const int next = tile + a.S;
+        if (next < a.total_tiles) {
+            cur = geom(next);
+            load_tile(cur);
         }
         stamp();
-        for (; tile < a.total_tiles; tile += a.S) {
-            __syncthreads();  // previous tile consumed
-            stamp();
-            if constexpr (TAB) store_tile_t(cur);
-            else store_tile(cur);
-            stamp();
-            __syncthreads();
-            stamp();
-            const int next = tile + a.S;
-            if (next < a.total_tiles) {
-                cur = geom(next);
-                if constexpr (TAB) load_tile_t(cur);
-                else load_tile(cur);
-            }
-            stamp();
-            compute_tile();
-        }
+        compute_tile();
     }
     // partial tile out: rows (chunk, mblock, m), cols co
     const int mrows_chunk = a.mblocks_per_chunk * 64 * MTW;
@@ -541,11 +404,11 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
 }
 
 typedef void (*wgrad_fn_t)(const WgradArgs);
-static wgrad_fn_t wgrad_fn(int M, int N, int PF, int tab) {
-#define OCL_CASE(A, B)                                                                                          \
-    if (M == A && N == B) {                                                                                     \
-        if (PF == 4) return tab ? conv_wgrad_kernel<A, B, 4, 0, 1> : conv_wgrad_kernel<A, B, 4, 0, 0>;          \
-        if (PF == 8) return tab ? conv_wgrad_kernel<A, B, 8, 0, 1> : conv_wgrad_kernel<A, B, 8, 0, 0>;          \
+static wgrad_fn_t wgrad_fn(int M, int N, int PF) {
+#define OCL_CASE(A, B)                                          \
+    if (M == A && N == B) {                                     \
+        if (PF == 4) return conv_wgrad_kernel<A, B, 4>;         \
+        if (PF == 8) return conv_wgrad_kernel<A, B, 8>;         \
     }
     OCL_CASE(1, 1) OCL_CASE(1, 2) OCL_CASE(1, 3) OCL_CASE(1, 4) OCL_CASE(1, 5)
     OCL_CASE(2, 1) OCL_CASE(2, 2) OCL_CASE(2, 3) OCL_CASE(2, 4) OCL_CASE(2, 5)
@@ -554,34 +417,21 @@ static wgrad_fn_t wgrad_fn(int M, int N, int PF, int tab) {
 #undef OCL_CASE
     return nullptr;
 }
-static wgrad_fn_t wgrad_q_fn(int rgw, int PF, int tab) {
-#define OCL_CASE(R)                                                                                                     \
-    if (rgw == R)                                                                                                       \
-        return tab ? (PF == 4 ? conv_wgrad_kernel<1, 1, 4, R, 1> : conv_wgrad_kernel<1, 1, 8, R, 1>)                    \
-                   : (PF == 4 ? conv_wgrad_kernel<1, 1, 4, R, 0> : conv_wgrad_kernel<1, 1, 8, R, 0>);
+static wgrad_fn_t wgrad_q_fn(int rgw, int PF) {
+#define OCL_CASE(R) \
+    if (rgw == R) return PF == 4 ? conv_wgrad_kernel<1, 1, 4, R> : conv_wgrad_kernel<1, 1, 8, R>;
     OCL_CASE(1) OCL_CASE(2) OCL_CASE(3)
 #undef OCL_CASE
     return nullptr;
 }
 // measurement builds (TRACE) of the forms the SCR pass runs most
-static wgrad_fn_t wgrad_trace_fn(int M, int N, int PF, int rgw, int tab) {
-    if (!tab || PF != 8) return nullptr;
-    if (rgw == 3) return conv_wgrad_kernel<1, 1, 8, 3, 1, 1>;
+static wgrad_fn_t wgrad_trace_fn(int M, int N, int PF, int rgw) {
+    if (PF != 8) return nullptr;
+    if (rgw == 3) return conv_wgrad_kernel<1, 1, 8, 3, 1>;
     if (rgw) return nullptr;
-    if (M == 2 && N == 3) return conv_wgrad_kernel<2, 3, 8, 0, 1, 1>;
-    if (M == 3 && N == 2) return conv_wgrad_kernel<3, 2, 8, 0, 1, 1>;
-    if (M == 1 && N == 3) return conv_wgrad_kernel<1, 3, 8, 0, 1, 1>;
-    return nullptr;
-}
-// prefetch distance 2 (PD = 2, OCL_WGRAD_PD=2): the forms the 220-view pass runs most; everything else keeps PD = 1
-static wgrad_fn_t wgrad_pd2_fn(int M, int N, int PF, int rgw, int tab) {
-    if (!tab || PF != 8) return nullptr;
-    if (rgw == 3) return conv_wgrad_kernel<1, 1, 8, 3, 1, 0, 2>;
-    if (rgw) return nullptr;
-    if (M == 2 && N == 3) return conv_wgrad_kernel<2, 3, 8, 0, 1, 0, 2>;
-    if (M == 3 && N == 2) return conv_wgrad_kernel<3, 2, 8, 0, 1, 0, 2>;
-    if (M == 1 && N == 3) return conv_wgrad_kernel<1, 3, 8, 0, 1, 0, 2>;
-    if (M == 1 && N == 2) return conv_wgrad_kernel<1, 2, 8, 0, 1, 0, 2>;
+    if (M == 2 && N == 3) return conv_wgrad_kernel<2, 3, 8, 0, 1>;
+    if (M == 3 && N == 2) return conv_wgrad_kernel<3, 2, 8, 0, 1>;
+    if (M == 1 && N == 3) return conv_wgrad_kernel<1, 3, 8, 0, 1>;
     return nullptr;
 }
 static int wgrad_pf_for(int units) { return units <= 1024 ? 4 : 8; }
@@ -679,10 +529,9 @@ int plan_wgrad(int N, int Hin, int Win, int Cin, int Ho, int Wo, int Cout, int k
     // pixel tile (KP output pixels, 128 / 64 / 32) and channel chunk KC: the largest tile whose patch + dy fit the LDS
     // target and the prefetch registers with a chunk of at least min(20, Cin) channels; else the best that fits at all.
     bool found = false;
-    // measurement knobs (kbench sweeps): largest pixel tile, workgroup target of the pixel split, smallest grid that stops the search
-    static const int env_kp = [] { const char* e = getenv("OCL_WGRAD_KP"); return e ? atoi(e) : 128; }();
-    static const int env_target = [] { const char* e = getenv("OCL_WGRAD_TARGET"); return e ? atoi(e) : 512; }();
-    static const int env_enough = [] { const char* e = getenv("OCL_WGRAD_ENOUGH"); return e ? atoi(e) : 384; }();
+    // largest pixel tile, workgroup target of the pixel split, smallest grid that stops the search (swept in round 4:
+    // profiles/r4_kbench_wgrad_planner_sweep.txt, r4_wgrad_knobs_netcheck.txt -- these are the best column)
+    constexpr int env_kp = 128, env_target = 512, env_enough = 384;
     for (int pass = 0; pass < 2 && !found; ++pass) {
         for (int KPmax = env_kp; KPmax >= 32 && !found; KPmax /= 2) {
             if (LP >= KPmax) {
@@ -747,27 +596,20 @@ int plan_wgrad(int N, int Hin, int Win, int Cin, int Ho, int Wo, int Cout, int k
     p->MTW = MTW; p->NTW = NTW;
     p->grid_x = a.S; p->grid_y = by;
     p->partial_floats = (size_t)a.S * a.Mrows_total * a.CoutP;
-    // staging with precomputed unit tables (conv_wgrad_kernel, TAB): the default; OCL_WGRAD_TAB=0 selects the form that re-derives the
-    // units per tile (bit-identical results: scripts/gpu_r4z3.sh, profiles/r4_wgrad_tab_ab.txt)
-    static const int env_tab = [] { const char* e = getenv("OCL_WGRAD_TAB"); return e ? atoi(e) : 1; }();
-    p->tab = env_tab ? 1 : 0;
-    // The 4x4x1 form (OCL_WGRAD_Q=1; validated per layer and through the whole pass -- tests/test_gpu_netcheck.py -- but off by default
-    // until the full GPU suite has run with it) for <= 20 output channels and a single channel chunk: layer 1's 3x3 convolutions.
-    //   OCL_WGRAD_Q_RGW     row groups (16 gradient rows) per wave, 1..3 (default: the smallest count that covers the rows with one
-    //                       row block, i.e. the patch is staged once per pixel tile)
-    //   OCL_WGRAD_Q_TARGET  workgroups aimed at by the pixel split (default 256: the block sums of the epilogue cost about one pixel
-    //                       tile's MFMAs, so fewer, longer workgroups than the 16x16x4 form)
-    static const int env_q = [] { const char* e = getenv("OCL_WGRAD_Q"); return e ? atoi(e) : 0; }();
+    // The 4x4x1 form for <= 20 output channels and a single channel chunk: layer 1's 3x3 convolutions (round 5: the default where the
+    // gate below plans it -- whole GPU suite green with it, -13 .. -33 us per SCR pass; OCL_WGRAD_Q=0 keeps the 16x16x4 form everywhere,
+    // which tests/test_gpu_netcheck.py uses as the reference of its A/B).  Row groups (16 gradient rows) per wave: the smallest count
+    // that covers the rows with one row block, i.e. the patch is staged once per pixel tile; the pixel split aims at 256 workgroups (the
+    // block sums of the epilogue cost about one pixel tile's MFMAs, so fewer, longer workgroups than the 16x16x4 form).
+    static const int env_q = [] { const char* e = getenv("OCL_WGRAD_Q"); return e ? atoi(e) : 1; }();
     // (the stem's 9 units fill 3 of 4 waves: measured slower; the block sums of the epilogue cost about 1.7 pixel tiles, and the form
-    // runs one workgroup per CU: it pays from ~6 tiles of 128 pixels per workgroup at 256 workgroups -- SCR's 220 views yes (-33 us per
-    // pass), 20 images of 84 x 84 no (+40 us); OCL_WGRAD_Q=2 lifts that limit)
+    // runs one workgroup per CU: it pays from ~6 tiles of 128 pixels per workgroup at 256 workgroups -- SCR's 220 views yes,
+    // 20 images of 84 x 84 no (+40 us); OCL_WGRAD_Q=2 lifts that limit for the planner test)
     if (env_q && Cout <= 4 * kQBlocks && Cin >= 8 && a.nchunks == 1 && a.CP % 4 == 0 && a.KP % 16 == 0 &&
         ((int64_t)a.total_tiles * a.KP >= 6 * 128 * 256 || env_q >= 2)) {
-        static const int env_rgw = [] { const char* e = getenv("OCL_WGRAD_Q_RGW"); return e ? atoi(e) : 0; }();
-        static const int env_qtarget = [] { const char* e = getenv("OCL_WGRAD_Q_TARGET"); return e ? atoi(e) : 256; }();
+        constexpr int env_qtarget = 256;
         const int rg = cdiv(a.ntaps * (a.KC / 4), 4);
-        int rgw = rg <= 4 ? 1 : rg <= 8 ? 2 : 3;
-        if (env_rgw >= 1 && env_rgw <= 3) rgw = env_rgw;
+        const int rgw = rg <= 4 ? 1 : rg <= 8 ? 2 : 3;
         a.nblocks = 1;
         a.DP = a.CoutP = 4 * kQBlocks;
         const size_t bytes = 16 + (size_t)a.KP * 4 + (size_t)a.KP * a.DP * 4 + (((size_t)a.imgs * a.PR * a.PC * a.CP + 3) & ~(size_t)3) * 4 +
@@ -785,23 +627,20 @@ int plan_wgrad(int N, int Hin, int Win, int Cin, int Ho, int Wo, int Cout, int k
         p->grid_x = S; p->grid_y = qby;
         p->partial_floats = (size_t)S * a.Mrows_total * a.CoutP;
     }
-    static const int env_pd = [] { const char* e = getenv("OCL_WGRAD_PD"); return e ? atoi(e) : 1; }();   // prefetch distance in pixel tiles (2: the hot forms only; not yet measured)
-    p->pd = env_pd == 2 ? 2 : 1;
-    // XCD-aware order of the workgroups (conv_wgrad_kernel: bx / by); written at the end of round 4, not yet measured: default off
-    static const int env_xcd = [] { const char* e = getenv("OCL_WGRAD_XCD"); return e ? atoi(e) : 0; }();
-    a.xcd_by = (env_xcd && p->grid_y > 1 && a.S >= 8) ? p->grid_y : 0;
+    // XCD-aware order of the workgroups (conv_wgrad_kernel: bx / by) for launches with more than one output block and at least 8 pixel
+    // splits: bit-identical, the 20 launches of the 220-view pass 622 -> 607 us, load wait per tile 1185 -> 581 ticks on layers 2 - 3
+    // (profiles/r5_wgrad_switches.txt)
+    a.xcd_by = (p->grid_y > 1 && a.S >= 8) ? p->grid_y : 0;
     return OCL_OK;
 }
 
 int launch_wgrad(const WgradPlan& p, hipStream_t s) {
     const int pf = wgrad_pf_for(p.a.imgs * p.a.PR * p.a.PC * (p.a.KC / 4));
-    wgrad_fn_t fn = p.q_rgw ? wgrad_q_fn(p.q_rgw, pf, p.tab) : wgrad_fn(p.MTW, p.NTW, pf, p.tab);
-    if (p.pd == 2 && !p.a.trace)
-        if (wgrad_fn_t f2 = wgrad_pd2_fn(p.MTW, p.NTW, pf, p.q_rgw, p.tab)) fn = f2;
+    wgrad_fn_t fn = p.q_rgw ? wgrad_q_fn(p.q_rgw, pf) : wgrad_fn(p.MTW, p.NTW, pf);
     if (p.a.trace) {
-        fn = wgrad_trace_fn(p.MTW, p.NTW, pf, p.q_rgw, p.tab);
+        fn = wgrad_trace_fn(p.MTW, p.NTW, pf, p.q_rgw);
         if (!fn) {
-            set_error("launch_wgrad: no trace build for MTW=%d NTW=%d PF=%d rgw=%d tab=%d", p.MTW, p.NTW, pf, p.q_rgw, p.tab);
+            set_error("launch_wgrad: no trace build for MTW=%d NTW=%d PF=%d rgw=%d", p.MTW, p.NTW, pf, p.q_rgw);
             return OCL_ERR_UNSUPPORTED;
         }
         OCL_HIP(hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
@@ -857,16 +696,10 @@ int wgrad_kernels_init() {
     for (int m = 1; m <= 4; ++m)
         for (int n = 1; n <= 5; ++n)
             for (int pf = 4; pf <= 8; pf += 4)
-                for (int tab = 0; tab < 2; ++tab)
-                    OCL_HIP(hipFuncSetAttribute((const void*)wgrad_fn(m, n, pf, tab), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+                OCL_HIP(hipFuncSetAttribute((const void*)wgrad_fn(m, n, pf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     for (int r = 1; r <= 3; ++r)
         for (int pf = 4; pf <= 8; pf += 4)
-            for (int tab = 0; tab < 2; ++tab)
-                OCL_HIP(hipFuncSetAttribute((const void*)wgrad_q_fn(r, pf, tab), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
-    for (int m = 1; m <= 3; ++m)
-        for (int n = 2; n <= 3; ++n)
-            if (wgrad_fn_t f = wgrad_pd2_fn(m, n, 8, 0, 1)) OCL_HIP(hipFuncSetAttribute((const void*)f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
-    OCL_HIP(hipFuncSetAttribute((const void*)wgrad_pd2_fn(1, 1, 8, 3, 1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+            OCL_HIP(hipFuncSetAttribute((const void*)wgrad_q_fn(r, pf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     return OCL_OK;
 }
 

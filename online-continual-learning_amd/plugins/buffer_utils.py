@@ -19,11 +19,10 @@ _hostc_ok = None
 
 def _hostc_usable():
     """The C helper restates torch's CPU generator; it is trusted only after its permutations have been compared with the
-    installed torch's on a scratch copy of the generator state (once per process).  OCL_HOSTC=0 forces the Python loop."""
+    installed torch's on a scratch copy of the generator state (once per process)."""
     global _hostc_ok
     if _hostc_ok is None:
-        import os
-        ok = _hostc is not None and os.environ.get("OCL_HOSTC", "1") != "0"
+        ok = _hostc is not None
         if ok:
             saved = torch.get_rng_state()
             try:

@@ -111,15 +111,12 @@ def test_ring_schedule_index_model():
 
 
 def test_weight_gradient_forms_chosen_by_the_planner():
-    """The table-driven staging is the default form of every layer (OCL_WGRAD_TAB=0 selects the other); the 4x4x1 form (OCL_WGRAD_Q=1)
-    is only planned where it was measured faster: layer 1's 3x3 convolutions (<= 20 output channels, one channel chunk, not the stem)
-    of a pass with at least ~6 tiles of 128 pixels per workgroup -- SCR's 220 views, not a replay-sized batch, not 20 images of 84x84;
-    its slabs are 20 columns wide and its pixel tiles whole 16-pixel steps."""
-    for l in [l for l in _plan_lines(220, 2, 32) if " wgrad " in l]:
-        f = _fields(l)
-        assert f["tab"] == 1 and f["q4"] == 0
-    assert all(_fields(l)["tab"] == 0 for l in _plan_lines(220, 2, 32, {"OCL_WGRAD_TAB": "0"}) if " wgrad " in l)
-    q = {l.split()[0]: _fields(l) for l in _plan_lines(220, 2, 32, {"OCL_WGRAD_Q": "1"}) if " wgrad " in l}
+    """The 4x4x1 form (the default since round 5; OCL_WGRAD_Q=0 keeps the 16x16x4 form everywhere) is only planned where it was
+    measured faster: layer 1's 3x3 convolutions (<= 20 output channels, one channel chunk, not the stem) of a pass with at least ~6
+    tiles of 128 pixels per workgroup -- SCR's 220 views, not a replay-sized batch, not 20 images of 84x84; its slabs are 20 columns
+    wide and its pixel tiles whole 16-pixel steps."""
+    assert not any(_fields(l)["q4"] for l in _plan_lines(220, 2, 32, {"OCL_WGRAD_Q": "0"}) if " wgrad " in l)
+    q = {l.split()[0]: _fields(l) for l in _plan_lines(220, 2, 32) if " wgrad " in l}
     on = sorted(k for k, f in q.items() if f["q4"])
     assert on == ["layer1.0.conv1", "layer1.0.conv2", "layer1.1.conv1", "layer1.1.conv2"]
     for k in on:
@@ -127,18 +124,18 @@ def test_weight_gradient_forms_chosen_by_the_planner():
         assert f["q4"] == 3 and f["KP"] % 16 == 0 and f["CP"] % 4 == 0 and f["KC"] == 20 and f["lds"] <= 72 * 1024
         assert 128 <= f["grid"] <= 256                    # one workgroup per CU: a single wave of workgroups
     for n, groups, hw in [(20, 1, 32), (20, 1, 84)]:
-        assert not any(_fields(l)["q4"] for l in _plan_lines(n, groups, hw, {"OCL_WGRAD_Q": "1"}) if " wgrad " in l)
+        assert not any(_fields(l)["q4"] for l in _plan_lines(n, groups, hw) if " wgrad " in l)
     assert any(_fields(l)["q4"] for l in _plan_lines(20, 1, 84, {"OCL_WGRAD_Q": "2"}) if " wgrad " in l)   # (2 lifts the size gate)
 
 
-def test_weight_gradient_schedule_switches_default_off_and_plan_consistent():
-    """OCL_WGRAD_XCD / OCL_WGRAD_PD (written at the end of round 4, not yet measured): off by default; the XCD-aware order is only planned for
+def test_xcd_aware_workgroup_order_is_planned_where_output_blocks_share_pixel_tiles():
+    """The XCD-aware order of conv_wgrad_kernel's workgroups (round 5: measured bit-identical and faster, the default) is planned for
     launches with more than one output block and at least 8 pixel splits, and carries the plan's own block count."""
-    for l in [l for l in _plan_lines(220, 2, 32) if " wgrad " in l]:
-        f = _fields(l)
-        assert f["pd"] == 1 and f["xcd"] == 0
-    for l in [l for l in _plan_lines(220, 2, 32, {"OCL_WGRAD_XCD": "1", "OCL_WGRAD_PD": "2"}) if " wgrad " in l]:
-        f = _fields(l)
-        gx, gy = (int(v) for v in re.search(r"grid= *(\d+)x *(\d+)", l).groups())
-        assert f["pd"] == 2
-        assert f["xcd"] == (gy if gy > 1 and gx >= 8 else 0) and gx == f["S"]
+    some = 0
+    for n, groups, hw in [(220, 2, 32), (20, 1, 32), (20, 1, 84)]:
+        for l in [l for l in _plan_lines(n, groups, hw) if " wgrad " in l]:
+            f = _fields(l)
+            gx, gy = (int(v) for v in re.search(r"grid= *(\d+)x *(\d+)", l).groups())
+            assert f["xcd"] == (gy if gy > 1 and gx >= 8 else 0) and gx == f["S"]
+            some += f["xcd"] > 0
+    assert some >= 10

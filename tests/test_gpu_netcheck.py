@@ -4,9 +4,8 @@
 backward of the engine on seeded inputs; the flat gradient, the outputs and the BatchNorm running statistics go to a file or are compared
 with one, tensor by tensor.  The planner reads its knobs once per process, so the two forms of an A/B are two processes.
 
-  * conv_wgrad_kernel<..., TAB = 1> (default) stages the same values into the same LDS cells as the TAB = 0 form: with the
-    order-independent batch sums (OCL_DETERMINISTIC=1) every tensor of the pass must be bit-identical.
-  * the 4x4x1 form of layer 1 (OCL_WGRAD_Q=1) sums in another order: exactly the four 3x3 weights of layer 1 may differ, by rounding.
+  * the 4x4x1 form of layer 1 (the default where the planner's gate takes it; OCL_WGRAD_Q=0 = the 16x16x4 form everywhere) sums in another
+    order: exactly the four 3x3 weights of layer 1 may differ, by rounding; on the passes the gate leaves alone nothing may differ.
 """
 import os
 import re
@@ -34,10 +33,10 @@ def _run(cfg, mode, path, env):
 CASES = [(220, 2, 32, 1), (20, 1, 32, 0), (13, 1, 32, 0), (6, 2, 84, 1)]
 
 
-@pytest.mark.parametrize("cfg", CASES, ids=lambda c: "n%d_g%d_hw%d_head%d" % c)
-def test_table_driven_weight_gradient_staging_is_bit_identical(cfg, tmp_path):
+@pytest.mark.parametrize("cfg", CASES[1:], ids=lambda c: "n%d_g%d_hw%d_head%d" % c)
+def test_4x4x1_weight_gradient_form_is_not_planned_on_small_passes(cfg, tmp_path):
     ref = str(tmp_path / "ref.bin")
-    rc, out = _run(cfg, "write", ref, {"OCL_WGRAD_TAB": "0"})
+    rc, out = _run(cfg, "write", ref, {"OCL_WGRAD_Q": "0"})
     assert rc == 0, out
     rc, out = _run(cfg, "compare", ref, {})
     assert rc == 0, out
@@ -48,9 +47,9 @@ def test_table_driven_weight_gradient_staging_is_bit_identical(cfg, tmp_path):
 def test_4x4x1_weight_gradient_form_changes_only_layer_1_and_only_by_rounding(tmp_path):
     cfg = (220, 2, 32, 1)
     ref = str(tmp_path / "ref.bin")
-    rc, out = _run(cfg, "write", ref, {})
+    rc, out = _run(cfg, "write", ref, {"OCL_WGRAD_Q": "0"})
     assert rc == 0, out
-    rc, out = _run(cfg, "compare", ref, {"OCL_WGRAD_Q": "1"})
+    rc, out = _run(cfg, "compare", ref, {})
     assert rc == 0, out                                   # (exit 1: some tensor off by more than 1e-4 of its largest entry, or NaN)
     differing = re.findall(r"^\s+(\S+)\s+\d+ floats\s+reldiff (\S+)", out, re.M)
     assert sorted(n for n, _ in differing) == ["encoder.layer1.%d.conv%d.weight" % (b, c) for b in (0, 1) for c in (1, 2)], out

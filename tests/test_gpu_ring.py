@@ -142,6 +142,13 @@ def test_bn_backward_sums_in_the_dgrad_epilogue_match_the_one_pass_kernel(tmp_pa
     worst = max(errs.items(), key=lambda kv: kv[1])
     print("bnb epilogue vs one-pass kernel: worst", worst, "median %.2e" % float(np.median(list(errs.values()))))
     assert worst[1] < 2e-5, worst
+    # ... and the reduce + apply pair (OCL_BN_FUSED=0: what passes of more than two groups run, and the way out when a shared GPU cannot
+    # hold the one-pass kernel's grid-wide arrival) against the one-pass kernel
+    two = _run_s(tmp_path, "bnf0", OCL_BNB_EPI="0", OCL_BN_FUSED="0")
+    errs = {k: float(np.abs(two[k] - ref[k]).max() / (1e-12 + np.abs(ref[k]).max())) for k in ref}
+    worst = max(errs.items(), key=lambda kv: kv[1])
+    print("reduce + apply pair vs one-pass kernel: worst", worst)
+    assert worst[1] < 2e-5, worst
 
 
 # ---- launch-sequence replay (OCL_GRAPH=1, csrc/net.hip run_replayed) ------------------------------------------------------------------------
