@@ -224,9 +224,9 @@ def gpu_leg(args, rank, world, local, workload=None, steps=None, warmup=None):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         agent.train_learner(xt_d, yt)          # EXACTLY args.steps iterations (drop_last, len = steps*batch)
-        env = gpu_env_sample(local)            # host done enqueueing, GPU still working through its backlog: inside the timed region
         torch.cuda.synchronize()
         t_own = time.perf_counter() - t0       # this rank's own stream (before it waits for the others)
+        env = gpu_env_sample(local)            # clocks / power right after the last step retired (outside this rank's own time: on a host-bound loop the sysfs reads would add to it)
         odist.barrier()
         elapsed = time.perf_counter() - t0
         per_rank = odist.gather_scalars([t_own], device)[:, 0]
@@ -241,10 +241,9 @@ def gpu_leg(args, rank, world, local, workload=None, steps=None, warmup=None):
     out = dict(elapsed=elapsed, total_steps=total_steps, hw=hw, bs=bs, steps=steps,
                per_rank_images_per_s=[float(steps * bs / t) for t in per_rank],
                repeats_ms_per_step=[r["elapsed"] / steps * 1e3 for r in reps], preroll_ms=preroll_ms, preroll_steps=args.preroll,
-               env=dict(env_static, sclk_mhz=(sorted(sclk)[len(sclk) // 2] if sclk else None), sclk_mhz_per_repeat=sclk,
-                        mclk_mhz=med["env"]["mclk_mhz"], power_w=(sorted(pw)[len(pw) // 2] if pw else None), power_w_per_repeat=pw,
-                        source="sysfs of this GPU's PCI function, read once per timed repeat after the host has enqueued the last "
-                               "step and before it waits for the GPU"))
+               env=dict(env_static, sclk_mhz=(sorted(sclk)[len(sclk) // 2] if sclk else None), sclk_mhz_range=[min(sclk), max(sclk)] if sclk else None,
+                        mclk_mhz=med["env"]["mclk_mhz"], power_w=(sorted(pw)[len(pw) // 2] if pw else None),
+                        source="sysfs of this GPU's PCI function, once per timed repeat right after its last step retired (median)"))
 
     # ---- roofline leg: HIP events around every kernel launch, on the stream the kernels run on (rank 0) -----------
     # With profiling enabled the engine keeps the weight-gradient kernels on the same stream (no overlap), so each duration is
@@ -397,7 +396,7 @@ def summarise_accuracy(accs):
     accs = np.asarray(accs)
     if accs.shape[0] > 1:
         names = ("avg_end_acc", "avg_end_fgt", "avg_acc", "avg_bwtp", "avg_fwt")
-        return {k: dict(mean=float(v[0]), ci95=float(v[1])) for k, v in zip(names, compute_performance(accs))}
+        return {k: dict(mean=float(v[0]), ci95=float(v[1])) for k, v in list(zip(names, compute_performance(accs)))[:3]}
     end = accs[0, -1, :]
     fgt = accs[0].max(axis=0) - end
     return dict(avg_end_acc=dict(mean=float(end.mean()), ci95=None), avg_end_fgt=dict(mean=float(fgt.mean()), ci95=None))
@@ -440,8 +439,8 @@ def accuracy_leg(args, rank, world, local):
             accs = np.stack(runs)
             if world > 1:
                 accs, _ = odist.gather_runs(runs[0], device=device)
-            res[tag] = dict(summarise_accuracy(accs), runs=int(accs.shape[0]), train_s=t_train, wall_s=wall,
-                            end_acc_per_run=[float(a[-1].mean()) for a in accs])
+            res[tag] = dict(summarise_accuracy(accs), runs=int(accs.shape[0]), wall_s=wall,
+                            end_acc_per_run=[float(a[-1].mean()) for a in accs])   # (per-run values feed the summary, then leave the line)
         out[kind] = res
     out["stream"] = ("%d tasks x %d classes, %d train / %d test images per class; SCR random/random, mem_size 5000, eps_mem_batch 100, temp 0.07, "
                      "NCM classifier; %d runs, seeds = --seed + rank + 100 * run; noise_prototype: class prototype (white noise) blended %.0f%% "
@@ -548,6 +547,17 @@ def cpu_leg(args):
                 ms_per_step=dt / n_timed * 1e3)
 
 
+def compact(v, sig=5):
+    """Floats to `sig` significant digits (the driver stores a bounded tail of the line: every config must stay inside it)."""
+    if isinstance(v, float):
+        return float("%.*g" % (sig, v)) if v == v and abs(v) != float("inf") else None
+    if isinstance(v, dict):
+        return {k: compact(x, 7 if k in ("value", "ms_per_step") else sig) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [compact(x, sig) for x in v]
+    return v
+
+
 def main():
     if len(sys.argv) >= 5 and sys.argv[1] == "--oracle-accuracy-worker":
         return accuracy_oracle_worker(int(sys.argv[2]), sys.argv[3], int(sys.argv[4]))
@@ -605,11 +615,15 @@ def main():
     cpu_line, oracle_handle = None, None
     if rank == 0 and world == 1:
         with contextlib.redirect_stdout(sys.stderr):
+            # the CPU legs run on the mask the process started with, not on the GPU-local slice the launch loop was pinned to
             if not args.no_cpu_baseline:
+                odist.restore_affinity()
                 cpu_line = cpu_leg(args)        # (before the oracle's accuracy processes take the host cores)
             if not args.no_accuracy:
                 if not args.no_cpu_baseline:
                     oracle_handle = accuracy_oracle_start([odist.run_seed(args.seed, rank) + 100 * i for i in range(ACC_CFG["seeds"])], 8)
+                if pinned:
+                    odist.pin_to_gpu_numa(local, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
                 acc_res, acc_seeds = accuracy_leg(args, rank, world, local)
     if rank != 0:
         return
@@ -659,13 +673,14 @@ def main():
             rf = a.get("roofline", {})
             line["also"][wl] = {
                 "metric": "replay-step images/sec (%s)" % names[wl][0],
-                "workload": "BASELINE.json configs[%d]: " % names[wl][1] + ", ".join("%s=%s" % kv for kv in sorted(wa.items())),
+                "workload": "BASELINE.json configs[%d]" % names[wl][1],
                 "value": a["total_steps"] * a["bs"] / a["elapsed"], "unit": "stream images/s", "steps": a["steps"],
                 "ms_per_step": a["elapsed"] / a["steps"] * 1e3, "ms_per_step_repeats": a["repeats_ms_per_step"],
                 "images_through_network_per_step": names[wl][2], "env": {k: a["env"].get(k) for k in ("sclk_mhz", "power_w")},
-                "roofline": {k: rf.get(k) for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "calibrated_peak", "frac_of_calibrated",
-                                                    "avg_launch_us", "launches_per_step", "algorithmic_gflop_per_step", "whole_step_frac",
-                                                    "wgrad", "knn_buffer", "per_step_ms", "launches_per_step_all")} if rf else None}
+                # (same kernel class, peak and unit as the headline's roofline object)
+                "roofline": {k: rf.get(k) for k in ("bound", "achieved", "frac", "frac_of_calibrated", "avg_launch_us", "launches_per_step",
+                                                    "algorithmic_gflop_per_step", "whole_step_frac", "wgrad", "knn_buffer", "per_step_ms",
+                                                    "launches_per_step_all")} if rf else None}
     if acc_res is not None:
         if oracle_handle is not None:
             orc = accuracy_oracle_finish(oracle_handle)   # 5 concurrent runs x 8 intra-op threads, started before the HIP accuracy runs
@@ -682,8 +697,18 @@ def main():
                     # the stream on which the augmentation must not hurt: product - identity >= -(the oracle's own spread over the seeds)
                     acc_res[kind]["summary"]["augmentation_not_harmful"] = bool(
                         acc_res[kind]["summary"]["product_minus_identity_augmentation"] >= -spread)
+        # the line keeps means / intervals / the summary; per-run values and wall times have done their job
+        for kind in ACC_STREAMS:
+            for tag, v in acc_res[kind].items():
+                if tag != "summary":
+                    v.pop("end_acc_per_run", None)
+                    v.pop("wall_s", None)
+        if "cpu_oracle" in acc_res:
+            for kind in ACC_STREAMS:
+                o = acc_res["cpu_oracle"][kind]
+                acc_res["cpu_oracle"][kind] = dict(avg_end_acc=o["avg_end_acc"], runs=o["runs"], seeds=o["seeds"])
         line["accuracy"] = acc_res
-    print(json.dumps(line))
+    print(json.dumps(compact(line), separators=(",", ":")))
 
 
 if __name__ == "__main__":

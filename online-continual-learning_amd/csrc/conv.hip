@@ -164,12 +164,23 @@ __device__ __forceinline__ double fx_total_atomic(const StatCell* cells, int64_t
     }
     return bad ? __builtin_nan("") : fx_decode(hi, lo);
 }
-static int g_det_host = 0;   // the host's copy of g_det_sums (conv_s_kernel's instantiation is chosen by it)
+// The host's copy of g_det_sums, PER DEVICE (conv_s_kernel's instantiation is chosen by it; the __constant__ lives per device, so a
+// process-wide host flag could disagree with it as soon as a second device is touched: cells written as fixed point and read as doubles)
+static const int kMaxDevices = 64;
+static int g_det_dev[kMaxDevices] = {0};
+static int det_host() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return 0;
+    return g_det_dev[dev];
+}
 int set_deterministic_sums(int on) {
     const int v = on ? 1 : 0;
-    g_det_host = v;
+    int dev = 0;
+    OCL_HIP(hipGetDevice(&dev));
+    OCL_REQUIRE(dev >= 0 && dev < kMaxDevices, "set_deterministic: device %d", dev);
     OCL_HIP(hipDeviceSynchronize());   // (no launch may straddle the switch: the cells are interpreted by the flag)
     OCL_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_det_sums), &v, sizeof(int)));
+    g_det_dev[dev] = v;                // the current device only: the mode is a per-device state, like the symbol
     return OCL_OK;
 }
 
@@ -2270,7 +2281,8 @@ int launch_conv(const ConvPlan& p, hipStream_t s) {
             return OCL_ERR_STATE;
         }
         ProfScope ps(PROF_CONV, s);
-        hipLaunchKernelGGL(convs_fn(p.NT, p.a.trace != nullptr && !g_det_host, (p.a.flags & EPI_BNB) != 0, g_det_host != 0), dim3(p.grid_x, p.grid_y), dim3(256),
+        const int det = det_host();
+        hipLaunchKernelGGL(convs_fn(p.NT, p.a.trace != nullptr && !det, (p.a.flags & EPI_BNB) != 0, det != 0), dim3(p.grid_x, p.grid_y), dim3(256),
                            p.lds_bytes, s, p.a);
         OCL_LAUNCH_CHECK();
         return OCL_OK;
@@ -3123,7 +3135,11 @@ int launch_fill(float* p, int64_t n, float v, hipStream_t s) {
 
 // Allow every instantiation to use the full 160 KiB of dynamic LDS.
 int conv_kernels_init() {
-    static bool done = false;
+    static bool done_dev[kMaxDevices] = {false};   // function attributes and the mode symbol are per device
+    int dev = 0;
+    OCL_HIP(hipGetDevice(&dev));
+    OCL_REQUIRE(dev >= 0 && dev < kMaxDevices, "conv_kernels_init: device %d", dev);
+    bool& done = done_dev[dev];
     if (done) return OCL_OK;
     {
         const char* e = getenv("OCL_DETERMINISTIC");

@@ -518,7 +518,8 @@ int plan_wgrad(int N, int Hin, int Win, int Cin, int Ho, int Wo, int Cout, int k
     a.min_dy = a.min_dx = -pad;
     a.max_dy = a.max_dx = ksize - 1 - pad;
     const int ntile = cdiv(Cout, 16);
-    int NTW = ntile <= 3 ? ntile : 3;   // 48 output channels per workgroup (register budget of the dy prefetch)
+    static const int env_ntmax = [] { const char* e = getenv("OCL_WGRAD_NTMAX"); return e ? atoi(e) : 3; }();   // EXPERIMENT (round 5): 5 = 80-channel blocks
+    int NTW = ntile <= env_ntmax ? ntile : env_ntmax;   // 48 output channels per workgroup (register budget of the dy prefetch)
     a.nblocks = cdiv(ntile, NTW);
     if (a.nblocks > 1) NTW = cdiv(ntile, a.nblocks);
     a.CoutP = a.nblocks * NTW * 16;

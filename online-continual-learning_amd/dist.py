@@ -113,18 +113,39 @@ def _read(path):
         return None
 
 
+def _set_affinity_all_threads(cpus):
+    """sched_setaffinity(0, ...) moves the calling thread only (and threads created later): the HIP runtime's and the process group's
+    helper threads exist by the time the GPU's PCI address can be read, so every tid of /proc/self/task is moved."""
+    try:
+        tids = [int(t) for t in os.listdir("/proc/self/task")]
+    except Exception:
+        tids = []
+    for tid in tids:
+        try:
+            os.sched_setaffinity(tid, cpus)
+        except Exception:
+            pass
+    os.sched_setaffinity(0, cpus)
+
+
+_original_affinity = None
+
+
 def pin_to_gpu_numa(local=0, n_local=1):
-    """Pins the calling process to the CPUs of its GPU's NUMA node (sysfs local_cpulist of the GPU's PCI function); ranks whose GPUs
-    share a node split that list into disjoint slices.  Why: the step is ~150 kernel launches per 2 ms from one Python thread; kernel
-    arguments, doorbells and the pinned staging ring live in host memory that is first touched by this process -- from the far socket
-    every launch pays a cross-socket hop (leases whose GPU hangs off the other socket ran the same tree 12 - 17 % slower, the small
-    launch-latency-bound kernels 40 - 100 %: DESIGN.md section 7).  Call it before the first model is built (the runtime's queues and
-    the kernel-argument pools are created on first use).  Returns the CPU list taken, or None when sysfs does not say (nothing is
-    pinned).  OCL_PIN=0 disables it."""
+    """Pins the calling process (all of its threads) to the CPUs of its GPU's NUMA node (sysfs local_cpulist of the GPU's PCI function);
+    the local ranks whose GPUs share a node -- or that share a GPU -- split that list into disjoint slices, keyed on the LOCAL RANK.
+    Why: with N ranks on one node there are N Python launch loops of ~150 kernel launches per 2 ms each plus their runtime threads;
+    disjoint slices keep them from migrating onto each other.  It is NOT the explanation of the lease-to-lease variance of round 3 / 4:
+    the bench pinned to the GPU's node, unpinned and pinned to the FAR node runs at 2.112 / 2.107 / 2.111 ms
+    (profiles/r4_placement_ab.txt) -- harmless hygiene for a single rank.  Returns the CPU list taken, or None
+    when sysfs does not say (nothing is pinned).  OCL_PIN=0 disables it; restore_affinity() undoes it (bench.py: the CPU baseline and
+    the oracle's processes run on the mask the process started with)."""
+    global _original_affinity
     if os.environ.get("OCL_PIN", "1") == "0":
         return None
     try:
-        d = _pci_dir(local)
+        n_dev = max(1, torch.cuda.device_count())
+        d = _pci_dir(local % n_dev)
         txt = _read(os.path.join(d, "local_cpulist")) if d else None
         if not txt or not hasattr(os, "sched_setaffinity"):
             return None
@@ -132,12 +153,13 @@ def pin_to_gpu_numa(local=0, n_local=1):
         for part in txt.strip().split(","):
             a, _, b = part.partition("-")
             cpus += list(range(int(a), int(b or a) + 1))
-        allowed = sorted(set(cpus) & set(os.sched_getaffinity(0)))
+        start = _original_affinity if _original_affinity is not None else set(os.sched_getaffinity(0))
+        allowed = sorted(set(cpus) & set(start))
         if not allowed:
             return None
-        peers = []
-        for r in range(min(max(1, n_local), torch.cuda.device_count())):
-            dr = _pci_dir(r)
+        peers = []   # local ranks (not devices) whose GPU reports the same CPU list: ranks sharing a GPU get different slices too
+        for r in range(max(1, n_local)):
+            dr = _pci_dir(r % n_dev)
             if dr and _read(os.path.join(dr, "local_cpulist")) == txt:
                 peers.append(r)
         if local not in peers:
@@ -145,7 +167,18 @@ def pin_to_gpu_numa(local=0, n_local=1):
         k, n = peers.index(local), len(peers)
         per = max(1, len(allowed) // n)
         mine = allowed[k * per:(k + 1) * per] or allowed
-        os.sched_setaffinity(0, mine)
+        if _original_affinity is None:
+            _original_affinity = set(start)
+        _set_affinity_all_threads(mine)
         return mine
     except Exception:
         return None
+
+
+def restore_affinity():
+    """Back to the CPU mask the process had before pin_to_gpu_numa (no-op when nothing was pinned)."""
+    if _original_affinity is not None and hasattr(os, "sched_setaffinity"):
+        try:
+            _set_affinity_all_threads(_original_affinity)
+        except Exception:
+            pass

@@ -482,14 +482,16 @@ def test_er_data_stream_overlap_is_schedule_only(cuda, monkeypatch):
     x = rng.integers(0, 256, (600, 32, 32, 3), dtype=np.uint8)
     y = rng.integers(0, 10, 600).astype(np.int64)
     finals = []
-    for flag in ("1", "0"):
-        monkeypatch.setenv("OCL_DATA_STREAM", flag)
-        params, model, agent = build_agent(cfg)
-        agent.train_learner(torch.from_numpy(x).to(cuda), y)
-        torch.cuda.synchronize()
-        finals.append((model.flat_params().cpu().numpy().copy(), agent.buffer.buffer_img.cpu().numpy().copy(),
-                       agent.buffer.buffer_label.cpu().numpy().copy(), agent.buffer.n_seen_so_far))
-    ops.set_deterministic(False)
+    try:
+        for flag in ("1", "0"):
+            monkeypatch.setenv("OCL_DATA_STREAM", flag)
+            params, model, agent = build_agent(cfg)
+            agent.train_learner(torch.from_numpy(x).to(cuda), y)
+            torch.cuda.synchronize()
+            finals.append((model.flat_params().cpu().numpy().copy(), agent.buffer.buffer_img.cpu().numpy().copy(),
+                           agent.buffer.buffer_label.cpu().numpy().copy(), agent.buffer.n_seen_so_far))
+    finally:
+        ops.set_deterministic(False)   # (also when a step raised: the rest of the session must not run in the integer-sum mode)
     (w1, b1, l1, n1), (w0, b0, l0, n0) = finals
     assert n1 == n0 == 600 and np.array_equal(l1, l0) and np.array_equal(b1, b0)
     assert np.array_equal(w1, w0)
