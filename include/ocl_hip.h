@@ -224,6 +224,11 @@ int ocl_net_bind(ocl_net* net, float* params, float* grads, float* running, int6
                                      the activations are kept, so that ocl_net_backward gives the gradients of an eval-mode
                                      forward: model.eval() followed by loss.backward(), utils/buffer/gss_greedy_update.py:16,
                                      77-79,97-100,116-118 */
+#define OCL_FWD_SAME_WEIGHTS 16u  /* the caller asserts that the parameter array of this call has not been written since this net's
+                                     previous forward read it (several forwards between two optimiser steps: the ASER retrieval's
+                                     feature pass, the memory pass and the combined pass of agents/exp_replay.py:49-84): the engine
+                                     reuses the weight packs it made then instead of re-packing (it still re-packs when its arena
+                                     holds another array's packs, e.g. after a params_override call) */
 /* x: [n,3,H,W] fp32 NCHW (what the reference's agents hand to model.forward).
  * groups: the batch is `groups` equal consecutive sub-batches that the reference would have run as
  * separate forward calls (SCR's two views, agents/scr.py:55): BatchNorm statistics are per group.

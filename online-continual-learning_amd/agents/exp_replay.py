@@ -76,20 +76,27 @@ class ExperienceReplay(ContinualLearner):
     def _two_pass_step(self, batch_x, batch_y, batch_y_host, meters, aser, retrieved=None, logits=None):
         if logits is None:      # (the pipelined ASER loop has issued this forward already)
             logits = self.model.forward(batch_x)
-        loss = self._kd_mix(self.criterion(logits, batch_y), logits, batch_x)
-        self._track(meters[0], logits, batch_y, loss)
-        self._emit("er_loss", loss)
+        # ASER mode throws the gradients of passes 1 and 2 away (zero_grad below): their losses are only ever printed / traced, so
+        # without a reader (no verbose meter, no trace, no distillation term to mix in) the loss kernels are not launched either
+        trick = self.params.trick
+        back12 = not aser or self.params.retrieve == 'MIR'   # MIR reads the batch pass's gradient
+        need_loss = back12 or self.verbose or debug.on() or trick['kd_trick'] or trick['kd_trick_star']
+        if need_loss:
+            loss = self._kd_mix(self.criterion(logits, batch_y), logits, batch_x)
+            self._track(meters[0], logits, batch_y, loss)
+            self._emit("er_loss", loss)
         self.opt.zero_grad()
-        if not aser or self.params.retrieve == 'MIR':   # ASER mode discards this gradient; MIR reads it
+        if back12:
             loss.backward(unit_gradient(loss))
 
         mem_x, mem_y = retrieved if retrieved is not None else self.buffer.retrieve(x=batch_x, y=batch_y)
         if mem_x.size(0) > 0:
             mem_x, mem_y = maybe_cuda(mem_x, self.cuda), maybe_cuda(mem_y, self.cuda)
             mem_logits = self.model.forward(mem_x)
-            loss_mem = self._kd_mix(self.criterion(mem_logits, mem_y), mem_logits, mem_x)
-            self._track(meters[1], mem_logits, mem_y, loss_mem)
-            self._emit("er_loss_mem", loss_mem)
+            if need_loss or not aser:
+                loss_mem = self._kd_mix(self.criterion(mem_logits, mem_y), mem_logits, mem_x)
+                self._track(meters[1], mem_logits, mem_y, loss_mem)
+                self._emit("er_loss_mem", loss_mem)
             if not aser:
                 loss_mem.backward(unit_gradient(loss_mem))
 
@@ -108,7 +115,10 @@ class ExperienceReplay(ContinualLearner):
 
     # ---- the loop ------------------------------------------------------------------------------------------------------
     def train_learner(self, x_train, y_train):
-        with self.launch_stream():
+        # Between two optimiser steps every forward of the loop reads the same weights (ASER mode: five of them per iteration): inside
+        # model.same_weights() the engine packs them once per step (resnet.py; writes by anybody else are detected, not assumed away)
+        same = self.model.same_weights() if hasattr(self.model, "same_weights") else contextlib.nullcontext()
+        with self.launch_stream(), same:
             self._train_learner(x_train, y_train)
 
     def _train_learner(self, x_train, y_train):
@@ -161,7 +171,7 @@ class ExperienceReplay(ContinualLearner):
                 batch_y_host = train_loader.last_y_host
                 pre = None
                 if pipeline:
-                    pre = self.model.forward(batch_x)
+                    pre = self.model.forward(batch_x)   # (same weights as update_begin's feature pass, which read the stepped weights first)
                     upd.update_finish(self.buffer, pending)
                     pending = None
                 for j in range(self.mem_iters):

@@ -231,6 +231,7 @@ static int build_layout(ocl_net* n) {
     const int lin_in = d.head == 0 ? n->feat_dim : in_planes;
     n->t_linear_w = add_tensor(n, pre + "linear.weight", {d.n_classes, lin_in});
     n->t_linear_b = add_tensor(n, pre + "linear.bias", {d.n_classes});
+    OCL_REQUIRE(n->tensors[n->t_linear_b].off == n->tensors[n->t_linear_w].off + n->tensors[n->t_linear_w].numel, "net: linear.weight / linear.bias not adjacent");
     if (d.head == 0) {
         n->out_dim = d.n_classes;
     } else if (d.head == 1) {
@@ -896,6 +897,9 @@ int ocl_net_forward_segments(ocl_net* n, const float* const* xs, const int32_t* 
     // every forward packs (the caller may have stepped the weights), but only the layouts the pass reads: the forward packs, and the
     // data-gradient packs when a backward will follow this tape
     const int pack_mask = n->pack_need_fwd | ((flags & OCL_FWD_SAVE_TAPE) ? n->pack_need_bwd : 0);
+    // OCL_FWD_SAME_WEIGHTS: the packs of the previous forward are still those of this array -- no pack launch; a train-mode pass
+    // clears its statistics arenas (the pack launch's other job) with one memset over both, an eval-mode pass needs nothing
+    const bool same_weights = (flags & OCL_FWD_SAME_WEIGHTS) && n->pack_src == P && (n->pack_have & pack_mask) == pack_mask;
 
     float* S = n->slotf(slot);
     float* x4 = S + n->x4_off;
@@ -921,9 +925,17 @@ int ocl_net_forward_segments(ocl_net* n, const float* const* xs, const int32_t* 
 
     // ---- the launch sequence (everything below depends only on the key: shapes, slot, flags, parameter array) -----------------------
     auto body = [&]() -> int {
-        int rc = launch_pack_weights(P, pack, pack_descs(n), (int)n->convs.size(), max_elems, s, pack_mask, n->statsbuf(), n->stats_doubles,
+        int rc = OCL_OK;
+        if (!same_weights) {
+            rc = launch_pack_weights(P, pack, pack_descs(n), (int)n->convs.size(), max_elems, s, pack_mask, n->statsbuf(), n->stats_doubles,
                                      n->bsumsbuf(), n->bsums_doubles);   // (also clears the statistics arenas of the pass and of its backward)
-        if (rc != OCL_OK) return rc;
+            if (rc != OCL_OK) return rc;
+        } else if (train) {   // the two arenas are neighbours in the workspace: one clear from the first cell of one to the last of the other
+            unsigned char* lo = n->ws + std::min(n->off_stats, n->off_bsums);
+            unsigned char* hi = n->ws + std::max(n->off_stats + n->stats_doubles * (int64_t)sizeof(StatCell),
+                                                 n->off_bsums + n->bsums_doubles * (int64_t)sizeof(StatCell));
+            OCL_HIP(hipMemsetAsync(lo, 0, (size_t)(hi - lo), s));
+        }
         if (train) {
             if ((rc = trunk_forward_train(n, ps, P, S, N, groups, upd && !frozen, feat, s, side, frozen, fused))) return rc;
         } else {
@@ -963,13 +975,13 @@ int ocl_net_forward_segments(ocl_net* n, const float* const* xs, const int32_t* 
     ocl_net::GraphKey key;
     memset(&key, 0, sizeof(key));
     key.kind = 0; key.N = N; key.G = groups; key.slot = slot; key.a = (int)flags; key.b = pack_mask;
-    key.c = (want_head ? 1 : 0) | (feat == S + n->feat_off ? 2 : 0);
+    key.c = (want_head ? 1 : 0) | (feat == S + n->feat_off ? 2 : 0) | (same_weights ? 4 : 0);
     key.p = (uint64_t)(uintptr_t)P;
     // (sequences that fork to the side stream are not replayed: as a graph the SCR pass ran at 4.2 ms per step against 2.35 with
     // stream launches -- profiles/r4_graph_replay.txt -- while a single-stream ER pass keeps its GPU time and halves the host's)
     rc = side ? body() : run_replayed(n, key, s, body);
     // host state of the pass (also when the launches were replayed)
-    n->bsums_clean = true;
+    if (!same_weights || train) n->bsums_clean = true;
     n->pack_have = n->pack_src == P ? (n->pack_have | pack_mask) : pack_mask;   // (older packs of the same array stay as they were)
     n->pack_src = P;
     if (rc != OCL_OK) return rc;
@@ -1366,8 +1378,8 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
             if ((rc = lin_bwd(dout, OD, feat, FD, n->t_linear_w, n->t_linear_b, dfeat))) return rc;
         } else {
             if (!accumulate) {  // encoder.linear takes no part in SupConResNet.forward: its gradient is zero
-                if ((rc = launch_fill(GT(n->t_linear_w), n->tensors[n->t_linear_w].numel, 0.f, s))) return rc;
-                if ((rc = launch_fill(GT(n->t_linear_b), n->tensors[n->t_linear_b].numel, 0.f, s))) return rc;
+                // (weight and bias are neighbours in the flat array: one fill)
+                if ((rc = launch_fill(GT(n->t_linear_w), n->tensors[n->t_linear_w].numel + n->tensors[n->t_linear_b].numel, 0.f, s))) return rc;
             }
             if (n->d.head == 1) {
                 if ((rc = launch_l2norm_bwd(o, norms, dout, dh2, N, OD, s))) return rc;

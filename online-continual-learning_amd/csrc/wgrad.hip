@@ -518,8 +518,13 @@ int plan_wgrad(int N, int Hin, int Win, int Cin, int Ho, int Wo, int Cout, int k
     a.min_dy = a.min_dx = -pad;
     a.max_dy = a.max_dx = ksize - 1 - pad;
     const int ntile = cdiv(Cout, 16);
-    static const int env_ntmax = [] { const char* e = getenv("OCL_WGRAD_NTMAX"); return e ? atoi(e) : 3; }();   // EXPERIMENT (round 5): 5 = 80-channel blocks
-    int NTW = ntile <= env_ntmax ? ntile : env_ntmax;   // 48 output channels per workgroup (register budget of the dy prefetch)
+    // 48 output channels per workgroup; 80 (five 16-column blocks: layers 3 - 4 exactly, no padded columns -- 96 / 192 issued for 80 / 160
+    // -- and 6 operand reads per 5 MFMAs) on passes of 48 images and more.  Alone (kbench) the wider block is faster at every size (220
+    // views: 592 -> 546 us over the 20 launches, layer 4 39.2 -> 30.8 us; 20 x 84 x 84: layer 3 31.6 -> 23.6 us), but beside the dependent
+    // chain of a 20-image pass the whole pass gets SLOWER (20 x 32 x 32: +8 us, 20 x 84 x 84: +16 us), while passes of 50 - 220 images gain
+    // 22 - 75 us (profiles/r5_wgrad_ntw5.txt): the rule follows the pass times.
+    const int ntmax = (ntile >= 5 && N >= 48) ? 5 : 3;
+    int NTW = ntile <= ntmax ? ntile : ntmax;
     a.nblocks = cdiv(ntile, NTW);
     if (a.nblocks > 1) NTW = cdiv(ntile, a.nblocks);
     a.CoutP = a.nblocks * NTW * 16;

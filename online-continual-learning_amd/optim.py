@@ -31,6 +31,7 @@ class FusedSGD(torch.optim.Optimizer):
             named = dict(m.named_parameters())
             keep = [(named[n], named[n].detach().clone()) for n in self._no_grad_names]
         ops.sgd_step(m.flat_params(), m.flat_grads(), g["lr"], g["weight_decay"], grad_scale)
+        m.mark_weights_written()
         if keep is not None:      # undo the decay of the gradient-less tensors (two small device copies; weight_decay is 0 in every BASELINE config)
             for p, old in keep:
                 p.data.copy_(old)

@@ -9,6 +9,8 @@ place; the flat gradient is exactly the vector `get_grad_vector` builds (utils/b
 """
 import ctypes as C
 
+import contextlib
+
 import torch
 import torch.nn as nn
 
@@ -73,6 +75,9 @@ class _EngineMixin:
         self._flat = None
         self._gflat = None
         self._grads_fresh = True   # True: next backward overwrites (grads are logically zero / None)
+        self._weights_dirty = True   # the parameter array was written (optimiser step, load, re-bind) since the engine last packed it
+        self._same_weights = False   # inside `with model.same_weights():` -- see there
+        self._packed_version = None
         self._slot_rr = 0
         self._slot_gen = {}
         self._anchor = None
@@ -185,6 +190,43 @@ class _EngineMixin:
         self._ensure_bound()
         return self._gflat
 
+    def mark_weights_written(self):
+        """The bound parameter array was written through the engine (FusedSGD.step): the next forward re-packs."""
+        self._weights_dirty = True
+
+    @contextlib.contextmanager
+    def same_weights(self):
+        """Inside the block, a forward that follows another forward of the block with no write to the parameters in between carries
+        OCL_FWD_SAME_WEIGHTS: the engine reuses the weight packs it made for the earlier one (agents/exp_replay.py: the ASER update's
+        feature pass, the batch pass, the retrieval's feature pass, the memory pass and the combined pass between two optimiser steps).
+        "No write" is checked, not assumed: FusedSGD.step() reports itself, and every torch in-place write to a parameter or to the
+        flat array (load_state_dict, copy_, mul_ ...) moves a version counter that is compared here.  What the counters cannot see is
+        a write through `p.data` -- do not do that inside such a block (nothing in this package does)."""
+        prev, self._same_weights = self._same_weights, True
+        try:
+            yield
+        finally:
+            self._same_weights = prev
+
+    def _weights_version(self):
+        v = self._flat._version
+        for p, _ in self._views:
+            v += p._version
+        return v
+
+    def _weights_flag(self, params_override):
+        """OCL_FWD_SAME_WEIGHTS for the forward being issued, and the bookkeeping behind it: `_weights_dirty` (a step since the last
+        pack) and `_packed_version` (the parameters' version counters at the last forward of a same_weights block; None = unknown)."""
+        if params_override is not None:
+            return 0          # (the engine notices by itself that its arena holds another array's packs afterwards)
+        if not self._same_weights:
+            self._packed_version, self._weights_dirty = None, False
+            return 0
+        v = self._weights_version()
+        flag = ffi.FWD_SAME_WEIGHTS if (not self._weights_dirty and self._packed_version == v) else 0
+        self._packed_version, self._weights_dirty = v, False
+        return flag
+
     def mark_grads_zero(self):
         """zero_grad() without touching memory: the next backward overwrites."""
         self._grads_fresh = True
@@ -240,6 +282,7 @@ class _EngineMixin:
         flags = ffi.FWD_TRAIN | (ffi.FWD_SAVE_TAPE if save else 0) | (ffi.FWD_UPDATE_RUNNING if update_running else 0)
         if frozen:   # model.eval() under autograd: running statistics, activations kept for backward
             flags = ffi.FWD_SAVE_TAPE | ffi.FWD_FROZEN_BN
+        flags |= self._weights_flag(params_override)
         ffi.check(ffi.lib().ocl_net_forward_segments(self._net, ptrs, sizes, len(parts), groups, flags, ffi.ptr(params_override), ffi.ptr(feat),
                                                      ffi.ptr(out), slot, ffi.stream()), "net_forward(train)")
         if want_feat:
@@ -252,8 +295,8 @@ class _EngineMixin:
         dev = parts[0].device
         out = torch.empty((n, self.out_dim), dtype=torch.float32, device=dev) if want_out else None
         feat = torch.empty((n, self.feature_dim), dtype=torch.float32, device=dev) if want_feat else None
-        ffi.check(ffi.lib().ocl_net_forward_segments(self._net, ptrs, sizes, len(parts), 1, 0, ffi.ptr(params_override), ffi.ptr(feat),
-                                                     ffi.ptr(out), self._n_tapes, ffi.stream()), "net_forward(eval)")
+        ffi.check(ffi.lib().ocl_net_forward_segments(self._net, ptrs, sizes, len(parts), 1, self._weights_flag(params_override), ffi.ptr(params_override),
+                                                     ffi.ptr(feat), ffi.ptr(out), self._n_tapes, ffi.stream()), "net_forward(eval)")
         return out, feat
 
     def _engine_backward(self, slot, gen, dout):

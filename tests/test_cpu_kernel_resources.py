@@ -22,6 +22,7 @@ HOT = [
     r"conv_t_kernel<1, 1, 8, true, false, false, true>", r"conv_t_kernel<2, 1, 4, true, false, false, true>",   # the EPI_BNB data gradients of a replay-sized pass
     r"conv_wgrad_kernel<2, 3, 8, 0, 0>", r"conv_wgrad_kernel<3, 2, 8, 0, 0>", r"conv_wgrad_kernel<1, 3, 8, 0, 0>",
     r"conv_wgrad_kernel<1, 2, 8, 0, 0>", r"conv_wgrad_kernel<1, 2, 4, 0, 0>",
+    r"conv_wgrad_kernel<1, 5, [48], 0, 0>",       # (80-channel blocks: layers 3 - 4 of passes of 48 images and more)
     r"conv_wgrad_kernel<1, 1, [48], [123], 0>",   # (the 4x4x1 form: layer 1 of the large passes)
     r"bn_fwd_kernel", r"bn_bwd_fused_kernel<\d+, \d>", r"bn_bwd_apply_e_kernel", r"wgrad_reduce_kernel", r"wgrad_reduce_multi_kernel",
 ]

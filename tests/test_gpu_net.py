@@ -317,6 +317,75 @@ def test_virtual_params_forward_does_not_touch_model(cuda):
     assert np.abs(out_v - ref).max() < 1e-4
 
 
+def test_same_weights_reuses_the_packs_and_every_writer_invalidates_them(cuda):
+    """OCL_FWD_SAME_WEIGHTS (include/ocl_hip.h): inside `with model.same_weights()` forwards that follow a forward without a step in
+    between reuse the engine's weight packs -- same outputs, bit for bit, in eval and train mode; FusedSGD.step() reports itself, so the
+    next forward re-packs (its outputs follow the NEW weights: compared with a model that never carries the flag); a params_override
+    forward in between makes the engine re-pack by itself; and the raw flag on changed weights DOES give the stale result (the flag
+    is honoured, i.e. the test can see it)."""
+    from ocl_amd import ops
+    from ocl_amd.optim import FusedSGD
+    ops.set_deterministic(True)      # (bit-for-bit comparisons of train-mode passes need the order-independent batch sums)
+    try:
+        _same_weights_body(cuda, FusedSGD)
+    finally:
+        ops.set_deterministic(False)
+
+
+def _same_weights_body(cuda, FusedSGD):
+    rng = np.random.default_rng(17)
+    x = torch.from_numpy(rng.random((12, 3, 32, 32)).astype(np.float32)).to(cuda)
+    y = torch.from_numpy(rng.random((12, 100)).astype(np.float32)).to(cuda)
+    outs = {}
+    for tag in ("flag", "plain"):
+        m, _ = build("ER", "cifar100", cuda=cuda)
+        opt = FusedSGD(m, 0.1)
+        ctx = m.same_weights if tag == "flag" else __import__("contextlib").nullcontext
+        seq = []
+        with ctx():
+            m.eval()
+            with torch.no_grad():
+                seq.append(m.forward(x))            # packs
+                seq.append(m.forward(x))            # flag: reuses (eval: no launch at all in front of the convolutions)
+            m.train()
+            out = m.forward(x)                      # flag, train mode: the statistics arenas are cleared by a memset instead
+            seq.append(out.detach().clone())
+            opt.zero_grad()
+            (out * y).sum().backward()
+            opt.step()                              # writes the weights: the next forward must re-pack
+            with torch.no_grad():
+                seq.append(m.forward(x))
+                shadow = m.flat_params().clone() * 1.01
+                seq.append(m.forward_with_params(x, shadow))   # the arena now holds the shadow's packs
+                seq.append(m.forward(x))            # flag set by Python, refused by the engine (pack_src differs): re-packs
+        outs[tag] = [t.cpu().numpy() for t in seq]
+        if tag == "flag":
+            with torch.no_grad():
+                m.eval()
+                with m.same_weights():
+                    before = m.forward(x).cpu().numpy()
+                    # a torch write nobody reported: the version counters see it, the next forward re-packs
+                    m.flat_params().mul_(1.05)
+                    seen = m.forward(x).cpu().numpy()
+                    dict(m.named_parameters())["layer2.0.conv1.weight"].mul_(1.05)
+                    seen2 = m.forward(x).cpu().numpy()
+                    # ... and the RAW flag on changed weights does give the stale convolutions (the flag is honoured: this test can see it)
+                    m.flat_params().mul_(1.05)
+                    m._packed_version = m._weights_version()
+                    stale = m.forward(x).cpu().numpy()
+                fresh = m.forward(x).cpu().numpy()
+            assert not np.array_equal(seen, before) and not np.array_equal(seen2, seen) and not np.array_equal(stale, fresh)
+            m2, _ = build("ER", "cifar100", cuda=cuda)
+            m2.load_state_dict(m.state_dict())
+            m2.eval()
+            with torch.no_grad():
+                assert np.array_equal(m2.forward(x).cpu().numpy(), fresh)
+    for a, b in zip(outs["flag"], outs["plain"]):
+        assert np.array_equal(a, b)
+    assert np.array_equal(outs["flag"][0], outs["flag"][1])
+    assert not np.array_equal(outs["flag"][3], outs["flag"][2])
+
+
 def test_resnet_matches_reference_golden(cuda):
     """Directly against vectors recorded from the reference modules (tests/golden/resnet.npz)."""
     from ocl_amd.loss import cross_entropy_mean
