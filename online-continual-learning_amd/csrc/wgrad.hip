@@ -474,10 +474,44 @@ __device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part
     }
 }
 
+// Few slabs (S <= 4: layer 4 of a replay-sized pass, two thirds of the network's weights): one thread per output sums its S slab
+// entries itself, 256 outputs per block instead of 32 x 8 split lanes of which most idled.  Same arithmetic as the split form at
+// S <= 8 -- lane sums of one term each, combined in the same tree -- hence the same bits (csrc/netcheck against the library before:
+// 0 of 64 tensors differ).  20-image pass 832.5 -> 818.5 us, 13 images 807.7 -> 791.2; with the form taken up to S = 8 a 64-view pass
+// got 20 us SLOWER (its layer 4 has 8 slabs: all split lanes busy, and eight times the threads in flight): profiles/r5_reduce_few.txt
+__device__ __forceinline__ void wgrad_reduce_few(const float* __restrict__ partial, int S, int Mrows_total, int CoutP, int mrows_chunk,
+                                                 int KC, int ntaps, int CinReal, int Cout, float* __restrict__ grad, int accumulate, int block) {
+    const int idx = block * 256 + threadIdx.x;  // (t, ci, co) with co fastest
+    if (idx >= ntaps * CinReal * Cout) return;
+    const int co = idx % Cout;
+    const int r = idx / Cout;
+    const int ci = r % CinReal, t = r / CinReal;
+    const int chunk = ci / KC, cc = ci - chunk * KC;
+    const int row = chunk * mrows_chunk + t * KC + cc;
+    const int64_t stride = (int64_t)Mrows_total * CoutP;
+    const float* p = partial + (int64_t)row * CoutP + co;
+    float l[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) l[k] = k < S ? p[(int64_t)k * stride] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) l[k] = (l[k] + 0.f) + (0.f + 0.f);   // the split form's (s0 + s1) + (s2 + s3) with one term per lane
+    const float z = (0.f + 0.f) + (0.f + 0.f);                      // (lanes 4 .. 7 of the split form hold this)
+    float v = ((l[0] + l[1]) + (l[2] + l[3])) + ((z + z) + (z + z));
+    float* gp = grad + ((int64_t)co * CinReal + ci) * ntaps + t;
+    if (accumulate) v += *gp;
+    *gp = v;
+}
+constexpr int kReduceFewMaxS = 4;
+static int reduce_blocks(int S, int total) { return S <= kReduceFewMaxS ? cdiv(total, 256) : cdiv(total, 32); }
+
 __global__ void __launch_bounds__(256) wgrad_reduce_kernel(const float* __restrict__ partial, int S, int Mrows_total, int CoutP,
                                                            int mrows_chunk, int KC, int ntaps, int CinReal, int Cout,
                                                            float* __restrict__ grad, int accumulate) {
     __shared__ float red[8][33];
+    if (S <= kReduceFewMaxS) {   // (uniform per launch)
+        wgrad_reduce_few(partial, S, Mrows_total, CoutP, mrows_chunk, KC, ntaps, CinReal, Cout, grad, accumulate, blockIdx.x);
+        return;
+    }
     wgrad_reduce_body(partial, S, Mrows_total, CoutP, mrows_chunk, KC, ntaps, CinReal, Cout, grad, accumulate, blockIdx.x, red);
 }
 
@@ -489,6 +523,11 @@ __global__ void __launch_bounds__(256) wgrad_reduce_multi_kernel(const WgradRedu
 #pragma unroll 1
     while (l + 1 < m.n && (int)blockIdx.x >= m.L[l + 1].block0) ++l;
     const WgradReduceLayer& d = m.L[l];
+    if (d.S <= kReduceFewMaxS) {   // (uniform per block)
+        wgrad_reduce_few(m.partial + d.partial_off, d.S, d.Mrows_total, d.CoutP, d.mrows_chunk, d.KC, d.ntaps, d.CinReal, d.Cout,
+                         m.grads + d.grad_off, m.accumulate, (int)blockIdx.x - d.block0);
+        return;
+    }
     wgrad_reduce_body(m.partial + d.partial_off, d.S, d.Mrows_total, d.CoutP, d.mrows_chunk, d.KC, d.ntaps, d.CinReal, d.Cout,
                       m.grads + d.grad_off, m.accumulate, (int)blockIdx.x - d.block0, red);
 }
@@ -666,7 +705,7 @@ int launch_wgrad_reduce(const WgradPlan& p, float* grad_oihw, int accumulate, hi
     const int cin_real = a.Cin == 4 ? 3 : a.Cin;  // the stem's NHWC4 input carries a zero 4th channel
     const int total = a.ntaps * cin_real * a.Cout;
     ProfScope ps(PROF_WGRAD, s);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(cdiv(total, 32)), dim3(256), 0, s, a.partial, a.S, a.Mrows_total, a.CoutP,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(reduce_blocks(a.S, total)), dim3(256), 0, s, a.partial, a.S, a.Mrows_total, a.CoutP,
                        a.mblocks_per_chunk * 64 * p.MTW, a.KC, a.ntaps, cin_real, a.Cout, grad_oihw, accumulate);
     OCL_LAUNCH_CHECK();
     return OCL_OK;
@@ -689,7 +728,7 @@ int launch_wgrad_reduce_multi(WgradReduceMulti m, hipStream_t s) {
     int blocks = 0;
     for (int i = 0; i < m.n; ++i) {
         m.L[i].block0 = blocks;
-        blocks += cdiv(m.L[i].ntaps * m.L[i].CinReal * m.L[i].Cout, 32);
+        blocks += reduce_blocks(m.L[i].S, m.L[i].ntaps * m.L[i].CinReal * m.L[i].Cout);
     }
     ProfScope ps(PROF_WGRAD, s);
     hipLaunchKernelGGL(wgrad_reduce_multi_kernel, dim3(blocks), dim3(256), 0, s, m);

@@ -21,7 +21,7 @@ def _db(d, name):
 def main(tag, version, rnd="r3"):
     g = os.path.join(ROOT, "gpurun_out")
     p = os.path.join(ROOT, "profiles")
-    for sub, name, suffix in (("prof", "scr", ""), ("prof1", "scr", "_single_stream"), ("prof2", "aser", "_single_stream")):
+    for sub, name, suffix in (("prof", "scr", ""), ("prof1", "scr", "_single_stream"), ("prof2", "aser", "_single_stream"), ("prof3", "er", "_single_stream")):
         db = _db(os.path.join(g, "%s_%s" % (tag, sub)), name)
         if db:
             rocpd_stats.main(db, os.path.join(p, "%s_%s_kernel_stats_%s%s.csv" % (rnd, name, version, suffix)))

@@ -7,6 +7,7 @@ Q="--no-cpu-baseline --no-also --no-accuracy --no-roofline --preroll 0 --repeats
 timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/${T}_prof -o scr -- python bench.py --steps 50 --warmup 10 $Q > gpurun_out/${T}_prof.log 2>&1; echo "prof rc=$?"
 timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/${T}_prof1 -o scr -- python bench.py --steps 50 --warmup 10 $Q --single-stream > gpurun_out/${T}_prof1.log 2>&1; echo "prof single-stream rc=$?"
 timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/${T}_prof2 -o aser -- python bench.py --workload aser --steps 50 --warmup 10 $Q --single-stream > gpurun_out/${T}_prof2.log 2>&1; echo "prof aser rc=$?"
+timeout 300 rocprofv3 --kernel-trace --stats -d gpurun_out/${T}_prof3 -o er -- python bench.py --workload er --steps 50 --warmup 10 $Q --single-stream > gpurun_out/${T}_prof3.log 2>&1; echo "prof er rc=$?"
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/${T}_pmc_$c -o p -- python bench.py --steps 10 --warmup 3 $Q --single-stream > gpurun_out/${T}_pmc_$c.log 2>&1; echo "pmc $c rc=$?"
 done
