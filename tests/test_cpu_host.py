@@ -372,3 +372,40 @@ def test_texture_accuracy_stream_is_flip_invariant_and_class_separable():
     acc_flip = ncm(spectrum(x), spectrum(xt[:, :, ::-1]))
     acc_raw = ncm(x[..., 0].reshape(len(x), -1).astype(np.float32), xt[..., 0].reshape(len(xt), -1).astype(np.float32))
     assert acc > 0.7 and abs(acc - acc_flip) < 0.03 and acc_raw < 0.2, (acc, acc_flip, acc_raw)
+
+
+def test_same_weights_flag_bookkeeping_sees_every_kind_of_write():
+    """resnet._EngineMixin._weights_flag (the Python half of OCL_FWD_SAME_WEIGHTS, no GPU needed): the flag is raised only inside
+    `same_weights()`, only for a forward that follows another forward of the block, and never after a write -- FusedSGD.step()'s report,
+    a torch in-place write to a parameter (what load_state_dict does), a write to the flat array; a params_override forward neither
+    raises it nor disturbs the bookkeeping; leaving the block forgets what was packed."""
+    import torch.nn as nn
+    from types import SimpleNamespace
+    from ocl_amd import ffi
+    from ocl_amd.resnet import _EngineMixin
+
+    flat = torch.zeros(10)
+    p1, p2 = nn.Parameter(torch.zeros(2, 3)), nn.Parameter(torch.zeros(4))
+    p1.data, p2.data = flat[:6].view(2, 3), flat[6:]
+    m = SimpleNamespace(_flat=flat, _views=[(p1, None), (p2, None)], _weights_dirty=True, _same_weights=False, _packed_version=None)
+    m._weights_version = lambda: _EngineMixin._weights_version(m)
+    flag = lambda override=None: _EngineMixin._weights_flag(m, override)
+    same = lambda: _EngineMixin.same_weights(m)
+    S = ffi.FWD_SAME_WEIGHTS
+    assert flag() == 0                                  # outside a block: never
+    with same():
+        assert flag() == 0 and flag() == S and flag() == S      # first forward of the block packs, the next ones reuse
+        _EngineMixin.mark_weights_written(m)                    # FusedSGD.step()
+        assert flag() == 0 and flag() == S
+        with torch.no_grad():
+            p1.mul_(2.0)                                        # load_state_dict / copy_ on a parameter
+        assert flag() == 0 and flag() == S
+        flat.add_(1.0)                                          # a write to the flat array
+        assert flag() == 0 and flag() == S
+        assert flag(override=flat.clone()) == 0 and flag() == S  # (the engine itself refuses the flag after an override pass)
+        with same():                                            # nested blocks
+            assert flag() == S
+        assert flag() == S
+    assert flag() == 0                                  # left the block
+    with same():
+        assert flag() == 0                              # ... and what was packed before is forgotten
