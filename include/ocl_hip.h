@@ -229,6 +229,8 @@ int ocl_net_bind(ocl_net* net, float* params, float* grads, float* running, int6
                                      feature pass, the memory pass and the combined pass of agents/exp_replay.py:49-84): the engine
                                      reuses the weight packs it made then instead of re-packing (it still re-packs when its arena
                                      holds another array's packs, e.g. after a params_override call) */
+#define OCL_FWD_PACK_ALL 32u      /* with a pass that packs (no OCL_FWD_SAME_WEIGHTS, or refused): also write the data-gradient packs
+                                     although this pass keeps no tape -- a taped pass on the same weights will follow */
 /* x: [n,3,H,W] fp32 NCHW (what the reference's agents hand to model.forward).
  * groups: the batch is `groups` equal consecutive sub-batches that the reference would have run as
  * separate forward calls (SCR's two views, agents/scr.py:55): BatchNorm statistics are per group.

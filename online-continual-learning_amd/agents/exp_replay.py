@@ -73,14 +73,25 @@ class ExperienceReplay(ContinualLearner):
         total.backward(unit_gradient(total))
         self.opt.step()
 
-    def _two_pass_step(self, batch_x, batch_y, batch_y_host, meters, aser, retrieved=None, logits=None):
-        if logits is None:      # (the pipelined ASER loop has issued this forward already)
-            logits = self.model.forward(batch_x)
-        # ASER mode throws the gradients of passes 1 and 2 away (zero_grad below): their losses are only ever printed / traced, so
-        # without a reader (no verbose meter, no trace, no distillation term to mix in) the loss kernels are not launched either
+    def _passes_12_have_readers(self, aser):
+        """ASER mode throws the gradients of the batch pass and the memory pass away (exp_replay.py:76 zero_grad): their logits and
+        losses are only ever printed / traced / mixed with a distillation term.  Without such a reader (no verbose meter, no trace, no
+        KD trick, no MIR retrieval reading the batch pass's gradient) the two passes are run for what they DO leave behind -- their
+        BatchNorm running-statistic updates -- and nothing else: no head, no loss kernels, no tape (model.forward_stats_only).
+        `_force_losses` (tests) makes the readers' path run regardless: tests/test_gpu_steps.py proves the two paths end in the same
+        weights, statistics and memory bit for bit."""
         trick = self.params.trick
+        return (not aser or self.params.retrieve == 'MIR' or self.verbose or debug.on() or trick['kd_trick'] or trick['kd_trick_star']
+                or getattr(self, "_force_losses", False) or not hasattr(self.model, "forward_stats_only"))
+
+    def _two_pass_step(self, batch_x, batch_y, batch_y_host, meters, aser, retrieved=None, logits=None):
         back12 = not aser or self.params.retrieve == 'MIR'   # MIR reads the batch pass's gradient
-        need_loss = back12 or self.verbose or debug.on() or trick['kd_trick'] or trick['kd_trick_star']
+        need_loss = self._passes_12_have_readers(aser)
+        if logits is None:      # (else: the pipelined ASER loop has issued this pass already)
+            if need_loss:
+                logits = self.model.forward(batch_x)
+            else:
+                self.model.forward_stats_only(batch_x)
         if need_loss:
             loss = self._kd_mix(self.criterion(logits, batch_y), logits, batch_x)
             self._track(meters[0], logits, batch_y, loss)
@@ -92,13 +103,15 @@ class ExperienceReplay(ContinualLearner):
         mem_x, mem_y = retrieved if retrieved is not None else self.buffer.retrieve(x=batch_x, y=batch_y)
         if mem_x.size(0) > 0:
             mem_x, mem_y = maybe_cuda(mem_x, self.cuda), maybe_cuda(mem_y, self.cuda)
-            mem_logits = self.model.forward(mem_x)
-            if need_loss or not aser:
+            if not need_loss:
+                self.model.forward_stats_only(mem_x)
+            else:
+                mem_logits = self.model.forward(mem_x)
                 loss_mem = self._kd_mix(self.criterion(mem_logits, mem_y), mem_logits, mem_x)
                 self._track(meters[1], mem_logits, mem_y, loss_mem)
                 self._emit("er_loss_mem", loss_mem)
-            if not aser:
-                loss_mem.backward(unit_gradient(loss_mem))
+                if not aser:
+                    loss_mem.backward(unit_gradient(loss_mem))
 
         if aser:
             # exp_replay.py:76-84: the update comes from one more pass over memory + batch; passes 1 and 2 only leave their
@@ -171,7 +184,12 @@ class ExperienceReplay(ContinualLearner):
                 batch_y_host = train_loader.last_y_host
                 pre = None
                 if pipeline:
-                    pre = self.model.forward(batch_x)   # (same weights as update_begin's feature pass, which read the stepped weights first)
+                    # (same weights as update_begin's feature pass, which read the stepped weights first)
+                    if self._passes_12_have_readers(aser):
+                        pre = self.model.forward(batch_x)
+                    else:
+                        self.model.forward_stats_only(batch_x)
+                        pre = True          # "issued": nobody reads its logits
                     upd.update_finish(self.buffer, pending)
                     pending = None
                 for j in range(self.mem_iters):

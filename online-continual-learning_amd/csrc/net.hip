@@ -841,6 +841,7 @@ static int trunk_forward_train(ocl_net* n, PlanSet* ps, const float* P, float* S
         if ((rc = bn_fwd(b.conv2, at(c2.y_off, c2), z, res, 1, st))) return rc;
         cur = z;
     }
+    if (!feat) return OCL_OK;   // (a pass run for its running-statistic updates alone)
     return launch_avgpool_fwd(cur, feat, Nc, n->Hf, n->Wf, n->convs[n->blocks.back().conv2].Cout, st);
 }
 
@@ -896,7 +897,9 @@ int ocl_net_forward_segments(ocl_net* n, const float* const* xs, const int32_t* 
     for (auto& c : n->convs) max_elems = std::max(max_elems, c.Cout * c.Cin * c.k * c.k);
     // every forward packs (the caller may have stepped the weights), but only the layouts the pass reads: the forward packs, and the
     // data-gradient packs when a backward will follow this tape
-    const int pack_mask = n->pack_need_fwd | ((flags & OCL_FWD_SAVE_TAPE) ? n->pack_need_bwd : 0);
+    // (OCL_FWD_PACK_ALL: the caller will run more passes on these weights, a taped one among them: pack for the backward now as well)
+    // (a refused OCL_FWD_SAME_WEIGHTS counts as the same hint: the caller is inside a block of passes on one set of weights)
+    const int pack_mask = n->pack_need_fwd | ((flags & (OCL_FWD_SAVE_TAPE | OCL_FWD_PACK_ALL | OCL_FWD_SAME_WEIGHTS)) ? n->pack_need_bwd : 0);
     // OCL_FWD_SAME_WEIGHTS: the packs of the previous forward are still those of this array -- no pack launch; a train-mode pass
     // clears its statistics arenas (the pack launch's other job) with one memset over both, an eval-mode pass needs nothing
     const bool same_weights = (flags & OCL_FWD_SAME_WEIGHTS) && n->pack_src == P && (n->pack_have & pack_mask) == pack_mask;
@@ -937,7 +940,7 @@ int ocl_net_forward_segments(ocl_net* n, const float* const* xs, const int32_t* 
             OCL_HIP(hipMemsetAsync(lo, 0, (size_t)(hi - lo), s));
         }
         if (train) {
-            if ((rc = trunk_forward_train(n, ps, P, S, N, groups, upd && !frozen, feat, s, side, frozen, fused))) return rc;
+            if ((rc = trunk_forward_train(n, ps, P, S, N, groups, upd && !frozen, (feat_out || want_head) ? feat : nullptr, s, side, frozen, fused))) return rc;
         } else {
             float* fold = (float*)(n->ws + n->off_fold);
             if ((rc = launch_bn_fold(P, n->running, fold, fold_descs(n), (int)n->bns.size(), 1e-5f, s))) return rc;
@@ -975,15 +978,20 @@ int ocl_net_forward_segments(ocl_net* n, const float* const* xs, const int32_t* 
     ocl_net::GraphKey key;
     memset(&key, 0, sizeof(key));
     key.kind = 0; key.N = N; key.G = groups; key.slot = slot; key.a = (int)flags; key.b = pack_mask;
-    key.c = (want_head ? 1 : 0) | (feat == S + n->feat_off ? 2 : 0) | (same_weights ? 4 : 0);
+    key.c = (want_head ? 1 : 0) | (feat == S + n->feat_off ? 2 : 0) | (same_weights ? 4 : 0) | ((feat_out || want_head) ? 8 : 0);
     key.p = (uint64_t)(uintptr_t)P;
     // (sequences that fork to the side stream are not replayed: as a graph the SCR pass ran at 4.2 ms per step against 2.35 with
     // stream launches -- profiles/r4_graph_replay.txt -- while a single-stream ER pass keeps its GPU time and halves the host's)
     rc = side ? body() : run_replayed(n, key, s, body);
     // host state of the pass (also when the launches were replayed)
     if (!same_weights || train) n->bsums_clean = true;
-    n->pack_have = n->pack_src == P ? (n->pack_have | pack_mask) : pack_mask;   // (older packs of the same array stay as they were)
-    n->pack_src = P;
+    // A pack launch wrote exactly `pack_mask` from the array's CURRENT contents; whatever else the arena held for the same pointer may be
+    // from before an optimiser step and counts as gone (round 5: with OCL_FWD_SAME_WEIGHTS a stale data-gradient pack would otherwise
+    // be trusted by the next taped forward -- the bug tests/test_gpu_net.py::test_same_weights_... now pins)
+    if (!same_weights) {
+        n->pack_have = pack_mask;
+        n->pack_src = P;
+    }
     if (rc != OCL_OK) return rc;
     if (train) {
         n->slot_fused[slot] = fused;

@@ -80,7 +80,7 @@ SIGNATURES = {
     "ocl_mfma_calibrate": (C.c_int, [C.c_int, vp, C.POINTER(C.c_double), C.POINTER(C.c_double), vp]),
 }
 
-FWD_TRAIN, FWD_SAVE_TAPE, FWD_UPDATE_RUNNING, FWD_FROZEN_BN, FWD_SAME_WEIGHTS = 1, 2, 4, 8, 16
+FWD_TRAIN, FWD_SAVE_TAPE, FWD_UPDATE_RUNNING, FWD_FROZEN_BN, FWD_SAME_WEIGHTS, FWD_PACK_ALL = 1, 2, 4, 8, 16, 32
 
 
 def lib():

@@ -43,9 +43,13 @@ def compute_knn_sv_pair(model, eval_a_x, eval_a_y, eval_b_x, eval_b_y, cand_x, c
     features (computed twice by the reference) are the same in both calls."""
     na, nb, nc = eval_a_x.size(0), eval_b_x.size(0), cand_x.size(0)
     f = mini_batch_deep_features(model, [maybe_cuda(eval_a_x), maybe_cuda(eval_b_x), maybe_cuda(cand_x)], na + nb + nc)
-    fa, fb, fc = f[0:na].contiguous(), f[na:na + nb].contiguous(), f[na + nb:].contiguous()
-    return (ops.knn_sv(fa, eval_a_y, fc, cand_y, k, want_order=want_order),
-            ops.knn_sv(fb, eval_b_y, fc, cand_y, k, want_order=want_order))
+    # one workgroup per evaluation row, rows independent: both evaluation sets are ONE launch over the stacked rows
+    fab, fc = f[0:na + nb].contiguous(), f[na + nb:].contiguous()
+    sv = ops.knn_sv(fab, torch.cat((eval_a_y, eval_b_y)), fc, cand_y, k, want_order=want_order)
+    if want_order:
+        sv, order = sv
+        return (sv[:na], order[:na]), (sv[na:], order[na:])
+    return sv[:na], sv[na:]
 
 
 def add_minority_class_input(cur_x, cur_y, mem_size, num_class, cur_y_host=None):

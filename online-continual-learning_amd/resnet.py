@@ -223,7 +223,8 @@ class _EngineMixin:
             self._packed_version, self._weights_dirty = None, False
             return 0
         v = self._weights_version()
-        flag = ffi.FWD_SAME_WEIGHTS if (not self._weights_dirty and self._packed_version == v) else 0
+        # (a pass of the block that does pack writes the data-gradient packs too: a taped pass on the same weights follows in the block)
+        flag = ffi.FWD_SAME_WEIGHTS if (not self._weights_dirty and self._packed_version == v) else ffi.FWD_PACK_ALL
         self._packed_version, self._weights_dirty = v, False
         return flag
 
@@ -288,6 +289,17 @@ class _EngineMixin:
         if want_feat:
             return out, feat
         return out, slot, gen
+
+    def forward_stats_only(self, x):
+        """A train-mode pass run for its BatchNorm running-statistic updates alone (the batch and memory passes of ER + ASER, whose
+        logits and gradients the reference throws away, agents/exp_replay.py:49-76): no head, no pooled features, no tape, no output."""
+        self._ensure_bound()
+        if not self.training:
+            raise RuntimeError("forward_stats_only is a train-mode pass")
+        parts, n, ptrs, sizes = self._segments(x)
+        flags = ffi.FWD_TRAIN | ffi.FWD_UPDATE_RUNNING | self._weights_flag(None)
+        ffi.check(ffi.lib().ocl_net_forward_segments(self._net, ptrs, sizes, len(parts), 1, flags, None, None, None, self._n_tapes, ffi.stream()),
+                  "net_forward(stats only)")
 
     def _engine_eval_forward(self, x, want_out=True, want_feat=False, params_override=None):
         self._ensure_bound()

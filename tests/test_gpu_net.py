@@ -358,6 +358,23 @@ def _same_weights_body(cuda, FusedSGD):
                 shadow = m.flat_params().clone() * 1.01
                 seq.append(m.forward_with_params(x, shadow))   # the arena now holds the shadow's packs
                 seq.append(m.forward(x))            # flag set by Python, refused by the engine (pack_src differs): re-packs
+            # The ASER loop's order after a step: an eval-mode feature pass FIRST (it packs the forward layout; the data-gradient packs
+            # in the arena are the previous step's), then a taped pass + backward.  The first version of the flag trusted the stale
+            # data-gradient pack here: one more step, and the gradient itself, must match the model that never carries the flag.
+            out = m.forward(x)
+            opt.zero_grad()
+            (out * y).sum().backward()
+            opt.step()
+            m.eval()
+            with torch.no_grad():
+                seq.append(m.features(x))
+            m.train()
+            m.forward_stats_only(x)                 # (and a pass run for its running statistics alone in between)
+            out = m.forward(x)
+            opt.zero_grad()
+            (out * y).sum().backward()
+            seq.append(m.flat_grads().clone())
+            seq.append(torch.cat([v.flatten().float() for k, v in m.state_dict().items() if "running" in k]))
         outs[tag] = [t.cpu().numpy() for t in seq]
         if tag == "flag":
             with torch.no_grad():

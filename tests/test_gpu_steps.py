@@ -524,6 +524,41 @@ def test_aser_pipelined_loop_is_schedule_only(cuda, monkeypatch):
         assert np.abs(r1[k] - r0[k]).max() < 1e-4 * max(1.0, np.abs(r0[k]).max()), k
 
 
+def test_aser_passes_without_readers_are_schedule_only(cuda):
+    """ER + ASER: the batch pass and the memory pass of an iteration only leave their BatchNorm running-statistic updates behind (the
+    reference throws their gradients away, agents/exp_replay.py:76).  Without a reader of their logits / losses the loop runs them as
+    model.forward_stats_only (no head, no loss kernels, no tape), the retrieval's two Shapley matrices come out of ONE kNN launch, and
+    the engine packs the weights once per optimiser step (OCL_FWD_SAME_WEIGHTS).  Against the readers' path (`_force_losses`: full
+    forwards under autograd + both losses, as the co-simulations run it), with order-independent batch sums: 40 free-running steps
+    (memory filling up, then Shapley-ranked replacement and retrieval) end in the same weights, running statistics, replay memory,
+    class table and counters BIT FOR BIT."""
+    from ocl_amd import ops
+    from ocl_amd.plugins.buffer_utils import ClassBalancedRandomSampling as CBRS
+    cfg = dict(STEP_CASES["aser_c100"])
+    rng = np.random.default_rng(77)
+    x = rng.integers(0, 256, (400, 32, 32, 3), dtype=np.uint8)
+    y = rng.integers(0, 8, 400).astype(np.int64)
+    finals = []
+    ops.set_deterministic(True)
+    try:
+        for force in (False, True):
+            params, model, agent = build_agent(cfg)
+            agent._force_losses = force
+            agent.train_learner(torch.from_numpy(x).to(cuda), y)
+            torch.cuda.synchronize()
+            table = {int(k): sorted(v) for k, v in CBRS.class_index_cache.items()}
+            finals.append((model.flat_params().cpu().numpy().copy(), agent.buffer.buffer_img.cpu().numpy().copy(),
+                           agent.buffer.buffer_label.cpu().numpy().copy(), agent.buffer.n_seen_so_far, table,
+                           {k: v.cpu().numpy().copy() for k, v in model.state_dict().items() if "running" in k or "num_batches" in k}))
+    finally:
+        ops.set_deterministic(False)
+    (w1, b1, l1, n1, t1, r1), (w0, b0, l0, n0, t0, r0) = finals
+    assert n1 == n0 == 400 and np.array_equal(l1, l0) and np.array_equal(b1, b0) and t1 == t0
+    assert np.array_equal(w1, w0)
+    for k in r0:
+        assert np.array_equal(r1[k], r0[k]), k
+
+
 def test_kd_trick_teacher_and_combined_loss_vs_oracle(cuda):
     """KD trick (agents/exp_replay.py:42-44,64-66, utils/kd_manager.py): after the first task the teacher is the end-of-task
     model; its train-mode forward (batch statistics, no effect on the student's running statistics) and the combined loss
