@@ -139,3 +139,18 @@ def test_xcd_aware_workgroup_order_is_planned_where_output_blocks_share_pixel_ti
             assert f["xcd"] == (gy if gy > 1 and gx >= 8 else 0) and gx == f["S"]
             some += f["xcd"] > 0
     assert some >= 10
+
+
+def test_eighty_channel_weight_gradient_blocks_are_planned_by_pass_size():
+    """conv_wgrad_kernel's 80-channel output blocks (NTW = 5: layers 3 - 4 exactly, no padded columns) are planned on passes of 48 images
+    and more -- faster alone at every size, but beside the dependent chain of a 20-image pass the whole pass got slower
+    (profiles/r5_wgrad_ntw5.txt): layers 1 - 2 (<= 40 channels) never, layers 3 - 4 from 48 images on, with slabs of at most 12 MB."""
+    for n, groups, hw, wide in [(220, 2, 32, True), (64, 2, 32, True), (48, 2, 32, True), (50, 1, 84, True), (20, 1, 32, False), (20, 1, 84, False),
+                                (46, 2, 32, False)]:
+        for l in [l for l in _plan_lines(n, groups, hw) if " wgrad " in l]:
+            f, name = _fields(l), l.split()[0]
+            if name.startswith(("layer3", "layer4")):
+                assert f["NTW"] == (5 if wide else 3), l
+            else:
+                assert f["NTW"] <= 3, l
+            assert float(re.search(r"partial= *([\d.]+) MB", l).group(1)) <= 12.6, l
