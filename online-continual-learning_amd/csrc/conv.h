@@ -273,6 +273,16 @@ struct BnFwdArgs {
     float momentum, eps;
     const float* frozen_mean;   // non-null: normalise with these statistics instead of the batch's (eval-mode BatchNorm kept on the
     const float* frozen_var;    // tape: the forward of model.eval() under autograd, utils/buffer/gss_greedy_update.py:16,77-79)
+    // Second BatchNorm whose normalised output is this one's residual (the projection shortcut's, models/resnet.py:27-30,35:
+    // out += self.shortcut(x)): z = relu(bn(y) + bn_b(yb)) in one launch -- the shortcut's own normalise launch and its output tensor
+    // are gone.  Same arithmetic in the same order as the two launches (fma, then add): same bits.  yb == nullptr: none.
+    const float* yb;
+    const StatCell* stats_b;
+    const float *gamma_b, *beta_b;
+    float *running_mean_b, *running_var_b;
+    int64_t* nbt_b;
+    float *save_mean_b, *save_invstd_b;
+    const float *frozen_mean_b, *frozen_var_b;
 };
 int launch_bn_fwd(const BnFwdArgs& a, hipStream_t s);
 // z = relu(fma(y, scale, shift)) from saved statistics (the activation a fused pass never wrote: debug copies, tests)

@@ -2436,10 +2436,31 @@ __global__ void __launch_bounds__(256) bn_fwd_kernel(const BnFwdArgs a) {
     }
     if (blockIdx.x == 0 && g == 0 && a.running_mean)
         bn_running_update(a.stats, a.stat_rep_stride, a.G, a.C, M, a.momentum, a.eps, a.running_mean, a.running_var, a.nbt, tid, 256);
+    float* scb = sm + 2 * a.C;
+    float* shb = sm + 3 * a.C;
+    if (a.yb) {   // the projection shortcut's BatchNorm: the same table, statistics and running update from its own arena
+        for (int c = tid; c < a.C; c += 256) {
+            double mean, var;
+            bn_batch_moments(a.stats_b, a.stat_rep_stride, g, c, a.C, M, a.eps, mean, var);
+            if (a.frozen_mean_b) {
+                mean = (double)a.frozen_mean_b[c];
+                var = (double)a.frozen_var_b[c];
+            }
+            const double invstd = 1.0 / sqrt(var + (double)a.eps);
+            bn_scale_shift(a.gamma_b[c], a.beta_b[c], (float)mean, (float)invstd, scb[c], shb[c]);
+            if (blockIdx.x == 0) {
+                a.save_mean_b[(int64_t)g * a.C + c] = (float)mean;
+                a.save_invstd_b[(int64_t)g * a.C + c] = (float)invstd;
+            }
+        }
+        if (blockIdx.x == 0 && g == 0 && a.running_mean_b)
+            bn_running_update(a.stats_b, a.stat_rep_stride, a.G, a.C, M, a.momentum, a.eps, a.running_mean_b, a.running_var_b, a.nbt_b, tid, 256);
+    }
     __syncthreads();
     const int C4 = a.C >> 2;
     const int64_t units = a.m_per_group * C4;
     const float4* y4 = (const float4*)a.y + (int64_t)g * units;
+    const float4* b4 = a.yb ? (const float4*)a.yb + (int64_t)g * units : nullptr;
     const float4* r4 = a.res ? (const float4*)a.res + (int64_t)g * units : nullptr;
     float4* z4 = (float4*)a.z + (int64_t)g * units;
     for (int64_t u = (int64_t)blockIdx.x * 256 + tid; u < units; u += (int64_t)gridDim.x * 256) {
@@ -2453,6 +2474,14 @@ __global__ void __launch_bounds__(256) bn_fwd_kernel(const BnFwdArgs a) {
             const float4 r = r4[u];
             v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
         }
+        if (b4) {
+            float4 r = b4[u];
+            r.x = __fmaf_rn(r.x, scb[c], shb[c]);
+            r.y = __fmaf_rn(r.y, scb[c + 1], shb[c + 1]);
+            r.z = __fmaf_rn(r.z, scb[c + 2], shb[c + 2]);
+            r.w = __fmaf_rn(r.w, scb[c + 3], shb[c + 3]);
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+        }
         if (a.relu) {
             v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
         }
@@ -2464,7 +2493,7 @@ int launch_bn_fwd(const BnFwdArgs& a, hipStream_t s) {
     const int64_t units = a.m_per_group * (a.C / 4);
     const int bx = (int)std::max<int64_t>(1, std::min<int64_t>(1024, (units + 1023) / 1024));
     ProfScope ps(PROF_BN, s);
-    hipLaunchKernelGGL(bn_fwd_kernel, dim3(bx, a.G), dim3(256), (size_t)a.C * 8, s, a);
+    hipLaunchKernelGGL(bn_fwd_kernel, dim3(bx, a.G), dim3(256), (size_t)a.C * (a.yb ? 16 : 8), s, a);
     OCL_LAUNCH_CHECK();
     return OCL_OK;
 }

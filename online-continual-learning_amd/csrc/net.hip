@@ -764,9 +764,10 @@ static int trunk_forward_train(ocl_net* n, PlanSet* ps, const float* P, float* S
     int rc = OCL_OK;
     // (cleared by the forward's weight-pack launch)
     auto at = [&](int64_t off, const ConvInfo& c) { return S + off + (int64_t)img0 * c.Ho * c.Wo * c.Cout; };
-    // side: the projection shortcut (1x1 conv + BatchNorm, 3 blocks) runs on the engine's second stream next to conv1 / bn1 /
-    // conv2 of its block, which do not depend on it
-    auto bn_fwd = [&](int conv_i, const float* y, float* z, const float* res, int relu, hipStream_t st) -> int {
+    // side: the projection shortcut's 1x1 convolution (3 blocks) runs on the engine's second stream next to conv1 / bn1 / conv2 of its
+    // block, which do not depend on it
+    // conv_b >= 0: the projection shortcut whose BatchNorm output is this BatchNorm's residual, normalised in the same launch
+    auto bn_fwd = [&](int conv_i, const float* y, float* z, const float* res, int relu, hipStream_t st, int conv_b = -1) -> int {
         const ConvInfo& c = n->convs[conv_i];
         const BnInfo& b = n->bns[c.bn];
         BnFwdArgs a;
@@ -788,6 +789,23 @@ static int trunk_forward_train(ocl_net* n, PlanSet* ps, const float* P, float* S
             a.frozen_mean = n->running + b.stat_off;
             a.frozen_var = n->running + b.stat_off + b.C;
         }
+        if (conv_b >= 0) {
+            const ConvInfo& cb = n->convs[conv_b];
+            const BnInfo& bb = n->bns[cb.bn];
+            a.yb = at(cb.y_off, cb);
+            a.stats_b = stats + bb.arena_off;
+            a.gamma_b = P + n->tensors[bb.gamma_t].off;
+            a.beta_b = P + n->tensors[bb.beta_t].off;
+            a.running_mean_b = upd ? n->running + bb.stat_off : nullptr;
+            a.running_var_b = upd ? n->running + bb.stat_off + bb.C : nullptr;
+            a.nbt_b = upd ? n->nbt + cb.bn : nullptr;
+            a.save_mean_b = S + bb.save_off + (int64_t)g0 * bb.C;
+            a.save_invstd_b = S + bb.save_off + (int64_t)kGmax * bb.C + (int64_t)g0 * bb.C;
+            if (frozen) {
+                a.frozen_mean_b = n->running + bb.stat_off;
+                a.frozen_var_b = n->running + bb.stat_off + bb.C;
+            }
+        }
         return launch_bn_fwd(a, st);
     };
     auto conv_stats = [&](int conv_i, const float* in, hipStream_t st) -> int {
@@ -807,13 +825,11 @@ static int trunk_forward_train(ocl_net* n, PlanSet* ps, const float* P, float* S
         float* z = at(b.z_off, c2);
         const float* res = cur;
         if (b.convs >= 0) {
-            const ConvInfo& cs = n->convs[b.convs];
             hipStream_t ss = side ? n->s2 : st;
             if (side && (rc = side_wait(n, st))) return rc;       // `cur` (and the zeroed statistics) are ready
+            // (its BatchNorm is applied by the block's last BatchNorm launch below: z = relu(bn2(y2) + bn_s(ys)), one launch for both)
             if ((rc = conv_stats(b.convs, cur, ss))) return rc;
-            float* sc = n->gbuf(0);
-            if ((rc = bn_fwd(b.convs, at(cs.y_off, cs), sc, nullptr, 0, ss))) return rc;
-            res = sc;
+            res = nullptr;
         }
         if ((rc = conv_stats(b.conv1, cur, st))) return rc;
         if (fuse) {
@@ -838,7 +854,7 @@ static int trunk_forward_train(ocl_net* n, PlanSet* ps, const float* P, float* S
             if ((rc = conv_stats(b.conv2, a1, st))) return rc;
         }
         if (b.convs >= 0 && side && (rc = side_join(n, st))) return rc;
-        if ((rc = bn_fwd(b.conv2, at(c2.y_off, c2), z, res, 1, st))) return rc;
+        if ((rc = bn_fwd(b.conv2, at(c2.y_off, c2), z, res, 1, st, b.convs))) return rc;
         cur = z;
     }
     if (!feat) return OCL_OK;   // (a pass run for its running-statistic updates alone)
