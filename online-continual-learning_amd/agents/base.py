@@ -148,7 +148,7 @@ class ContinualLearner(torch.nn.Module, metaclass=abc.ABCMeta):
             seg[np.asarray(self.old_labels, dtype=np.int64)] = 0
             seg[np.asarray(self.new_labels, dtype=np.int64)] = 1
             return cross_entropy_segmented_mean(logits, labels, ops.upload(torch.from_numpy(seg), logits.device))
-        labels = labels.clone()
+        # (the reference clones the labels first, agents/base.py:94, because its label tricks relabel in place; nothing here writes to them: no copy launch)
         if self.params.agent in ['SCR', 'SCP']:
             SC = SupConLoss(temperature=self.params.temp)
             return SC(logits, labels)

@@ -140,15 +140,21 @@ def sgd_step(params_flat, grads_flat, lr, weight_decay=0.0, grad_scale=1.0, out=
 
 
 # ---- K6 ----------------------------------------------------------------------------------------------
-def cross_entropy(logits, y, reduction="mean", want_grad=True):
-    """(loss, dlogits): torch.nn.CrossEntropyLoss / F.cross_entropy(reduction='none')."""
+def cross_entropy(logits, y, reduction="mean", want_grad=True, dl_out=None):
+    """(loss, dlogits): torch.nn.CrossEntropyLoss / F.cross_entropy(reduction='none').  dl_out: a contiguous float32 [n, c] tensor
+    (e.g. a row block of a larger gradient buffer) that receives dlogits instead of a fresh one."""
     ffi.init()
     logits = _f32(logits)
     y = _i64(y)
     n, c = logits.shape
     red = {"none": 0, "mean": 1}[reduction]
     loss = torch.empty(n if red == 0 else 1, dtype=torch.float32, device=logits.device)
-    dl = torch.empty_like(logits) if want_grad else None
+    if dl_out is not None:
+        if dl_out.shape != logits.shape or dl_out.dtype != torch.float32 or not dl_out.is_contiguous() or dl_out.device != logits.device:
+            raise RuntimeError("cross_entropy: dl_out must be a contiguous float32 %s tensor on %s" % (tuple(logits.shape), logits.device))
+        dl = dl_out
+    else:
+        dl = torch.empty_like(logits) if want_grad else None
     ffi.check(ffi.lib().ocl_ce_fwd_bwd(ffi.ptr(logits), ffi.ptr(y), n, c, red, ffi.ptr(loss), ffi.ptr(dl), ffi.stream()), "ce")
     return (loss if red == 0 else loss[0]), dl
 

@@ -351,6 +351,26 @@ class _EngineMixin:
             raise RuntimeError("forward_views: the views must hold the same number of images, got %s" % sizes)
         return self._forward_out(tuple(parts), groups=len(views))
 
+    def forward_views_taped(self, views):
+        """forward_views for a caller that computes dL/dout itself: (out, tape) without an autograd node; backward_taped(tape, dout)
+        runs the backward of exactly this pass into the flat gradient (overwrite / accumulate as loss.backward() would).  Saves the
+        slice / add / fill launches autograd spends on `both[:n]`, `both[n:]` (agents/exp_replay.py: the merged ER step)."""
+        self._ensure_bound()
+        if not self.training:
+            raise RuntimeError("forward_views_taped is a train-mode pass")
+        parts, sizes = [], []
+        for v in views:
+            vs = list(v) if isinstance(v, (list, tuple)) else [v]
+            parts += vs
+            sizes.append(sum(t.shape[0] for t in vs))
+        if len(set(sizes)) != 1:
+            raise RuntimeError("forward_views_taped: the views must hold the same number of images, got %s" % sizes)
+        out, slot, gen = self._engine_train_forward(tuple(parts), len(views), save=True)
+        return out, (slot, gen)
+
+    def backward_taped(self, tape, dout):
+        self._engine_backward(tape[0], tape[1], dout)
+
     def forward_with_params(self, x, flat_params):
         """no-grad forward of a virtual model (MIR's theta - lr*grad, mir_retrieve.py:21,25) in the current mode,
         without touching this model's BatchNorm running statistics (the reference updates the deepcopy's)."""

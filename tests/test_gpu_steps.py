@@ -497,6 +497,36 @@ def test_er_data_stream_overlap_is_schedule_only(cuda, monkeypatch):
     assert np.array_equal(w1, w0)
 
 
+def test_er_merged_step_direct_backward_is_schedule_only(cuda):
+    """agents/exp_replay.py::_merged_step hands the engine's backward ONE dL/dlogits buffer whose two row blocks the two cross-entropy
+    launches wrote, instead of letting autograd assemble it (two slice-backward fills, two copies, an add, the loss add).  Same numbers
+    into the same backward: with order-independent batch sums 60 free-running ER steps end in bit-identical weights, running
+    statistics and replay memory on both paths (`_force_autograd` = the autograd path)."""
+    from ocl_amd import ops
+    cfg = dict(STEP_CASES["er_c10"], mem_size=200)
+    rng = np.random.default_rng(81)
+    x = rng.integers(0, 256, (600, 32, 32, 3), dtype=np.uint8)
+    y = rng.integers(0, 10, 600).astype(np.int64)
+    finals = []
+    ops.set_deterministic(True)
+    try:
+        for force in (False, True):
+            params, model, agent = build_agent(cfg)
+            agent._force_autograd = force
+            agent.train_learner(torch.from_numpy(x).to(cuda), y)
+            torch.cuda.synchronize()
+            finals.append((model.flat_params().cpu().numpy().copy(), agent.buffer.buffer_img.cpu().numpy().copy(),
+                           agent.buffer.buffer_label.cpu().numpy().copy(), agent.buffer.n_seen_so_far,
+                           {k: v.cpu().numpy().copy() for k, v in model.state_dict().items() if "running" in k}))
+    finally:
+        ops.set_deterministic(False)
+    (w1, b1, l1, n1, r1), (w0, b0, l0, n0, r0) = finals
+    assert n1 == n0 == 600 and np.array_equal(l1, l0) and np.array_equal(b1, b0)
+    assert np.array_equal(w1, w0)
+    for k in r0:
+        assert np.array_equal(r1[k], r0[k]), k
+
+
 def test_aser_pipelined_loop_is_schedule_only(cuda, monkeypatch):
     """agents/exp_replay.py issues the batch-pass forward of iteration i+1 before the host half of iteration i's ASER update (wait
     for the ranking, class table, row moves).  Same kernels on the same data, same RNG draws: 40 free-running ER + ASER steps
