@@ -110,6 +110,7 @@ struct ConvArgs {
 struct ConvPlan {
     ConvArgs a;
     int cs;                     // 1: conv_s_kernel (16-pixel tiles, the four waves split the input channels; MT = NT = 1)
+    int cw;                     // 1: conv_w_kernel (convw.hip: 512-thread workgroups, weights resident, every wave stages and multiplies its own pixel tiles)
     int q4;                     // > 0: conv_q_kernel<q4, ...> (4x4x1 MFMA, <= 20 output channels), q4 = 64-pixel sets per wave; MT = 5 blocks of 4 channels, NT = q4
     int MT, NT;                 // 16-channel tiles and 16-pixel tiles per wave (conv_t_kernel<MT, NT, ...>)
     int grid_x, grid_y;
@@ -132,6 +133,7 @@ struct ConvGeomDesc {
     int force_cs;                        // conv_s_kernel for few output pixels: 0 = planner (OCL_CONV_S, default on), 1 = always where it fits, -1 = never
     int force_q4;                        // conv_q_kernel for <= 20 output channels: 0 = planner (OCL_CONV_Q4, default on), 1 = always where it fits, -1 = never
     int force_pipe;                      // staged-weight schedule: 0 = environment (OCL_CONV_PIPE, default on), 1 = ring, -1 = two-buffer
+    int force_cw;                        // conv_w_kernel (wave-autonomous tiles, convw.hip): 0 = planner (OCL_CONV_W), 1 = always where it fits (force_MT / force_NT honoured), -1 = never
     int WPT;                    // row stride of the K-grouped weight pack (0: the plan's own CoutP)
     int xf;                     // reserve LDS for the input-transform table (ConvArgs::xf may then be set at launch)
     int bnb;                    // reserve LDS for the BatchNorm-backward epilogue table (EPI_BNB may then be set at launch)
@@ -170,6 +172,12 @@ void geom_fwd(const ConvShape& c, int N, int groups, ConvGeomDesc* g);
 // groups > 1: the tiles follow the BatchNorm groups of the pass (no tile straddles two groups: the EPI_BNB epilogue sums per group)
 void geom_dgrad(const ConvShape& c, int N, std::vector<ConvGeomDesc>* out, bool merge_classes = false, int groups = 1);
 int launch_conv(const ConvPlan& p, hipStream_t s);
+// conv_w_kernel (convw.hip): its planner (OCL_ERR_ARG: the geometry does not fit the form), its tables, its launch, its per-device set-up
+int plan_conv_w(const ConvGeomDesc& g, ConvPlan* p);
+void conv_w_tables(const ConvPlan& p, std::vector<int>* out);
+int launch_conv_w(const ConvPlan& p, hipStream_t s);
+int convw_kernels_init();
+int convw_set_det(int on);   // this translation unit's copy of the batch-sum mode flag (conv_stats_dev.h)
 
 // ---- wgrad -------------------------------------------------------------------------------------------
 struct WgradArgs {

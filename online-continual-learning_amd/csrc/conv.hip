@@ -11,6 +11,7 @@
 //
 // Replaces the ATen sequences behind models/resnet.py:10-12,32-37,90-99 and their autograd.
 #include "conv_dev.h"
+#include "conv_stats_dev.h"
 #include <string.h>
 #include <algorithm>
 #include <type_traits>
@@ -21,149 +22,6 @@ namespace ocl {
 
 
 
-// ---- batch sums (StatCell, conv.h) ---------------------------------------------------------------------------------------------
-// Two ways to accumulate a cell, chosen at run time (ocl_set_deterministic / OCL_DETERMINISTIC=1, a __constant__ flag):
-//  * default: the cell's first word holds a double and takes fp64 atomics (rounds 1 - 3): totals depend on the workgroups' arrival
-//    order in the last bit;
-//  * deterministic: 2^-40 fixed point added as two 64-bit INTEGERS (associative): bit-identical totals whatever the order.  Costs
-//    two atomics per partial sum instead of one: +12 % on the SCR step, +13 % on ER (profiles/r4_batch_sums_ab.txt) -- which is why
-//    it is a mode and not the default.
-__constant__ int g_det_sums = 0;
-// MODE -1: read the flag at run time; 0 / 1: compiled for the default / deterministic mode only (conv_s_kernel: a 96-register kernel
-// that cannot carry both paths without spilling -- its two instantiations are chosen by the host's copy of the flag)
-template <int MODE>
-__device__ __forceinline__ bool fx_det() { return MODE < 0 ? g_det_sums != 0 : MODE == 1; }
-
-__device__ __forceinline__ void fx_split(double v, long long& hi, unsigned long long& lo) {
-    if (fabs(v) < 7.0e13) {                                   // (false for NaN / Inf as well)
-        const double q = v * 1099511627776.0;                 // v * 2^40: exact
-        const double h = floor(q * (1.0 / 4294967296.0));     // floor(q / 2^32)
-        hi = (long long)h;
-        lo = (unsigned long long)(q - h * 4294967296.0);      // [0, 2^32): truncating it to an integer is the only rounding (< 2^-40)
-    } else {
-        hi = 1ll << 56;                                       // poison: reads back as NaN
-        lo = 0ull;
-    }
-}
-template <int MODE = -1>
-__device__ __forceinline__ void fx_add(StatCell* cell, double v) {
-    if (!fx_det<MODE>()) {
-        atomicAdd((double*)&cell->lo, v);
-        return;
-    }
-    long long hi;
-    unsigned long long lo;
-    fx_split(v, hi, lo);
-    atomicAdd(&cell->lo, lo);
-    atomicAdd((unsigned long long*)&cell->hi, (unsigned long long)hi);
-}
-template <int MODE = -1>
-__device__ __forceinline__ double fx_decode(long long hi, unsigned long long lo) {
-    if (!fx_det<MODE>()) return __longlong_as_double((long long)lo);
-    if (hi >= (1ll << 55) || hi <= -(1ll << 55)) return __builtin_nan("");
-    return (double)hi * (1.0 / 256.0) + (double)lo * (1.0 / 1099511627776.0);
-}
-typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
-// the total of a cell's kStatReps replicas (deterministic mode: integer sums, exact in any order; default: the replicas in a fixed
-// order).  All replicas are requested before any is consumed: left to itself the compiler waited for each 16-byte load before issuing
-// the next -- eight dependent L2 round trips in the prologue of every kernel that reads a statistic.
-// B: replicas in flight at once (4 registers each): 8 by default, 4 in conv_s_kernel's prologue (a 96-register kernel: with all
-// sixteen loads of a (sum, sum of squares) pair in flight it spilled 50 VGPRs to scratch)
-template <int B = kStatReps, int MODE = -1>
-__device__ __forceinline__ double fx_total(const StatCell* __restrict__ cells, int64_t rep_stride, int64_t idx) {
-    static_assert(kStatReps % B == 0, "batch divides the replica count");
-    if (!fx_det<MODE>()) {   // the replicas in a fixed order
-        double t = 0.0;
-#pragma unroll
-        for (int r0 = 0; r0 < kStatReps; r0 += B) {
-            double c[B];
-#pragma unroll
-            for (int r = 0; r < B; ++r) c[r] = *(const double*)&cells[(r0 + r) * rep_stride + idx].lo;
-#pragma unroll
-            for (int r = 0; r < B; ++r) t += c[r];
-        }
-        return t;
-    }
-    long long hi = 0;
-    unsigned long long lo = 0;
-    bool bad = false;
-#pragma unroll
-    for (int r0 = 0; r0 < kStatReps; r0 += B) {
-        u64x2_t c[B];
-#pragma unroll
-        for (int r = 0; r < B; ++r) c[r] = *(const u64x2_t*)(cells + (r0 + r) * rep_stride + idx);
-#pragma unroll
-        for (int r = 0; r < B; ++r) {
-            const long long h = (long long)c[r].y;
-            bad |= h >= (1ll << 55) || h <= -(1ll << 55);
-            hi += h;
-            lo += c[r].x;
-        }
-    }
-    return bad ? __builtin_nan("") : fx_decode<MODE>(hi, lo);
-}
-// two totals at once: all 2 * kStatReps loads in flight together
-__device__ __forceinline__ void fx_total2(const StatCell* __restrict__ cells, int64_t rep_stride, int64_t idx1, int64_t idx2, double& t1, double& t2) {
-    u64x2_t a[kStatReps], b[kStatReps];
-#pragma unroll
-    for (int r = 0; r < kStatReps; ++r) {
-        a[r] = *(const u64x2_t*)(cells + r * rep_stride + idx1);
-        b[r] = *(const u64x2_t*)(cells + r * rep_stride + idx2);
-    }
-    if (!g_det_sums) {
-        double s1 = 0.0, s2 = 0.0;
-#pragma unroll
-        for (int r = 0; r < kStatReps; ++r) {
-            s1 += __longlong_as_double((long long)a[r].x);
-            s2 += __longlong_as_double((long long)b[r].x);
-        }
-        t1 = s1; t2 = s2;
-        return;
-    }
-    long long h1 = 0, h2 = 0;
-    unsigned long long l1 = 0, l2 = 0;
-    bool bad1 = false, bad2 = false;
-#pragma unroll
-    for (int r = 0; r < kStatReps; ++r) {
-        const long long x = (long long)a[r].y, y = (long long)b[r].y;
-        bad1 |= x >= (1ll << 55) || x <= -(1ll << 55);
-        bad2 |= y >= (1ll << 55) || y <= -(1ll << 55);
-        h1 += x; l1 += a[r].x;
-        h2 += y; l2 += b[r].x;
-    }
-    t1 = bad1 ? __builtin_nan("") : fx_decode(h1, l1);
-    t2 = bad2 ? __builtin_nan("") : fx_decode(h2, l2);
-}
-// the same with returning device-scope atomics / device-scope atomic loads (bn_bwd_fused_kernel: the adds must have executed at the
-// coherence point before the wave signals its arrival; the totals are read while other workgroups may still be spinning)
-__device__ __forceinline__ unsigned long long fx_fetch_add(StatCell* cell, double v) {
-    if (!g_det_sums)
-        return (unsigned long long)__double_as_longlong(__hip_atomic_fetch_add((double*)&cell->lo, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    long long hi;
-    unsigned long long lo;
-    fx_split(v, hi, lo);
-    return __hip_atomic_fetch_add(&cell->lo, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) +
-           __hip_atomic_fetch_add((unsigned long long*)&cell->hi, (unsigned long long)hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double fx_total_atomic(const StatCell* cells, int64_t rep_stride, int64_t idx) {
-    if (!g_det_sums) {
-        double t = 0.0;
-        for (int r = 0; r < kStatReps; ++r)
-            t += __hip_atomic_load((const double*)&cells[r * rep_stride + idx].lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return t;
-    }
-    long long hi = 0;
-    unsigned long long lo = 0;
-    bool bad = false;
-    for (int r = 0; r < kStatReps; ++r) {
-        const StatCell* c = cells + r * rep_stride + idx;
-        const long long h = (long long)__hip_atomic_load((const unsigned long long*)&c->hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        bad |= h >= (1ll << 55) || h <= -(1ll << 55);
-        hi += h;
-        lo += __hip_atomic_load(&c->lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    return bad ? __builtin_nan("") : fx_decode(hi, lo);
-}
 // The host's copy of g_det_sums, PER DEVICE (conv_s_kernel's instantiation is chosen by it; the __constant__ lives per device, so a
 // process-wide host flag could disagree with it as soon as a second device is touched: cells written as fixed point and read as doubles)
 static const int kMaxDevices = 64;
@@ -180,74 +38,11 @@ int set_deterministic_sums(int on) {
     OCL_REQUIRE(dev >= 0 && dev < kMaxDevices, "set_deterministic: device %d", dev);
     OCL_HIP(hipDeviceSynchronize());   // (no launch may straddle the switch: the cells are interpreted by the flag)
     OCL_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_det_sums), &v, sizeof(int)));
+    if (int rc = convw_set_det(v)) return rc;   // (convw.hip's copy of the flag)
     g_det_dev[dev] = v;                // the current device only: the mode is a per-device state, like the symbol
     return OCL_OK;
 }
 
-// mean / invstd of (group g, channel c) from the replicated batch sums (biased variance, nn.BatchNorm2d's normalisation)
-template <int B = 2 * kStatReps, int MODE = -1>   // replica loads in flight (see fx_total)
-__device__ __forceinline__ void bn_batch_moments(const StatCell* __restrict__ stats, int64_t rep_stride, int g, int c, int C, double M, float eps,
-                                                 double& mean, double& var) {
-    double s1, s2;
-    if constexpr (B >= 2 * kStatReps) {
-        fx_total2(stats, rep_stride, ((int64_t)g * 2 + 0) * C + c, ((int64_t)g * 2 + 1) * C + c, s1, s2);
-    } else {
-        s1 = fx_total<B, MODE>(stats, rep_stride, ((int64_t)g * 2 + 0) * C + c);
-        s2 = fx_total<B, MODE>(stats, rep_stride, ((int64_t)g * 2 + 1) * C + c);
-    }
-    mean = s1 / M;
-    var = s2 / M - mean * mean;
-    if (var < 0.0) var = 0.0;
-    (void)eps;
-}
-// running statistics: one update per group, in order (= the reference's separate forward calls), unbiased variance, momentum
-template <int MODE = -1>
-__device__ __forceinline__ void bn_running_update(const StatCell* __restrict__ stats, int64_t rep_stride, int G, int C, double M, float momentum,
-                                                  float eps, float* __restrict__ running_mean, float* __restrict__ running_var,
-                                                  int64_t* __restrict__ nbt, int tid, int nthreads) {
-    for (int c = tid; c < C; c += nthreads) {
-        float rm = running_mean[c], rv = running_var[c];
-        for (int gg = 0; gg < G; ++gg) {
-            double mean, var;
-            bn_batch_moments<1, MODE>(stats, rep_stride, gg, c, C, M, eps, mean, var);   // (one workgroup per launch runs this: few loads in flight, few registers)
-            const double unb = M > 1.0 ? var * M / (M - 1.0) : var;
-            rm = momentum * (float)mean + (1.f - momentum) * rm;
-            rv = momentum * (float)unb + (1.f - momentum) * rv;
-        }
-        running_mean[c] = rm;
-        running_var[c] = rv;
-    }
-    if (tid == 0 && nbt) *nbt += G;
-}
-
-// ---- EPI_BNB: the reduction half of a BatchNorm backward in the epilogue of the data gradient that produces its input gradient ------
-// table [groups][Cout/4][3][4]: scale quad, shift quad (the forward's bn_scale_shift: the recomputed ReLU mask has the forward's bits),
-// mean quad
-__device__ __forceinline__ void bnb_table(const ConvArgs& a, float* tab, int tid, int nthreads) {
-    const int C = a.Cout;
-    for (int j = tid; j < a.groups * C; j += nthreads) {
-        const int gq = j / C, c = j - gq * C;
-        const float mean = a.bnb_mean[j];
-        float sc, sh;
-        bn_scale_shift(a.bnb_gamma[c], a.bnb_beta[c], mean, a.bnb_invstd[j], sc, sh);
-        float* t = tab + (size_t)(gq * (C >> 2) + (c >> 2)) * 12 + (c & 3);
-        t[0] = sc;
-        t[4] = sh;
-        t[8] = mean;
-    }
-}
-// one channel quad of one pixel: v = gradient w.r.t. the ReLU'd BatchNorm output (complete); masks it and adds to the lane's partial sums
-__device__ __forceinline__ void bnb_apply(const ConvArgs& a, const float4 sc, const float4 sh, const float4 mu, int64_t eo, float4& v,
-                                          float (&s1)[4], float (&s2)[4]) {
-    const float4 y = *(const float4*)(a.bnb_y + eo);
-    float4 zz;
-    if (a.bnb_z) zz = *(const float4*)(a.bnb_z + eo);
-    else zz = make_float4(__fmaf_rn(y.x, sc.x, sh.x), __fmaf_rn(y.y, sc.y, sh.y), __fmaf_rn(y.z, sc.z, sh.z), __fmaf_rn(y.w, sc.w, sh.w));
-    v.x = zz.x > 0.f ? v.x : 0.f; v.y = zz.y > 0.f ? v.y : 0.f; v.z = zz.z > 0.f ? v.z : 0.f; v.w = zz.w > 0.f ? v.w : 0.f;
-    s1[0] += v.x; s1[1] += v.y; s1[2] += v.z; s1[3] += v.w;
-    s2[0] = fmaf(v.x, y.x - mu.x, s2[0]); s2[1] = fmaf(v.y, y.y - mu.y, s2[1]);
-    s2[2] = fmaf(v.z, y.z - mu.z, s2[2]); s2[3] = fmaf(v.w, y.w - mu.w, s2[3]);
-}
 
 // =====================================================================================================
 // conv_t_kernel: channels x pixels orientation with K-grouped operands
@@ -265,23 +60,9 @@ __device__ __forceinline__ void bnb_apply(const ConvArgs& a, const float4 sc, co
 //    stream through a double-buffered stage of QS groups, fetched one stage ahead into registers.
 //  * BatchNorm statistics: fp32 per-lane partials over the workgroup's tiles, fp64 from the cross-lane reduction on, flushed with
 //    one fp64 atomic per channel per workgroup (8 replicas, as above).
-// x / d for a plan constant d through its precomputed M = ceil(2^32 / d): exact for x * d < 2^32 (checked by the planner)
-__device__ __forceinline__ int mdiv(int x, unsigned M, int d, int& rem) {
-    const int q = d == 1 ? x : (int)__umulhi((unsigned)x, M);
-    rem = x - q * d;
-    return q;
-}
 constexpr int kWPF = 4;                        // float4 weight-prefetch registers per thread (staged weights)
 constexpr size_t kResidentBytes = 80 * 1024;   // weights of one channel split kept in LDS for the workgroup's lifetime up to this
 
-// sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15), result in every lane: four v_add_f32 with DPP operands, no LDS traffic
-__device__ __forceinline__ float row16_sum(float v) {
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));    // quad_perm [1,0,3,2]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));    // quad_perm [2,3,0,1]
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xf, 0xf, true));   // row_half_mirror
-    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xf, 0xf, true));   // row_mirror
-    return v;
-}
 constexpr int kMaxWgTiles = 64;                // tile descriptors a workgroup keeps in LDS
 
 // PIPE variant of the staged-weight path (the default since round 3; OCL_CONV_PIPE=0 / ConvGeomDesc::force_pipe = -1 select the
@@ -1879,6 +1660,25 @@ static int plan_conv_s(const ConvGeomDesc& g, ConvPlan* p) {
 static int plan_conv_t(const ConvGeomDesc& g, ConvPlan* p) {
     ConvArgs& a = p->a;
     p->cs = 0;
+    p->cw = 0;
+    {   // wave-autonomous tiles over resident weights (convw.hip): no workgroup barrier between the prologue and the statistics flush
+        // OCL_CONV_W: 0 = never, 1 (default) = where its specialised form exists and measured faster (profiles/r6_convw_vs_planner.txt: the 3x3
+        // stride-1 convolutions of 40 and 80 channels from ~100 images on), 2 = wherever it fits (A/B reference of tests/test_gpu_ring.py)
+        static const int env_cw = [] { const char* e = getenv("OCL_CONV_W"); return e ? atoi(e) : 1; }();
+        if (g.force_cw > 0 || (g.force_cw == 0 && env_cw > 0 && !g.force_MT && !g.force_NT && g.force_cs <= 0 && g.force_q4 <= 0)) {
+            ConvPlan q = *p;
+            if (plan_conv_w(g, &q) == OCL_OK) {
+                const int64_t units = (int64_t)(g.N / q.a.imgs) * q.a.tiles_per_img * q.a.n_splits;   // (pixel tile, channel split) units of the launch
+                // (not with the input transform: conv_wx_kernel's register pipeline for it is slower than conv_t_kernel's staging -- 33.7 vs 33.3 us
+                // on layer 2, 196 us on layer 3: profiles/r6_convw_in_network.txt)
+                const bool hot = q.cw == 2 && !g.xf && g.ntaps == 9 && g.is == 1 && (g.Cout == 40 || g.Cout == 80) && g.Cin == g.Cout && units >= 2048;
+                if (g.force_cw > 0 || env_cw >= 2 || hot) {
+                    *p = q;
+                    return OCL_OK;
+                }
+            }
+        }
+    }
     {   // few output pixels behind a deep K (layers 3 - 4 of a replay-sized pass): K split over the waves
         static const bool env_cs = [] { const char* e = getenv("OCL_CONV_S"); return !(e && atoi(e) == 0); }();
         if (g.force_cs > 0 || (g.force_cs == 0 && env_cs && !g.force_MT && !g.force_NT)) {
@@ -1990,6 +1790,10 @@ static int plan_conv_t(const ConvGeomDesc& g, ConvPlan* p) {
 
 // ---- the plan's tables: every value the kernel's prologue used to compute per workgroup and per launch -------------------------
 void conv_plan_tables(const ConvPlan& p, std::vector<int>* out) {
+    if (p.cw) {
+        conv_w_tables(p, out);
+        return;
+    }
     const ConvArgs& a = p.a;
     const int NT = p.NT, MT = p.MT;
     (void)MT;
@@ -2275,6 +2079,7 @@ static conv_fn_t convq_fn(int ntq, int pf, int stats) {   // stats: 0 none, 1 EP
 }
 
 int launch_conv(const ConvPlan& p, hipStream_t s) {
+    if (p.cw) return launch_conv_w(p, s);
     if (p.cs) {
         if (!p.a.blob) {
             set_error("launch_conv: plan without device tables (conv_plan_finalize)");
@@ -3178,6 +2983,7 @@ int conv_kernels_init() {
         }
     }
     if (int rc = wgrad_kernels_init()) return rc;
+    if (int rc = convw_kernels_init()) return rc;
     for (int m = 1; m <= 5; ++m)
         for (int n = 1; n <= 2; ++n)
             for (int pf = 4; pf <= 8; pf += 4)

@@ -203,15 +203,18 @@ static void bench_geom(const char* lname, const char* kind, ConvGeomDesc g, cons
         CK(hipMalloc(&stats2, kStatReps * 8 * 2 * 1024 * sizeof(StatCell)));
         for (int mt = 0; mt <= (sweep ? 5 : 0); ++mt)
             for (int nt = (mt ? 1 : 0); nt <= (mt ? 2 : 0); ++nt)
-            for (int pipe = 0; pipe < 3; ++pipe) {   // staged-weight plans: the two-buffer schedule, then the three-buffer ring; 2: conv_t_kernel where the planner takes conv_q_kernel
+            for (int pipe = 0; pipe < 4; ++pipe) {   // staged-weight plans: the two-buffer schedule, then the three-buffer ring; 2: conv_t_kernel where the planner takes conv_q_kernel; 3: conv_w_kernel
                 ConvGeomDesc gt = g;
                 gt.force_MT = mt; gt.force_NT = nt;
+                gt.force_cw = pipe == 3 ? 1 : -1;
+                if (pipe == 3 && getenv("KBENCH_NO_CW")) continue;
                 gt.force_pipe = pipe == 1 ? 1 : pipe == 2 ? 0 : -1;   // (the comparison line runs conv_t_kernel's DEFAULT plan, ring included)
                 gt.force_q4 = pipe == 2 ? -1 : 0;
                 gt.force_cs = pipe == 2 ? -1 : 0;
                 ConvPlan pt;
                 if (plan_conv(gt, &pt) != OCL_OK) continue;
                 if (pipe == 1 && !pt.a.pipe) continue;
+                if (pipe == 3 && !pt.cw) continue;
                 if (pipe == 2) {   // only when the default plan is the 4x4x1 form
                     ConvGeomDesc g0 = gt;
                     g0.force_q4 = 0;
@@ -232,10 +235,13 @@ static void bench_geom(const char* lname, const char* kind, ConvGeomDesc g, cons
                     std::vector<StatCell> b(kStatReps * 8 * 2 * 1024);
                     CK(hipMemcpy(b.data(), stats2, b.size() * sizeof(StatCell), hipMemcpyDeviceToHost));
                     for (int i = 0; i < g.groups * 2 * g.Cout; ++i) {
-                        double y = 0;   // (2^-40 fixed point in two integer words: conv.h StatCell)
+                        double y = 0;   // (deterministic mode: 2^-40 fixed point in two integer words; default: a double in the first word -- conv.h StatCell)
+                        static const bool det = [] { const char* e = getenv("OCL_DETERMINISTIC"); return e && e[0] == '1'; }();
                         for (int r = 0; r < kStatReps; ++r) {
                             const StatCell& cell = b[(size_t)r * 8 * 2 * 1024 + i];
-                            y += (double)cell.hi / 256.0 + (double)cell.lo / 1099511627776.0;
+                            double dv;
+                            memcpy(&dv, &cell.lo, 8);
+                            y += det ? (double)cell.hi / 256.0 + (double)cell.lo / 1099511627776.0 : dv;
                         }
                         ds = fmax(ds, fabs(ref_stats[i] - y) / (1.0 + fabs(ref_stats[i])));
                     }
@@ -306,6 +312,53 @@ static void bench_geom(const char* lname, const char* kind, ConvGeomDesc g, cons
                     }
                     CK(hipFree(tr));
                 }
+                if (mt == 0 && pt.cw && getenv("KBENCH_TRACE")) {   // conv_w_kernel: 32 stamps per wave, 4 waves per workgroup
+                    const int nwg = pt.grid_x * pt.grid_y;
+                    unsigned long long* tr;
+                    CK(hipMalloc(&tr, (size_t)nwg * 128 * 8));
+                    CK(hipMemset(tr, 0, (size_t)nwg * 128 * 8));
+                    ConvPlan ptt = pt;
+                    ptt.a.trace = tr;
+                    stats = stats2;
+                    run(ptt, out);
+                    CK(hipMemset(tr, 0, (size_t)nwg * 128 * 8));
+                    run(ptt, out);   // (second launch: warm caches)
+                    stats = keep2;
+                    CK(hipDeviceSynchronize());
+                    std::vector<unsigned long long> h((size_t)nwg * 128);
+                    CK(hipMemcpy(h.data(), tr, h.size() * 8, hipMemcpyDeviceToHost));
+                    unsigned long long t0 = ~0ull, t1 = 0;
+                    for (size_t i = 0; i < h.size(); ++i) if (h[i]) { t0 = std::min(t0, h[i]); t1 = std::max(t1, h[i]); }
+                    double pro[3] = {0, 0, 0}, ph[2] = {0, 0}, tail = 0, life = 0;
+                    long nt_ = 0, nw_ = 0;
+                    for (int w = 0; w < nwg * 4; ++w) {
+                        const unsigned long long* r = &h[(size_t)w * 32];
+                        if (!r[0] || !r[31]) continue;
+                        ++nw_;
+                        for (int k = 0; k < 3; ++k) pro[k] += (double)(r[k + 1] - r[k]);
+                        int e = 4, last = 3;
+                        for (; e + 1 < 31 && r[e + 1]; e += 2) {
+                            ph[0] += (double)(r[e] - r[e - 1]); ph[1] += (double)(r[e + 1] - r[e]);
+                            ++nt_;
+                            last = e + 1;
+                        }
+                        tail += (double)(r[31] - r[last]);
+                        life += (double)(r[31] - r[0]);
+                    }
+                    if (nw_ && nt_)
+                        printf("      trace conv_w: span %llu ticks; %ld waves, %.2f items each | requests %5.0f  tables %5.0f  wait+barrier %5.0f | per item: K loop %6.0f  next request + epilogue %5.0f | flush %5.0f  lifetime %6.0f\n",
+                               t1 - t0, nw_, (double)nt_ / nw_, pro[0] / nw_, pro[1] / nw_, pro[2] / nw_, ph[0] / nt_, ph[1] / nt_, tail / nw_, life / nw_);
+                    for (int wg : {0, nwg / 2}) {
+                        for (int wv : {0, 3}) {
+                            const unsigned long long* r = &h[((size_t)wg * 4 + wv) * 32];
+                            if (pt.cw == 2 && wv == 0 && wg == 0) printf("        (conv_wx: per item four stamps: first third of the K loop (loads), second third, last third (stores), epilogue)\n");
+                            printf("        wg %4d wave %d: +%6llu |", wg, wv, r[0] - t0);
+                            for (int e = 1; e < 31 && r[e]; ++e) printf(" %llu", r[e] - r[e - 1]);
+                            printf(" | end +%llu\n", r[31] - t0);
+                        }
+                    }
+                    CK(hipFree(tr));
+                }
                 if (mt == 0 && pt.q4 == 2 && getenv("KBENCH_TRACE")) {   // conv_q_kernel<2, 12, *>: mean phase lengths over the workgroups (s_memtime ticks)
                     const int nwg = pt.grid_x * pt.grid_y;
                     unsigned long long* tr;
@@ -349,7 +402,7 @@ static void bench_geom(const char* lname, const char* kind, ConvGeomDesc g, cons
                         printf("      trace conv_q: no stamps (not a trace build of this plan)\n");
                     CK(hipFree(tr));
                 }
-                if (mt == 0 && !pt.cs && !pt.q4 && pt.a.wres && getenv("KBENCH_TRACE")) {   // phase timeline of wave 0 of a few workgroups (s_memtime cycles)
+                if (mt == 0 && !pt.cs && !pt.q4 && !pt.cw && pt.a.wres && getenv("KBENCH_TRACE")) {   // phase timeline of wave 0 of a few workgroups (s_memtime cycles)
                     const int nwg = pt.grid_x * pt.grid_y;
                     unsigned long long* tr;
                     CK(hipMalloc(&tr, (size_t)nwg * 64 * 8));
@@ -377,7 +430,7 @@ static void bench_geom(const char* lname, const char* kind, ConvGeomDesc g, cons
                     CK(hipFree(tr));
                 }
                 printf("    conv_%c%s%s MT=%d NT=%d grid=%5dx%d lds=%6zu KC=%3d Q=%3d QS=%3d res=%d  %7.1f us %6.1f TF/s  maxdiff=%.2e statdiff=%.1e%s\n",
-                       pt.cs ? 's' : pt.q4 ? 'q' : 't', mt ? "      " : (pipe == 2 ? " (no-q)" : " (auto)"), pipe == 1 ? " ring" : "     ", pt.MT, pt.NT, pt.grid_x, pt.grid_y, pt.lds_bytes, pt.a.KC, pt.a.Qc, pt.a.QS, pt.a.wres, t,
+                       pt.cw ? 'w' : pt.cs ? 's' : pt.q4 ? 'q' : 't', mt ? "      " : (pipe == 2 ? " (no-q)" : " (auto)"), pipe == 1 ? " ring" : "     ", pt.MT, pt.NT, pt.grid_x, pt.grid_y, pt.lds_bytes, pt.a.KC, pt.a.Qc, pt.a.QS, pt.a.wres, t,
                        flops / t * 1e-6, d, ds, (d > 1e-3 || ds > 1e-3) ? "  <-- MISMATCH" : "");
             }
         CK(hipFree(stats2));
@@ -722,6 +775,72 @@ int main(int argc, char** argv) {
                 // the check must then fail on the 84 x 84 lattices)
                 if (getenv("KBENCH_COVER_SELFTEST") && !p.a.aligned) p.a.aligned = 1;
                 const ConvArgs& a = p.a;
+                if (p.cw) {   // conv_w_kernel / conv_wx_kernel: the wave tiles' geometry is arithmetic (decode), the lane -> pixel map and the staging units are tables
+                    const int NTw = p.NT, T = (a.N / a.imgs) * a.tiles_per_img, SL = a.CP / 4, kc4 = a.KC / 4;
+                    const int* qoffw = b.data() + 16;
+                    const int* uw = b.data() + a.off_pu;
+                    const int* lcw = b.data() + a.off_loc;
+                    std::vector<unsigned char> hitw((size_t)a.N * a.Hout * a.Wout, 0);
+                    int errs = 0;
+                    auto failw = [&](const char* what, int tile, int r) {
+                        if (errs++ < 3) printf("  COVER %s conv_w geom %zu: %s (tile %d, pixel %d)\n", l.name.c_str(), gi, what, tile, r);
+                    };
+                    const int64_t in_bytes = (int64_t)a.N * a.Hin * a.Win * a.Cin * 4;
+                    for (int t = 0; t < T; ++t) {
+                        const int ti = t / a.tiles_per_img, tp = t % a.tiles_per_img;
+                        const int img0 = ti * a.imgs, p0 = tp * a.ppi;
+                        const int ly0 = p0 / a.LW, lx0 = p0 % a.LW;
+                        const int iy0 = ly0 * a.is + a.min_dy, ix0 = lx0 * a.is + a.min_dx;
+                        const int64_t in_base = ((((int64_t)img0 * a.Hin + iy0) * a.Win + ix0) * a.Cin) * 4;
+                        const int obase = ((img0 * a.Hout + ly0 * a.os + a.oy0) * a.Wout + lx0 * a.os + a.ox0) * a.Cout;
+                        const int nimg = std::min(a.imgs, a.N - img0);
+                        if (img0 / a.group_size != (img0 + nimg - 1) / a.group_size) failw("tile straddles two BatchNorm groups", t, 0);
+                        for (int r = 0; r < 16 * NTw; ++r) {
+                            const int nt = r / 16, r16 = r % 16;
+                            const int lp = lcw[(3 * nt + 0) * 16 + r16], lo = lcw[(3 * nt + 1) * 16 + r16], il = lcw[(3 * nt + 2) * 16 + r16];
+                            if (il >= nimg) continue;
+                            const int o = obase + lo;
+                            if (o % a.Cout || o < 0 || o / a.Cout >= (int)hitw.size()) { failw("output offset outside the tensor", t, r); continue; }
+                            if (hitw[o / a.Cout]++) failw("output pixel written twice", t, r);
+                            for (int q = 0; q < a.Qpad; ++q)
+                                if (lp + qoffw[q] < 0 || lp + qoffw[q] + 4 > a.patch_floats) { failw("operand read outside the patch", t, r); break; }
+                            // every tap of the pixel must read the unit the staging table puts there: patch slot -> (image, row, column, quad)
+                            for (int tq = 0; tq < a.ntaps && errs < 3; ++tq) {
+                                const int slot = (lp + a.tpo[tq]) / 4;                       // 16-byte slot of channel quad 0 of the tap
+                                const int pix = slot / SL, pc = pix % a.PC, row = pix / a.PC, pr = row % a.PR, ilp = row / a.PR;
+                                const int ly = (r % a.ppi) / a.LW + ly0, lx = (r % a.ppi) % a.LW + lx0;
+                                const int want_y = ly * a.is + a.tdy[tq] - iy0, want_x = lx * a.is + a.tdx[tq] - ix0;
+                                if (slot % SL || ilp != il || pr != want_y || pc != want_x) { failw("tap reads the wrong patch slot", t, r); break; }
+                            }
+                        }
+                        if (t % std::max(1, T / 64) == 0)
+                            for (int u = 0; u < a.nstage * 64; ++u) {
+                                const int w = uw[u];
+                                if (w < 0) continue;
+                                const int upr = (w >> 19) & 15, upc = (w >> 23) & 63, uil = (w >> 29) & 3, c4 = (w >> 13) & 63;
+                                const int s_ = u % SL, pix = u / SL;
+                                if (s_ != c4 || c4 >= kc4 || pix % a.PC != upc || (pix / a.PC) % a.PR != upr || (pix / a.PC) / a.PR != uil) { failw("staging unit does not sit at its patch slot", t, u); break; }
+                                if ((unsigned)(iy0 + upr) >= (unsigned)a.Hin || (unsigned)(ix0 + upc) >= (unsigned)a.Win || uil >= nimg) continue;
+                                for (int ch = 0; ch < a.Cin / a.KC; ++ch) {
+                                    const int64_t addr = in_base + (int64_t)ch * a.KC * 4 + ((int64_t)(w & 0x1fff) << 4);
+                                    const int64_t want = (((int64_t)(img0 + uil) * a.Hin + iy0 + upr) * a.Win + ix0 + upc) * a.Cin * 4 + ch * a.KC * 4 + c4 * 16;
+                                    if (addr != want || addr < 0 || addr + 16 > in_bytes) { failw("staging unit loads the wrong bytes", t, u); break; }
+                                }
+                            }
+                    }
+                    size_t want = 0, got = 0;
+                    for (int n = 0; n < a.N; ++n)
+                        for (int ly = 0; ly < a.LH; ++ly)
+                            for (int lx = 0; lx < a.LW; ++lx) {
+                                const size_t o = ((size_t)n * a.Hout + ly * a.os + a.oy0) * a.Wout + lx * a.os + a.ox0;
+                                ++want;
+                                if (o < hitw.size() && hitw[o] == 1) ++got;
+                            }
+                    if (got != want) failw("lattice pixels missing", -1, (int)(want - got));
+                    bad += errs ? 1 : 0;
+                    ++checked;
+                    continue;
+                }
                 const int ncls = a.cls_pack & 15, NT = p.NT;
                 const int ntiles = a.groups * a.tiles_per_group, LP = a.LH * a.LW;
                 const int tile_px = p.cs ? 16 * NT : p.q4 ? 256 * NT : 64 * NT;

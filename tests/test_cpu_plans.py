@@ -93,6 +93,15 @@ def test_every_plan_covers_its_output_exactly_once(n, groups, hw):
     assert r.returncode == 0 and " 0 with errors" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("n,groups,hw", [(7, 1, 32), (20, 2, 32), (128, 2, 32), (220, 2, 32), (410, 1, 32), (15, 1, 84)])
+def test_conv_w_plans_cover_their_output_exactly_once(n, groups, hw):
+    """The same replay for conv_w_kernel / conv_wx_kernel (csrc/convw.hip) wherever their planner accepts a geometry (OCL_CONV_W=2; the
+    product takes them only for the hot 3x3 layers of large passes): the wave tiles' arithmetic geometry, the lane -> pixel table, every
+    tap's patch slot against the staging table, the staged bytes against the input tensor, chunked and unchunked."""
+    r = subprocess.run([KBENCH, str(n), str(groups), str(hw), "cover"], capture_output=True, text=True, timeout=300, env=dict(os.environ, OCL_CONV_W="2"))
+    assert r.returncode == 0 and " 0 with errors" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_the_coverage_check_detects_a_wrong_pixel_map():
     """Self-test of the checker: unaligned plans read as aligned must fail it."""
     env = dict(os.environ, KBENCH_COVER_SELFTEST="1")

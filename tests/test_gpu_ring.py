@@ -72,8 +72,10 @@ sys.path.insert(0, %(root)r)
 import ocl_amd
 from ocl_amd.setup_elements import setup_architecture
 out = {}
-for agent, data, head, n, groups in [("ER", "cifar100", None, 20, 1), ("SCR", "cifar100", "mlp", 20, 2), ("ER", "cifar100", None, 7, 1),
-                                     ("SCR", "cifar100", "mlp", 50, 2), ("ER", "mini_imagenet", None, 6, 1)]:
+import json, os
+cases = json.loads(os.environ["OCL_TEST_CASES"]) if os.environ.get("OCL_TEST_CASES") else \
+    [("ER", "cifar100", None, 20, 1), ("SCR", "cifar100", "mlp", 20, 2), ("ER", "cifar100", None, 7, 1), ("SCR", "cifar100", "mlp", 50, 2), ("ER", "mini_imagenet", None, 6, 1)]
+for agent, data, head, n, groups in cases:
     torch.manual_seed(5)
     m = setup_architecture(SimpleNamespace(agent=agent, data=data, head=head))
     m.max_batch = max(64, n)
@@ -127,6 +129,32 @@ def test_conv_s_kernel_matches_conv_t_kernel_on_the_whole_network(tmp_path):
         print(tag, "worst", worst, "median %.2e; gradient tensors off by more than 2e-4: %d of %d" % (med, n_off, len(grad)))
         assert max(fwd.values()) < 2e-4, max(fwd.items(), key=lambda kv: kv[1])
         # (a flip also reaches every tensor upstream of it: one flipped case = up to 60 tensors)
+        assert med < 1e-5 and n_off <= 0.25 * len(grad) and worst[1] < 0.1, worst
+
+
+def test_conv_w_kernel_matches_conv_t_kernel_on_the_whole_network(tmp_path):
+    """conv_w_kernel / conv_wx_kernel (csrc/convw.hip: one wave per SIMD, wave-private double-buffered patches) wherever their planner accepts
+    a geometry (OCL_CONV_W=2: every variant runs -- plain, EPI_BNB, input transform, channel chunks, the generic and the specialised
+    kernels) and as the product plans them (OCL_CONV_W=1) against OCL_CONV_W=0.  Same MFMAs per accumulator in the same K order; the
+    BatchNorm batch sums are added in another order (per wave, then per workgroup), so activations differ in the last bit and a ReLU whose
+    input sits within round-off of zero may flip: same bars as the conv_s_kernel test above."""
+    import json
+    import numpy as np
+    # (the product takes conv_w_kernel from ~130 images on: the SCR step's 220 views and a 160-image pass join the small cases)
+    cases = json.dumps([("SCR", "cifar100", "mlp", 220, 2), ("ER", "cifar100", None, 160, 1), ("ER", "cifar100", None, 20, 1), ("SCR", "cifar100", "mlp", 50, 2),
+                        ("ER", "cifar100", None, 7, 1)])
+    ref = _run_s(tmp_path, "w0", OCL_CONV_W="0", OCL_TEST_CASES=cases)
+    for tag, env in (("w2", dict(OCL_CONV_W="2")), ("w1", dict(OCL_CONV_W="1"))):
+        got = _run_s(tmp_path, tag, OCL_TEST_CASES=cases, **env)
+        assert got.keys() == ref.keys() and len(ref) > 100
+        errs = {k: float(np.abs(got[k] - ref[k]).max() / (1e-12 + np.abs(ref[k]).max())) for k in ref}
+        fwd = {k: e for k, e in errs.items() if k.endswith((":y", ":eval"))}
+        grad = {k: e for k, e in errs.items() if k not in fwd}
+        worst = max(errs.items(), key=lambda kv: kv[1])
+        n_off = sum(e > 2e-4 for e in grad.values())
+        med = float(np.median(list(grad.values())))
+        print(tag, "worst", worst, "median %.2e; gradient tensors off by more than 2e-4: %d of %d" % (med, n_off, len(grad)))
+        assert max(fwd.values()) < 2e-4, max(fwd.items(), key=lambda kv: kv[1])
         assert med < 1e-5 and n_off <= 0.25 * len(grad) and worst[1] < 0.1, worst
 
 
