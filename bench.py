@@ -421,7 +421,7 @@ def accuracy_leg(args, rank, world, local):
             # the paper's SCR setting (config_CVPR/agent/scr/scr_5k.yml:9-10: temp 0.1 + review trick), product augmentation
             variants.append(("paper_setting", False, dict(temp=0.1, trick=dict(make_params({}).trick, review_trick=True))))
         for tag, identity, over in variants:
-            runs, t_train, wall = [], 0.0, 0.0
+            runs, t_train, wall, ev_ms = [], 0.0, 0.0, []
             for seed in seeds:
                 tasks, tests = accuracy_stream(seed, c["n_tasks"], c["classes_per_task"], c["n_train"], c["n_test"], c["blend"], kind=kind)
                 params = make_params(dict(WORKLOADS["scr"], num_tasks=c["n_tasks"], **over))
@@ -430,9 +430,10 @@ def accuracy_leg(args, rank, world, local):
                     scr_mod.ScrAugment.__call__ = lambda self, x: x
                 try:
                     t0 = time.perf_counter()
-                    acc, tt, n_img, _ = single_run(params, tasks, tests, seed)
+                    acc, tt, n_img, ag = single_run(params, tasks, tests, seed)
                     wall += time.perf_counter() - t0
                     t_train += tt
+                    ev_ms += [1e3 * t for t in ag.evaluate_seconds]
                 finally:
                     scr_mod.ScrAugment.__call__ = orig
                 runs.append(acc)
@@ -441,7 +442,26 @@ def accuracy_leg(args, rank, world, local):
                 accs, _ = odist.gather_runs(runs[0], device=device)
             res[tag] = dict(summarise_accuracy(accs), runs=int(accs.shape[0]), wall_s=wall,
                             end_acc_per_run=[float(a[-1].mean()) for a in accs])   # (per-run values feed the summary, then leave the line)
+            if tag == "hip":   # evaluate() after every task: NCM over the memory + every test set seen so far
+                res[tag]["evaluate_ms"] = dict(mean=float(np.mean(ev_ms)), last_task=float(np.mean(ev_ms[c["n_tasks"] - 1::c["n_tasks"]])))
         out[kind] = res
+    # BASELINE configs[2] (ER + ASER retrieve / update, softmax classifier, no augmentation on either side): the texture stream, same seeds as
+    # the oracle's runs
+    runs, ev_ms, wall = [], [], 0.0
+    for seed in seeds:
+        tasks, tests = accuracy_stream(seed, c["n_tasks"], c["classes_per_task"], c["n_train"], c["n_test"], c["blend"], kind="texture_prototype")
+        params = make_params(dict(WORKLOADS["aser"], num_tasks=c["n_tasks"]))
+        t0 = time.perf_counter()
+        acc, tt, n_img, ag = single_run(params, tasks, tests, seed)
+        wall += time.perf_counter() - t0
+        ev_ms += [1e3 * t for t in ag.evaluate_seconds]
+        runs.append(acc)
+    accs = np.stack(runs)
+    if world > 1:
+        accs, _ = odist.gather_runs(runs[0], device=device)
+    out["aser"] = dict(hip=dict(summarise_accuracy(accs), runs=int(accs.shape[0]), wall_s=wall, end_acc_per_run=[float(a[-1].mean()) for a in accs],
+                                evaluate_ms=dict(mean=float(np.mean(ev_ms)), last_task=float(np.mean(ev_ms[c["n_tasks"] - 1::c["n_tasks"]])))),
+                       stream="texture_prototype", config="BASELINE.json configs[2]: ER, retrieve ASER, update ASER, mem_size 5000, k 3, n_smp_cls 1.5, softmax classifier")
     out["stream"] = ("%d tasks x %d classes, %d train / %d test images per class; SCR random/random, mem_size 5000, eps_mem_batch 100, temp 0.07, "
                      "NCM classifier; %d runs, seeds = --seed + rank + 100 * run; noise_prototype: class prototype (white noise) blended %.0f%% "
                      "with white noise; smooth_prototype: smooth 4x4-grid prototype, 30%% + 70%% smooth per-image field + pixel noise; "
@@ -451,13 +471,13 @@ def accuracy_leg(args, rank, world, local):
     return out, seeds
 
 
-def accuracy_oracle_worker(seed, kind, threads):
+def accuracy_oracle_worker(seed, kind, threads, workload="scr"):
     """One run of the CPU oracle (identity augmentation) on the stream of (seed, kind); prints the [T, T] accuracy array as JSON."""
     from oracle import ocl_oracle as O
     import random
     c = ACC_CFG
     tasks, tests = accuracy_stream(seed, c["n_tasks"], c["classes_per_task"], c["n_train"], c["n_test"], c["blend"], kind=kind)
-    cfg = dict(WORKLOADS["scr"], seed=seed, tasks=[[0]] * c["n_tasks"], n_train=0, n_test=0)
+    cfg = dict(WORKLOADS[workload], seed=seed, tasks=[[0]] * c["n_tasks"], n_train=0, n_test=0)
     np.random.seed(seed)
     random.seed(seed)
     torch.manual_seed(seed)
@@ -486,6 +506,11 @@ def accuracy_oracle_start(seeds, threads):
     procs = {(k, s): subprocess.Popen([sys.executable, os.path.abspath(__file__), "--oracle-accuracy-worker", str(s), k, str(threads)],
                                       stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=dict(os.environ, OMP_NUM_THREADS=str(threads)))
              for k in ACC_STREAMS for s in todo[k]}
+    # ER + ASER (configs[2]) on the texture stream, every seed: three more concurrent runs
+    todo["aser"] = list(seeds)
+    for s in seeds:
+        procs[("aser", s)] = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--oracle-accuracy-worker", str(s), "texture_prototype", str(threads), "aser"],
+                                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=dict(os.environ, OMP_NUM_THREADS=str(threads)))
     return procs, todo, t0, threads
 
 
@@ -493,7 +518,7 @@ def accuracy_oracle_finish(handle):
     procs, todo, t0, threads = handle
     res = {k: json.loads(p.communicate()[0].strip().splitlines()[-1]) for k, p in procs.items()}
     out = {}
-    for kind in ACC_STREAMS:
+    for kind in ACC_STREAMS + ("aser",):
         accs = np.array([res[(kind, s)]["acc"] for s in todo[kind]])
         out[kind] = dict(summarise_accuracy(accs), runs=len(todo[kind]), seeds=todo[kind], end_acc_per_run=[float(a[-1].mean()) for a in accs],
                          run_wall_s=[res[(kind, s)]["wall_s"] for s in todo[kind]])
@@ -542,7 +567,8 @@ def cpu_leg(args):
     torch.set_num_threads(default_threads)
     return dict(value=n_timed * 10 / dt, unit="stream images/s", cores=best, kind="port",
                 sample="%d iterations of the %s step (oracle restatement: torch-CPU ATen ops, the reference's own backend) "
-                       "with the replay buffer full, %.1f s at %d intra-op threads (probed %s ms/step)"
+                       "with the replay buffer full, %.1f s at %d intra-op threads (probed %s ms/step); port vs the reference's own agents on the "
+                       "same 8 cores, alternating bursts: SCR 0.92x, ASER 1.08x of the reference's ms/step (profiles/r6_cpu_port_vs_reference.txt)"
                        % (n_timed, args.workload.upper(), dt, best, {k: round(v * 1e3) for k, v in probes.items()}),
                 ms_per_step=dt / n_timed * 1e3)
 
@@ -560,7 +586,7 @@ def compact(v, sig=5):
 
 def main():
     if len(sys.argv) >= 5 and sys.argv[1] == "--oracle-accuracy-worker":
-        return accuracy_oracle_worker(int(sys.argv[2]), sys.argv[3], int(sys.argv[4]))
+        return accuracy_oracle_worker(int(sys.argv[2]), sys.argv[3], int(sys.argv[4]), sys.argv[5] if len(sys.argv) > 5 else "scr")
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
@@ -642,6 +668,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": res["elapsed"] / args.steps * 1e3,
+        "ms_per_step_max": max(res["repeats_ms_per_step"]),
         "ms_per_step_repeats": res["repeats_ms_per_step"],
         "timing": "median of %d back-to-back repeats of the timed region (each EXACTLY --steps iterations, barrier + synchronize on both "
                   "sides, max over ranks); every repeat listed in ms_per_step_repeats" % len(res["repeats_ms_per_step"]),
@@ -675,7 +702,7 @@ def main():
                 "metric": "replay-step images/sec (%s)" % names[wl][0],
                 "workload": "BASELINE.json configs[%d]" % names[wl][1],
                 "value": a["total_steps"] * a["bs"] / a["elapsed"], "unit": "stream images/s", "steps": a["steps"],
-                "ms_per_step": a["elapsed"] / a["steps"] * 1e3, "ms_per_step_repeats": a["repeats_ms_per_step"],
+                "ms_per_step": a["elapsed"] / a["steps"] * 1e3, "ms_per_step_max": max(a["repeats_ms_per_step"]), "ms_per_step_repeats": a["repeats_ms_per_step"],
                 "images_through_network_per_step": names[wl][2], "env": {k: a["env"].get(k) for k in ("sclk_mhz", "power_w")},
                 # (same kernel class, peak and unit as the headline's roofline object)
                 "roofline": {k: rf.get(k) for k in ("bound", "achieved", "frac", "frac_of_calibrated", "avg_launch_us", "launches_per_step",
@@ -697,6 +724,15 @@ def main():
                     # the stream on which the augmentation must not hurt: product - identity >= -(the oracle's own spread over the seeds)
                     acc_res[kind]["summary"]["augmentation_not_harmful"] = bool(
                         acc_res[kind]["summary"]["product_minus_identity_augmentation"] >= -spread)
+            if "aser" in acc_res and "aser" in orc:
+                h, o = acc_res["aser"]["hip"], orc["aser"]
+                acc_res["aser"]["cpu_oracle"] = dict(avg_end_acc=o["avg_end_acc"], runs=o["runs"], seeds=o["seeds"])
+                acc_res["aser"]["summary"] = dict(abs_diff_avg_end_acc_vs_oracle=abs(h["avg_end_acc"]["mean"] - o["avg_end_acc"]["mean"]),
+                                                  oracle_spread_over_seeds=(max(o["end_acc_per_run"]) - min(o["end_acc_per_run"])) if o["runs"] > 1 else None)
+                orc.pop("aser", None)
+        if "aser" in acc_res:
+            acc_res["aser"]["hip"].pop("end_acc_per_run", None)
+            acc_res["aser"]["hip"].pop("wall_s", None)
         # the line keeps means / intervals / the summary; per-run values and wall times have done their job
         for kind in ACC_STREAMS:
             for tag, v in acc_res[kind].items():

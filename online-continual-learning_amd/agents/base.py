@@ -41,8 +41,29 @@ class ContinualLearner(torch.nn.Module, metaclass=abc.ABCMeta):
         if getattr(params, 'error_analysis', False):
             raise NotImplementedError("error_analysis is outside the HIP hot path")
 
+    _gc_frozen = False
+
+    @classmethod
+    def _freeze_long_lived_objects(cls):
+        """Once per process, at the first training call: gc.freeze() moves everything alive (the imported packages' ~10^6 containers, the
+        model, the replay memory's bookkeeping) to the collector's permanent generation.  Without it CPython's full (generation 2)
+        collection walks all of them whenever its counters say so -- 105 - 133 ms in the middle of a training loop whose step is 3 ms
+        (profiles/r6_aser_stall_probe.txt: the deterministic '+0.8 ms per step' of every fifth repeat of the ASER bench leg, at the same
+        step of a fixed-seed run, was exactly one such collection).  Reference counting is untouched: frozen objects are still freed when
+        their last reference goes, only cycle detection skips them; collections keep running over everything created afterwards.
+        OCL_GC_FREEZE=0 turns it off."""
+        if cls._gc_frozen:
+            return
+        cls._gc_frozen = True
+        import gc
+        import os
+        if os.environ.get("OCL_GC_FREEZE", "1") != "0":
+            gc.collect()
+            gc.freeze()
+
     def before_train(self, x_train, y_train):
         """agents/base.py:43-50."""
+        self._freeze_long_lived_objects()
         new_labels = list(set(y_train.tolist()))
         self.new_labels += new_labels
         for i, lbl in enumerate(new_labels):

@@ -1917,6 +1917,10 @@ int conv_plan_finalize(ConvPlan* p, PlanArena* arena, hipStream_t s) {
         const size_t cap = std::max<size_t>(8u << 20, bytes);
         void* c = nullptr;
         OCL_HIP(hipMalloc(&c, cap));
+        {
+            static const bool log_plans = [] { const char* e = getenv("OCL_LOG_PLANS"); return e && e[0] == '1'; }();
+            if (log_plans) fprintf(stderr, "[ocl] plan-table arena: chunk %zu allocated (%zu bytes)\n", arena->chunks.size() + 1, cap);
+        }
         arena->chunks.push_back(c);
         arena->used = 0;
         arena->cap = cap;

@@ -2,6 +2,7 @@
 // forward (train / eval) and backward.  Mirrors models/resnet.py:69-116 (ResNet(BasicBlock,[2,2,2,2],nf=20)) and
 // :140-168 (SupConResNet) of the reference; parameters stay in PyTorch's named_parameters() order and OIHW layout.
 #include "conv.h"
+#include <chrono>
 #include <string.h>
 #include <stdlib.h>
 #include <string>
@@ -369,6 +370,19 @@ static int get_plans(ocl_net* n, int N, int groups, PlanSet** out) {
         *out = &it->second;
         return OCL_OK;
     }
+    // OCL_LOG_PLANS=1: one line on stderr per plan set made (host time): what a first-seen batch shape costs a running loop
+    static const bool log_plans = [] { const char* e = getenv("OCL_LOG_PLANS"); return e && e[0] == '1'; }();
+    const auto t_plan0 = std::chrono::steady_clock::now();
+    struct PlanLog {
+        bool on; int N, groups; std::chrono::steady_clock::time_point t0; size_t* count;
+        ~PlanLog() {
+            if (on) fprintf(stderr, "[ocl] plan set %zu made for N=%d groups=%d: %.2f ms host\n", *count, N, groups,
+                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        }
+    };
+    static size_t n_sets = 0;
+    ++n_sets;
+    PlanLog plog{log_plans, N, groups, t_plan0, &n_sets};
     PlanSet ps;
     ps.fwd.resize(n->convs.size());
     ps.dgrad.resize(n->convs.size());

@@ -46,11 +46,13 @@ def barrier():
 
 def gather_runs(acc_array, extra=None, device=None):
     """all_gather of this rank's accuracy array (float64 [T,T]) and optional scalars.
-    Returns (accuracy_array [world,T,T], extras [world,len(extra)]) on every rank."""
+    Returns (accuracy_array [world,T,T], extras [world,len(extra)]) on every rank.
+    (An initialised group is always used, a world of one included: that is how a one-GPU box drives the RCCL branch,
+    tests/nccl_worker.py.)"""
     acc = np.ascontiguousarray(np.asarray(acc_array, dtype=np.float64))
     ex = np.asarray(extra if extra is not None else [], dtype=np.float64).reshape(-1)
     payload = torch.from_numpy(np.concatenate([acc.reshape(-1), ex]))
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return acc[None], ex[None]
     if dist.get_backend() == "nccl":
         payload = payload.to(device or torch.device("cuda", torch.cuda.current_device()))
@@ -64,7 +66,7 @@ def gather_runs(acc_array, extra=None, device=None):
 def gather_scalars(values, device=None):
     """all_gather of a few float64 scalars per rank -> array [world, len(values)] on every rank (bench: per-rank timings)."""
     v = torch.from_numpy(np.asarray(values, dtype=np.float64).reshape(-1))
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return v.numpy()[None]
     if dist.get_backend() == "nccl":
         v = v.to(device or torch.device("cuda", torch.cuda.current_device()))
@@ -75,7 +77,7 @@ def gather_scalars(values, device=None):
 
 def max_over_ranks(value, device=None):
     """MAX-reduce of a scalar (bench timing)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64)
     if dist.get_backend() == "nccl":
@@ -85,7 +87,7 @@ def max_over_ranks(value, device=None):
 
 
 def sum_over_ranks(value, device=None):
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64)
     if dist.get_backend() == "nccl":

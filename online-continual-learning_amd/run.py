@@ -25,6 +25,7 @@ def single_run(params, tasks, tests, seed):
     agent = name_match.agents[params.agent](model, opt, params)
     test_loaders = setup_test_loader(tests, params)
     tmp_acc = []
+    eval_s = []
     t_train = 0.0
     n_img = 0
     for i, (x_train, y_train) in enumerate(tasks):
@@ -33,7 +34,11 @@ def single_run(params, tasks, tests, seed):
         torch.cuda.synchronize()
         t_train += time.perf_counter() - t0
         n_img += (len(y_train) // params.batch) * params.batch
+        t0 = time.perf_counter()
         tmp_acc.append(agent.evaluate(test_loaders))
+        torch.cuda.synchronize()
+        eval_s.append(time.perf_counter() - t0)
+    agent.evaluate_seconds = eval_s      # wall time of evaluate() after every task (the bench line's evaluate_ms)
     return np.array(tmp_acc), t_train, n_img, agent
 
 

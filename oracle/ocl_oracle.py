@@ -130,7 +130,7 @@ def supcon_loss(features_bvd, labels, temperature):
     sim = (z @ z.t()) / temperature                                          # :67-69
     sim = sim - sim.max(dim=1, keepdim=True)[0].detach()                     # :71-72
     a = b * v
-    notself = 1.0 - torch.eye(a, dtype=z.dtype)                              # :77-82
+    notself = 1.0 - torch.eye(a, dtype=z.dtype, device=z.device)             # :77-82
     lab = labels.view(-1, 1)
     pos = (lab == lab.t()).to(z.dtype).repeat(v, v) * notself                # :51,75,83
     logprob = sim - torch.log((torch.exp(sim) * notself).sum(1, keepdim=True))  # :86-87

@@ -585,6 +585,17 @@ def test_sharded_runs_two_processes(cuda):
     assert "SHARDED_OK world=2" in r.stdout, r.stdout[-2000:]
 
 
+def test_rccl_group_of_one_runs_the_exchange(cuda):
+    """The RCCL branch on a one-GPU box: a world-size-1 "nccl" group, gather_runs / max_over_ranks / sum_over_ranks / gather_scalars with
+    device payloads, then run.sharded_runs over it (tests/nccl_worker.py)."""
+    env = dict(os.environ, PYTHONPATH=ROOT, OCL_TEST_PORT="29547")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "nccl_worker.py")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "RCCL_OK world=1 backend=nccl" in r.stdout, r.stdout[-2000:]
+
+
 def test_bench_gpus_2_launches_its_own_ranks(cuda):
     """`python bench.py --gpus 2` with no launcher around it: bench.py re-executes itself under torch.distributed.run with two ranks
     (one per GPU over RCCL; on a one-GPU box both ranks share GPU 0 and the scalars travel over gloo), each rank runs its own
