@@ -217,6 +217,25 @@ struct WgradPlan {
     size_t lds_bytes;
     size_t partial_floats;
 };
+// all layers' weight gradients of a replay-sized pass in one launch (conv_wgrad_multi_kernel)
+constexpr int kMaxWgradMulti = 24;
+struct WgradMultiEntry {
+    WgradArgs a;
+    int variant, grid_x;
+};
+struct WgradMultiArgs {
+    const WgradMultiEntry* tab;     // device table, one entry per layer
+    int n;
+    int start[kMaxWgradMulti + 1];  // first workgroup of each layer
+};
+struct WgradMultiTable {            // the device table + the host copy it was last written from
+    void* dev = nullptr;
+    std::vector<unsigned char> host;
+    int uploads = 0;
+};
+int wgrad_multi_variant(const WgradPlan& p);   // form index inside conv_wgrad_multi_kernel, -1: this plan launches on its own
+int launch_wgrad_multi(const WgradPlan* plans, int n, WgradMultiTable* t, hipStream_t s);
+void wgrad_multi_release(WgradMultiTable* t);
 // xf_groups > 0: reserve LDS for the input-transform table of that many BatchNorm groups
 int plan_wgrad(int N, int Hin, int Win, int Cin, int Ho, int Wo, int Cout, int ksize, int stride, WgradPlan* p, int xf_groups = 0);
 int launch_wgrad(const WgradPlan& p, hipStream_t s);

@@ -10,6 +10,7 @@
 #include <map>
 #include <algorithm>
 #include <tuple>
+#include <array>
 
 using namespace ocl;
 
@@ -75,6 +76,9 @@ struct ocl_net {
     int64_t off_g[5] = {0, 0, 0, 0, 0};
     static const int kDyRing = 6;        // dL/dy buffers handed to the weight-gradient stream (see ocl_net_backward)
     int64_t off_dy[6] = {0, 0, 0, 0, 0, 0};
+    // one dL/dy buffer per layer for replay-sized passes: their weight gradients wait for the end of the backward and leave in one launch
+    static const int kDyKeep = 24;
+    int64_t off_dykeep = 0, dykeep_floats = 0;   // floats per buffer (passes of < kTwoStreamMinBatch images)
     int64_t off_partial = 0, partial_floats = 0;
     int64_t off_stats = 0, stats_doubles = 0, stats_rep_stride = 0;
     int64_t off_bsums = 0, bsums_doubles = 0;
@@ -107,6 +111,7 @@ struct ocl_net {
     float* slotf(int slot) const { return (float*)(ws + slot_base + (int64_t)slot * slot_bytes); }
     float* gbuf(int i) const { return (float*)(ws + off_g[i]); }
     float* dybuf(int i) const { return (float*)(ws + off_dy[i]); }
+    float* dykeep(int i) const { return (float*)(ws + off_dykeep) + (int64_t)i * dykeep_floats; }
     float* partialbuf() const { return (float*)(ws + off_partial); }
     StatCell* statsbuf() const { return (StatCell*)(ws + off_stats); }
     StatCell* bsumsbuf() const { return (StatCell*)(ws + off_bsums); }
@@ -136,6 +141,8 @@ struct ocl_net {
     };
     std::map<GraphKey, GraphSlot> graphs;
     bool capturing = false;
+    // device tables of the merged weight-gradient launches, per (images, groups, tape slot): [form set]
+    std::map<std::tuple<int, int, const float*>, std::array<WgradMultiTable, 2>> wgrad_tables;
 };
 
 // -----------------------------------------------------------------------------------------------------
@@ -188,6 +195,7 @@ static int add_conv(ocl_net* n, const std::string& name, int Cin, int Cout, int 
 
 static int64_t align_up(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
 
+static const int kTwoStreamMinBatch = 48;
 static int build_layout(ocl_net* n) {
     const ocl_net_desc& d = n->d;
     const std::string pre = d.head == 0 ? "" : "encoder.";
@@ -312,6 +320,8 @@ static int build_layout(ocl_net* n) {
     n->gbuf_floats = max_act;
     for (int i = 0; i < 5; ++i) n->off_g[i] = takeb(max_act * 4);
     for (int i = 0; i < ocl_net::kDyRing; ++i) n->off_dy[i] = takeb(max_act * 4);
+    n->dykeep_floats = align_up((max_act + N - 1) / N * std::min<int64_t>(N, kTwoStreamMinBatch - 1), 64);
+    n->off_dykeep = takeb(n->dykeep_floats * 4 * ocl_net::kDyKeep);
     // wgrad partial: worst case over layers for the largest batch
     int64_t pmax = 0;
     for (auto& cv : n->convs) {
@@ -580,7 +590,6 @@ static int head_forward(ocl_net* n, const float* P, float* feat, float* h1, floa
     return rc;
 }
 
-static const int kTwoStreamMinBatch = 48;
 static const int kSideExtraMinBatch = 96;   // projection shortcut / head weight gradients on the side stream from 96 x 32 x 32 input pixels on
 
 static int ensure_side_stream(ocl_net* n) {
@@ -705,6 +714,8 @@ void ocl_net_destroy(ocl_net* net) {
     if (net->ev_fork) (void)hipEventDestroy(net->ev_fork);
     if (net->s2) (void)hipStreamDestroy(net->s2);
     plan_arena_release(&net->plan_arena);   // the plans' device tables
+    for (auto& kv : net->wgrad_tables)
+        for (auto& t : kv.second) wgrad_multi_release(&t);
     delete net;
 }
 
@@ -1070,7 +1081,24 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
     hipStream_t sw = two_streams ? side : s;   // stream of the weight gradients
     n->dy_next = 0;
     for (int i = 0; i < ocl_net::kDyRing; ++i) n->ev_done_pending[i] = false;
+    // one stream (replay-sized batches: bound by the number of dependent launches): every layer writes its slabs into its own region
+    // and ONE launch at the end of the backward reduces them all
+    // (with a side stream too: the small launches of a replay-sized backward leave most of the machine idle, so the weight gradients
+    // run BESIDE the dependent chain there, each layer into its own slab region, and one launch at the end reduces them all)
+    const bool batched = Nc < kTwoStreamMinBatch && ps->batched_reduce && n->dbg_stop < 0;
+    // ... and on one stream the weight gradients themselves wait for the end: every dL/dy stays in its own buffer, and the layers leave in
+    // one launch per form set (conv_wgrad_multi_kernel) in front of the one reduction: 20 launches of the dependent chain -> 1 or 2
+    static const bool env_multi = [] { const char* e = getenv("OCL_WGRAD_MULTI"); return !e || e[0] != '0'; }();
+    int n_dy = 1;
+    for (auto& b : n->blocks) n_dy += b.convs >= 0 ? 3 : 2;
+    const bool defer = env_multi && batched && !two_streams && !n->capturing && n_dy <= ocl_net::kDyKeep &&
+                       (int64_t)Nc * ((n->max_act_floats + n->d.max_batch - 1) / n->d.max_batch) <= n->dykeep_floats;
+    std::vector<WgradPlan> deferred;
     auto take_dy = [&](int* slot_out) -> float* {   // next ring slot; the main stream waits for its previous readers
+        if (defer) {
+            *slot_out = n->dy_next;
+            return n->dykeep(n->dy_next++);
+        }
         const int r = n->dy_next;
         n->dy_next = (r + 1) % ocl_net::kDyRing;
         if (two_streams && n->ev_done_pending[r]) {
@@ -1130,11 +1158,6 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
         a.frozen = frozen ? 1 : 0;
         return launch_bn_bwd(a, s);
     };
-    // one stream (replay-sized batches: bound by the number of dependent launches): every layer writes its slabs into its own region
-    // and ONE launch at the end of the backward reduces them all
-    // (with a side stream too: the small launches of a replay-sized backward leave most of the machine idle, so the weight gradients
-    // run BESIDE the dependent chain there, each layer into its own slab region, and one launch at the end reduces them all)
-    const bool batched = Nc < kTwoStreamMinBatch && ps->batched_reduce && n->dbg_stop < 0;
     WgradReduceMulti rm;
     rm.partial = partial; rm.grads = Gr; rm.accumulate = accumulate; rm.n = 0;
     // Large passes: four layers write their slabs into regions of 12 MB side by side -- plan_wgrad caps a layer's split at that -- and ONE
@@ -1174,6 +1197,11 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
             }
         }
         wp.a.partial = batched ? partial + ps->partial_off[conv_i] : partial;
+        if (defer) {
+            deferred.push_back(wp);
+            wgrad_reduce_layer(wp, ps->partial_off[conv_i], n->tensors[n->convs[conv_i].w_t].off, &rm.L[rm.n++]);
+            return OCL_OK;
+        }
         int r = launch_wgrad(wp, sw);
         if (r) return r;
         if (batched) {
@@ -1336,6 +1364,19 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
         if (wp.a.partial) return OCL_OK;
     }
     if ((rc = wgrad(0, S + n->x4_off + (int64_t)img0 * n->d.in_h * n->d.in_w * 4, gS))) return rc;
+    if (defer) {   // every layer's weight gradient: one launch per form set, the layers without a form in the merged kernel on their own
+        auto& tabs = n->wgrad_tables[std::make_tuple(Nc, G, (const float*)(S + (int64_t)img0))];
+        for (int set = 0; set < 2; ++set) {
+            std::vector<WgradPlan> grp;
+            for (auto& wp : deferred)
+                if (wgrad_multi_variant(wp) >= 0 && wgrad_multi_variant(wp) / 4 == set) grp.push_back(wp);
+            if (grp.size() == 1) rc = launch_wgrad(grp[0], s);
+            else if (!grp.empty()) rc = launch_wgrad_multi(grp.data(), (int)grp.size(), &tabs[set], s);
+            if (rc) return rc;
+        }
+        for (auto& wp : deferred)
+            if (wgrad_multi_variant(wp) < 0 && (rc = launch_wgrad(wp, s))) return rc;
+    }
     if ((batched || grouped) && rm.n > 0 && (rc = launch_wgrad_reduce_multi(rm, s))) return rc;
     return OCL_OK;
 }

@@ -44,8 +44,9 @@ struct WTile {
 // TRACE = 1 (measurement build, kbench `wgradtrace`): s_memtime stamps of thread 0 at the phase boundaries into WgradArgs::trace,
 // 64 slots per workgroup: start | prologue done | per tile: passed barrier 1, tile stored, passed barrier 2, next tile's loads issued,
 // K loop done | ... | slab written.
+// (the body takes its workgroup id from the caller: conv_wgrad_kernel passes blockIdx, conv_wgrad_multi_kernel the id inside its layer)
 template <int MTW, int NTW, int PF, int RGW = 0, int TRACE = 0>
-__global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
+__device__ __forceinline__ void conv_wgrad_body(const WgradArgs& a, const int bid_x, const int bid_y) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     int* pixoff = (int*)lds_raw + 4;                // [KP]   (in front of it: the staging's dummy slot)
     float* dyt = (float*)(pixoff + a.KP);           // [KP][DP]
@@ -61,9 +62,9 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
     // the `by` workgroups that read the SAME pixel tiles get linear ids that agree modulo 8 and lie within 8 * by of each other --
     // workgroup b is observed to run on XCD b % 8, so they share one L2 (4 MB per XCD, not coherent across XCDs) at about the same
     // time, instead of fetching every tile once per output block from memory.  The last S % 8 splits keep the plain order.
-    int bx = blockIdx.x, by = blockIdx.y;
+    int bx = bid_x, by = bid_y;
     if (a.xcd_by > 0) {
-        const int id = blockIdx.x, per = 8 * a.xcd_by, full = (a.S >> 3) * per;
+        const int id = bid_x, per = 8 * a.xcd_by, full = (a.S >> 3) * per;
         if (id < full) {
             const int grp = id / per, rem = id - grp * per;
             by = rem >> 3;
@@ -402,6 +403,42 @@ __global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
         }
     stamp();
 }
+template <int MTW, int NTW, int PF, int RGW = 0, int TRACE = 0>
+__global__ void __launch_bounds__(256) conv_wgrad_kernel(const WgradArgs a) {
+    conv_wgrad_body<MTW, NTW, PF, RGW, TRACE>(a, blockIdx.x, blockIdx.y);
+}
+
+// Every layer's weight gradient of a replay-sized pass in ONE launch (agents/exp_replay.py:36-89: 10 + 10 images per step).  Such a pass is
+// bound by the NUMBER of dependent launches (~7 us each, 130 of them), and its 20 weight-gradient launches depend on nothing but their own
+// layer's input and dL/dy: the backward keeps every dL/dy (ocl_net: one buffer per layer) and launches them together at its end.  The
+// workgroup looks up its layer in the start table, reads that layer's WgradArgs from the device table (uniform address, constant address
+// space: scalar loads, as the kernarg segment of the per-layer launch) and runs the same body: same slabs, same bits.  The forms a small
+// pass plans: 16 x {32, 48} blocks at either prefetch depth, and the two 128-row forms of the 84 x 84 passes.
+typedef const WgradMultiEntry __attribute__((address_space(4))) * WgradTabPtr;
+template <int SET>   // 0: the 16-row forms (3 workgroups per CU by registers), 1: the 32- / 48-row forms
+__global__ void __launch_bounds__(256) conv_wgrad_multi_kernel(const WgradMultiArgs m) {
+    int l = 0;
+    while (l + 1 < m.n && (int)blockIdx.x >= m.start[l + 1]) ++l;
+    const WgradTabPtr e = (WgradTabPtr)m.tab + l;
+    const WgradArgs& a = (const WgradArgs&)e->a;
+    const int id = (int)blockIdx.x - m.start[l];
+    int bx = id, by = 0;
+    if (e->a.xcd_by <= 0) {
+        by = id / e->grid_x;
+        bx = id - by * e->grid_x;
+    }
+    if constexpr (SET == 0) {
+        switch (e->variant) {
+            case 0: conv_wgrad_body<1, 2, 4>(a, bx, by); break;
+            case 1: conv_wgrad_body<1, 2, 8>(a, bx, by); break;
+            case 2: conv_wgrad_body<1, 3, 4>(a, bx, by); break;
+            default: conv_wgrad_body<1, 3, 8>(a, bx, by); break;
+        }
+    } else {
+        if (e->variant == 4) conv_wgrad_body<2, 3, 8>(a, bx, by);
+        else conv_wgrad_body<3, 2, 8>(a, bx, by);
+    }
+}
 
 typedef void (*wgrad_fn_t)(const WgradArgs);
 static wgrad_fn_t wgrad_fn(int M, int N, int PF) {
@@ -700,6 +737,59 @@ int launch_wgrad(const WgradPlan& p, hipStream_t s) {
     return OCL_OK;
 }
 
+int wgrad_multi_variant(const WgradPlan& p) {
+    if (p.q_rgw || p.a.trace) return -1;
+    const int pf = wgrad_pf_for(p.a.imgs * p.a.PR * p.a.PC * (p.a.KC / 4));
+    if (p.MTW == 1 && p.NTW == 2) return pf == 4 ? 0 : 1;
+    if (p.MTW == 1 && p.NTW == 3) return pf == 4 ? 2 : 3;
+    if (p.MTW == 2 && p.NTW == 3 && pf == 8) return 4;
+    if (p.MTW == 3 && p.NTW == 2 && pf == 8) return 5;
+    return -1;
+}
+// (the layers of one call share a form set: wgrad_multi_variant(p) / 4)
+int launch_wgrad_multi(const WgradPlan* plans, int n, WgradMultiTable* t, hipStream_t s) {
+    OCL_REQUIRE(n > 0 && n <= kMaxWgradMulti, "launch_wgrad_multi: %d layers", n);
+    const int set = wgrad_multi_variant(plans[0]) / 4;
+    std::vector<WgradMultiEntry> host((size_t)n);
+    WgradMultiArgs m;
+    memset(&m, 0, sizeof(m));
+    size_t lds = 0;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        memset(&host[i], 0, sizeof(WgradMultiEntry));
+        host[i].a = plans[i].a;
+        host[i].variant = wgrad_multi_variant(plans[i]);
+        host[i].grid_x = plans[i].grid_x;
+        OCL_REQUIRE(host[i].variant >= 0 && host[i].variant / 4 == set, "launch_wgrad_multi: layer %d has no form in this merged kernel (MTW=%d NTW=%d)", i,
+                    plans[i].MTW, plans[i].NTW);
+        m.start[i] = blocks;
+        blocks += plans[i].grid_x * plans[i].grid_y;
+        lds = std::max(lds, plans[i].lds_bytes);
+    }
+    m.start[n] = blocks;
+    m.n = n;
+    // the device table is rewritten only when it changes: in the steady state of a stream every pointer of the pass repeats
+    const size_t bytes = host.size() * sizeof(WgradMultiEntry);
+    if (!t->dev) OCL_HIP(hipMalloc(&t->dev, sizeof(WgradMultiEntry) * kMaxWgradMulti));
+    if (t->host.size() != bytes || memcmp(t->host.data(), host.data(), bytes) != 0) {
+        t->host.assign((const unsigned char*)host.data(), (const unsigned char*)host.data() + bytes);
+        // (pageable source: the runtime stages it before the call returns, so the vector may change under a later call)
+        OCL_HIP(hipMemcpyAsync(t->dev, t->host.data(), bytes, hipMemcpyHostToDevice, s));
+        ++t->uploads;
+    }
+    m.tab = (const WgradMultiEntry*)t->dev;
+    ProfScope ps(PROF_WGRAD, s);
+    if (set == 0) hipLaunchKernelGGL(conv_wgrad_multi_kernel<0>, dim3(blocks), dim3(256), lds, s, m);
+    else hipLaunchKernelGGL(conv_wgrad_multi_kernel<1>, dim3(blocks), dim3(256), lds, s, m);
+    OCL_LAUNCH_CHECK();
+    return OCL_OK;
+}
+void wgrad_multi_release(WgradMultiTable* t) {
+    if (t->dev) (void)hipFree(t->dev);
+    t->dev = nullptr;
+    t->host.clear();
+}
+
 int launch_wgrad_reduce(const WgradPlan& p, float* grad_oihw, int accumulate, hipStream_t s) {
     const WgradArgs& a = p.a;
     const int cin_real = a.Cin == 4 ? 3 : a.Cin;  // the stem's NHWC4 input carries a zero 4th channel
@@ -745,6 +835,8 @@ int wgrad_kernels_init() {
     for (int r = 1; r <= 3; ++r)
         for (int pf = 4; pf <= 8; pf += 4)
             OCL_HIP(hipFuncSetAttribute((const void*)wgrad_q_fn(r, pf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+    OCL_HIP(hipFuncSetAttribute((const void*)conv_wgrad_multi_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
+    OCL_HIP(hipFuncSetAttribute((const void*)conv_wgrad_multi_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     return OCL_OK;
 }
 
