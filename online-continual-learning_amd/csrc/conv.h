@@ -237,7 +237,8 @@ int wgrad_multi_variant(const WgradPlan& p);   // form index inside conv_wgrad_m
 int launch_wgrad_multi(const WgradPlan* plans, int n, WgradMultiTable* t, hipStream_t s);
 void wgrad_multi_release(WgradMultiTable* t);
 // xf_groups > 0: reserve LDS for the input-transform table of that many BatchNorm groups
-int plan_wgrad(int N, int Hin, int Win, int Cin, int Ho, int Wo, int Cout, int ksize, int stride, WgradPlan* p, int xf_groups = 0);
+// wg_target > 0: workgroups the pixel split aims at (default 512: a launch of its own fills the machine)
+int plan_wgrad(int N, int Hin, int Win, int Cin, int Ho, int Wo, int Cout, int ksize, int stride, WgradPlan* p, int xf_groups = 0, int wg_target = 0);
 int launch_wgrad(const WgradPlan& p, hipStream_t s);
 // sums the S partials and writes/accumulates the OIHW gradient
 int launch_wgrad_reduce(const WgradPlan& p, float* grad_oihw, int accumulate, hipStream_t s);

@@ -78,7 +78,7 @@ struct ocl_net {
     int64_t off_dy[6] = {0, 0, 0, 0, 0, 0};
     // one dL/dy buffer per layer for replay-sized passes: their weight gradients wait for the end of the backward and leave in one launch
     static const int kDyKeep = 24;
-    int64_t off_dykeep = 0, dykeep_floats = 0;   // floats per buffer (passes of < kTwoStreamMinBatch images)
+    int64_t off_dykeep = 0, dykeep_floats = 0;   // floats per buffer
     int64_t off_partial = 0, partial_floats = 0;
     int64_t off_stats = 0, stats_doubles = 0, stats_rep_stride = 0;
     int64_t off_bsums = 0, bsums_doubles = 0;
@@ -320,7 +320,7 @@ static int build_layout(ocl_net* n) {
     n->gbuf_floats = max_act;
     for (int i = 0; i < 5; ++i) n->off_g[i] = takeb(max_act * 4);
     for (int i = 0; i < ocl_net::kDyRing; ++i) n->off_dy[i] = takeb(max_act * 4);
-    n->dykeep_floats = align_up((max_act + N - 1) / N * std::min<int64_t>(N, kTwoStreamMinBatch - 1), 64);
+    n->dykeep_floats = align_up(max_act, 64);
     n->off_dykeep = takeb(n->dykeep_floats * 4 * ocl_net::kDyKeep);
     // wgrad partial: worst case over layers for the largest batch
     int64_t pmax = 0;
@@ -439,7 +439,12 @@ static int get_plans(ocl_net* n, int N, int groups, PlanSet** out) {
                 n->pack_need_bwd |= PACK_TD;
             }
         }
-        rc = plan_wgrad(N, c.Hin, c.Win, c.CinT, c.Ho, c.Wo, c.Cout, c.k, c.stride, &ps.wgrad[i], c.xf_src >= 0 ? groups : 0);
+        // (a pass whose weight gradients leave in one launch -- trunk_backward's `defer` -- splits every layer's pixels less)
+        // (96 workgroups per layer: the merged launch 111 -> ~70 us, the 20-image pass 746 -> 706 us, ER 0.818 -> 0.779 ms; 192 / 128 / 64 / 48 / 32:
+        // 0.790 / 0.790 / 0.785 / 0.786 / 0.801 ms -- profiles/r6_wgrad_multi_target.txt; 0 = split as for a launch of its own)
+        static const int env_mt = [] { const char* e = getenv("OCL_WGRAD_MULTI_TARGET"); return e ? atoi(e) : 96; }();
+        const bool merged = env_mt > 0 && N < kTwoStreamMinBatch && (int64_t)N * n->d.in_h * n->d.in_w < (int64_t)kTwoStreamMinBatch * 1024;
+        rc = plan_wgrad(N, c.Hin, c.Win, c.CinT, c.Ho, c.Wo, c.Cout, c.k, c.stride, &ps.wgrad[i], c.xf_src >= 0 ? groups : 0, merged ? env_mt : 0);
         if (rc != OCL_OK) return rc;
         if ((int64_t)ps.wgrad[i].partial_floats > n->partial_floats) {
             set_error("net: wgrad partial workspace too small (%zu > %lld floats)", ps.wgrad[i].partial_floats,
@@ -1091,11 +1096,22 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
     static const bool env_multi = [] { const char* e = getenv("OCL_WGRAD_MULTI"); return !e || e[0] != '0'; }();
     int n_dy = 1;
     for (auto& b : n->blocks) n_dy += b.convs >= 0 ? 3 : 2;
-    const bool defer = env_multi && batched && !two_streams && !n->capturing && n_dy <= ocl_net::kDyKeep &&
-                       (int64_t)Nc * ((n->max_act_floats + n->d.max_batch - 1) / n->d.max_batch) <= n->dykeep_floats;
+    const bool defer = env_multi && batched && !two_streams && !n->capturing && n_dy <= ocl_net::kDyKeep;
+    // Two streams: with one dL/dy buffer per layer as well, the dependent chain never waits for the weight-gradient stream to hand a ring
+    // slot back (and records no event per layer for it) -- OCL_DY_KEEP=0: the ring of kDyRing buffers
+    static const bool env_keep = [] { const char* e = getenv("OCL_DY_KEEP"); return !e || e[0] != '0'; }();
+    const bool keep = defer || (env_keep && two_streams && n_dy <= ocl_net::kDyKeep);
+    // ... and the weight-gradient stream is told about new dL/dy buffers every OCL_WGRAD_FLUSH layers (an event record on the chain's stream +
+    // a wait on the other per hand-over): it lags behind the chain anyway
+    // (SCR's 220 views: ring 2.025 ms, per-layer buffers 2.005, + hand-over every 2 / 3 / 5 / 10 / 21 layers 2.000 / 1.990 / 2.054 / 2.109 /
+    // 2.256 -- the sooner the other stream has work, the more of it hides; MIR's 50 - 60-image passes: 4.614 / 4.545 / 4.603 at 3:
+    // profiles/r6_dy_keep_flush_ab.txt.  Three layers per hand-over from 128 images on.)
+    static const int env_flush = [] { const char* e = getenv("OCL_WGRAD_FLUSH"); return e ? std::max(1, atoi(e)) : 0; }();
+    const int flush_every = env_flush > 0 ? env_flush : (Nc >= 128 ? 3 : 1);
+    const bool coarse = two_streams && keep && flush_every > 1;
     std::vector<WgradPlan> deferred;
     auto take_dy = [&](int* slot_out) -> float* {   // next ring slot; the main stream waits for its previous readers
-        if (defer) {
+        if (keep) {
             *slot_out = n->dy_next;
             return n->dykeep(n->dy_next++);
         }
@@ -1109,10 +1125,10 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
         return n->dybuf(r);
     };
     auto publish = [&]() -> int {   // everything the main stream has written so far is visible to the wgrad stream
-        return two_streams ? side_wait(n, s) : OCL_OK;
+        return two_streams && !coarse ? side_wait(n, s) : OCL_OK;
     };
     auto release = [&](int r) -> int {   // the wgrad stream is done reading ring slot r
-        if (!two_streams) return OCL_OK;
+        if (!two_streams || keep) return OCL_OK;
         OCL_HIP(hipEventRecord(n->ev_done[r], sw));
         n->ev_done_pending[r] = true;
         return OCL_OK;
@@ -1168,7 +1184,13 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
     const bool grouped = !batched && n->dbg_stop < 0 && (int64_t)(group_k + 1) * kGroupRegion <= n->partial_floats * 4;
     const int64_t stem_region = grouped ? (int64_t)group_k * kGroupRegion : (16ll << 20);   // bytes from `partial`
     // xf_conv >= 0: xin is the RAW output of that convolution; its BatchNorm + ReLU is applied while the kernel stages its patches
-    auto wgrad = [&](int conv_i, const float* xin, const float* dy, int xf_conv = -1) -> int {   // on the weight-gradient stream
+    // measurement only (OCL_DEBUG_SKIP_WGRAD=1: the gradients of the convolution weights are NOT computed): the wall time of the dependent
+    // chain alone; step time - that = the weight-gradient time the second stream does not hide (bench.py --exposed-wgrad)
+    static const bool env_skip_wgrad = [] { const char* e = getenv("OCL_DEBUG_SKIP_WGRAD"); return e && e[0] == '1'; }();
+    struct PendingWgrad { int conv_i; const float* xin; const float* dy; int xf_conv; };
+    std::vector<PendingWgrad> pending;
+    auto wgrad_now = [&](int conv_i, const float* xin, const float* dy, int xf_conv = -1) -> int {   // on the weight-gradient stream
+        if (env_skip_wgrad) return OCL_OK;
         WgradPlan wp = ps->wgrad[conv_i];
         wp.a.x = xin;
         wp.a.dy = dy;
@@ -1209,6 +1231,18 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
             return OCL_OK;
         }
         return launch_wgrad_reduce(wp, GT(n->convs[conv_i].w_t), accumulate, sw);
+    };
+    auto flush_pending = [&]() -> int {
+        if (pending.empty()) return OCL_OK;
+        int r = side_wait(n, s);
+        for (size_t i = 0; i < pending.size() && !r; ++i) r = wgrad_now(pending[i].conv_i, pending[i].xin, pending[i].dy, pending[i].xf_conv);
+        pending.clear();
+        return r;
+    };
+    auto wgrad = [&](int conv_i, const float* xin, const float* dy, int xf_conv = -1) -> int {
+        if (!coarse) return wgrad_now(conv_i, xin, dy, xf_conv);
+        pending.push_back({conv_i, xin, dy, xf_conv});
+        return (int)pending.size() >= flush_every ? flush_pending() : OCL_OK;
     };
     auto dgrad = [&](int conv_i, const float* dy, float* dx, const float* res, const float* resmask, int extra_flags,
                      const BnbEpi* be = nullptr) -> int {
@@ -1330,9 +1364,11 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
     // still running there when the chain ends -- with its own slab region (the slabs of one layer stay under 12 MB; the stem's start
     // 16 MB into the buffer), and the join follows it.
     (void)rS;
+    if ((rc = flush_pending())) return rc;
     if (two_streams && batched) {   // replay-sized pass: the stem's weight gradient and the one reduction of all layers on the side stream, then the join
         if ((rc = publish())) return rc;
         if ((rc = wgrad(0, S + n->x4_off + (int64_t)img0 * n->d.in_h * n->d.in_w * 4, gS))) return rc;
+        if ((rc = flush_pending())) return rc;
         if (rm.n > 0 && (rc = launch_wgrad_reduce_multi(rm, sw))) return rc;
         OCL_HIP(hipEventRecord(n->ev_join, sw));
         OCL_HIP(hipStreamWaitEvent(s, n->ev_join, 0));
@@ -1353,7 +1389,7 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
         // below it (plan_wgrad caps a split at 12 MB, but a single slab of a wider net may exceed that)
         for (size_t i = 1; i < ps->wgrad.size(); ++i)
             if ((int64_t)ps->wgrad[i].partial_floats * 4 > (grouped ? kGroupRegion : (16ll << 20))) wp.a.partial = nullptr;
-        if (wp.a.partial) {
+        if (wp.a.partial && !env_skip_wgrad) {
             if ((rc = launch_wgrad(wp, s))) return rc;
             if ((rc = launch_wgrad_reduce(wp, GT(n->convs[0].w_t), accumulate, s))) return rc;
         }

@@ -579,7 +579,7 @@ static int wg_cp(int kc, int stride) {
     }
 }
 
-int plan_wgrad(int N, int Hin, int Win, int Cin, int Ho, int Wo, int Cout, int ksize, int stride, WgradPlan* p, int xf_groups) {
+int plan_wgrad(int N, int Hin, int Win, int Cin, int Ho, int Wo, int Cout, int ksize, int stride, WgradPlan* p, int xf_groups, int wg_target) {
     memset(p, 0, sizeof(*p));
     WgradArgs& a = p->a;
     OCL_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0 && (ksize == 1 || ksize == 3), "plan_wgrad: Cin=%d Cout=%d k=%d", Cin, Cout, ksize);
@@ -613,7 +613,10 @@ int plan_wgrad(int N, int Hin, int Win, int Cin, int Ho, int Wo, int Cout, int k
     bool found = false;
     // largest pixel tile, workgroup target of the pixel split, smallest grid that stops the search (swept in round 4:
     // profiles/r4_kbench_wgrad_planner_sweep.txt, r4_wgrad_knobs_netcheck.txt -- these are the best column)
-    constexpr int env_kp = 128, env_target = 512, env_enough = 384;
+    // (wg_target > 0: the layer shares its launch with the other layers of the pass -- conv_wgrad_multi_kernel -- and need not fill the
+    // machine alone: fewer pixel splits, i.e. fewer slabs to write and to reduce)
+    constexpr int env_kp = 128;
+    const int env_target = wg_target > 0 ? wg_target : 512, env_enough = wg_target > 0 ? std::max(1, wg_target * 3 / 4) : 384;
     for (int pass = 0; pass < 2 && !found; ++pass) {
         for (int KPmax = env_kp; KPmax >= 32 && !found; KPmax /= 2) {
             if (LP >= KPmax) {
@@ -658,7 +661,7 @@ int plan_wgrad(int N, int Hin, int Win, int Cin, int Ho, int Wo, int Cout, int k
     // balance the pixel tiles over the S slices.
     int MTW = 1, bestS = 1;
     int64_t best_blocks = -1;
-    for (int m = std::min(4, cdiv(mtiles, 4)); m >= 1; --m) {
+    for (int m = wg_target > 0 ? 1 : std::min(4, cdiv(mtiles, 4)); m >= 1; --m) {   // (merged launch: the 64-row forms of its kernel)
         if (m * NTW > 20) continue;
         const int mb = cdiv(mtiles, 4 * m);
         const int by = a.nchunks * mb * a.nblocks;

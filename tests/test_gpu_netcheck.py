@@ -54,3 +54,44 @@ def test_4x4x1_weight_gradient_form_changes_only_layer_1_and_only_by_rounding(tm
     differing = re.findall(r"^\s+(\S+)\s+\d+ floats\s+reldiff (\S+)", out, re.M)
     assert sorted(n for n, _ in differing) == ["encoder.layer1.%d.conv%d.weight" % (b, c) for b in (0, 1) for c in (1, 2)], out
     assert all(float(v) < 5e-6 for _, v in differing), out
+
+
+@pytest.mark.parametrize("cfg", [(20, 2, 32, 0), (10, 1, 32, 0), (13, 1, 32, 1)], ids=lambda c: "n%d_g%d_hw%d_head%d" % c)
+def test_merged_weight_gradient_launch_is_bit_identical_to_per_layer_launches(cfg, tmp_path):
+    """conv_wgrad_multi_kernel (every layer of a replay-sized pass in one launch at the end of the backward) runs the per-layer kernel's
+    body on the same slabs: with the same pixel split (OCL_WGRAD_MULTI_TARGET=0) not one bit of any gradient, output or running statistic
+    differs from the per-layer launches (OCL_WGRAD_MULTI=0)."""
+    ref = str(tmp_path / "ref.bin")
+    rc, out = _run(cfg, "write", ref, {"OCL_WGRAD_MULTI": "0", "OCL_WGRAD_MULTI_TARGET": "0"})
+    assert rc == 0, out
+    rc, out = _run(cfg, "compare", ref, {"OCL_WGRAD_MULTI_TARGET": "0"})
+    assert rc == 0, out
+    m = re.search(r"(\d+) of (\d+) tensors differ in some bit", out)
+    assert m and int(m.group(1)) == 0 and int(m.group(2)) >= 60, out
+
+
+@pytest.mark.parametrize("cfg", [(20, 2, 32, 0), (47, 1, 32, 1)], ids=lambda c: "n%d_g%d_hw%d_head%d" % c)
+def test_merged_weight_gradient_launch_at_its_own_pixel_split_differs_by_rounding_only(cfg, tmp_path):
+    """The product's split inside the merged launch (96 workgroups per layer instead of 512) sums the pixel tiles in another order: the
+    convolution weights' gradients may differ by rounding, nothing else may differ at all."""
+    ref = str(tmp_path / "ref.bin")
+    rc, out = _run(cfg, "write", ref, {"OCL_WGRAD_MULTI": "0", "OCL_WGRAD_MULTI_TARGET": "0"})
+    assert rc == 0, out
+    rc, out = _run(cfg, "compare", ref, {})
+    assert rc == 0, out
+    differing = re.findall(r"^\s+(\S+)\s+\d+ floats\s+reldiff (\S+)", out, re.M)
+    assert all(("conv" in n or "shortcut.0" in n) and n.endswith(".weight") for n, _ in differing), out
+    assert all(float(v) < 5e-6 for _, v in differing), out
+
+
+def test_two_stream_backward_with_one_gradient_buffer_per_layer_is_bit_identical_to_the_ring(tmp_path):
+    """SCR's 220-view pass: per-layer dL/dy buffers and a hand-over to the weight-gradient stream every third layer change WHEN kernels run,
+    not what they compute."""
+    cfg = (220, 2, 32, 1)
+    ref = str(tmp_path / "ref.bin")
+    rc, out = _run(cfg, "write", ref, {"OCL_DY_KEEP": "0"})
+    assert rc == 0, out
+    rc, out = _run(cfg, "compare", ref, {})
+    assert rc == 0, out
+    m = re.search(r"(\d+) of (\d+) tensors differ in some bit", out)
+    assert m and int(m.group(1)) == 0, out
