@@ -18,6 +18,8 @@ Prints ONE JSON line on rank 0 (see the task's bench contract) including
                and summarised by experiment/metrics.py's formulas; at N=1 the CPU oracle runs the same stream for comparison.
 """
 import argparse
+import contextlib
+import subprocess
 import json
 import os
 import sys
@@ -226,9 +228,9 @@ def gpu_leg(args, rank, world, local, workload=None, steps=None, warmup=None):
         agent.train_learner(xt_d, yt)          # EXACTLY args.steps iterations (drop_last, len = steps*batch)
         torch.cuda.synchronize()
         t_own = time.perf_counter() - t0       # this rank's own stream (before it waits for the others)
-        env = gpu_env_sample(local)            # clocks / power right after the last step retired (outside this rank's own time: on a host-bound loop the sysfs reads would add to it)
         odist.barrier()
         elapsed = time.perf_counter() - t0
+        env = gpu_env_sample(local)            # clocks / power right after the timed region closed (the sysfs reads are in nobody's time)
         per_rank = odist.gather_scalars([t_own], device)[:, 0]
         elapsed = odist.max_over_ranks(elapsed, device)
         reps.append(dict(elapsed=elapsed, per_rank=[float(t) for t in per_rank], env=env))
@@ -270,7 +272,7 @@ def gpu_leg(args, rank, world, local, workload=None, steps=None, warmup=None):
         g = cls["conv_gemm"]
         wg = cls["conv_wgrad"]
         out["roofline"] = dict(
-            bound="mfma", kernel="conv_t_kernel + conv_q_kernel + conv_s_kernel (implicit-GEMM forward + data-gradient; class PROF_CONV of ocl_prof_*)",
+            bound="mfma", kernel="conv_t_kernel + conv_q_kernel + conv_s_kernel + conv_wx_kernel (implicit-GEMM forward + data-gradient; class PROF_CONV of ocl_prof_*)",
             achieved=(gemm_fl * n_prof / (g["ms"] * 1e-3) / 1e12) if g["ms"] > 0 else None,
             peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
             frac=(gemm_fl * n_prof / (g["ms"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS) if g["ms"] > 0 else None,
@@ -638,6 +640,22 @@ def main():
         if args.workload == "scr" and not args.no_also and world == 1:
             for wl in ("aser", "er", "mir"):
                 also[wl] = gpu_leg(args, rank, world, local, workload=wl, steps=args.also_steps, warmup=10)
+    # weight-gradient time the second stream does not hide: the same timed region in a second process whose engine skips the convolution
+    # weight gradients (OCL_DEBUG_SKIP_WGRAD=1, a timing-only debug switch of csrc/net.hip read once per process): step - chain-only step
+    exposed = None
+    if rank == 0 and world == 1 and "roofline" in res and args.workload == "scr" and not args.single_stream:
+        try:
+            cmd = [sys.executable, os.path.abspath(__file__), "--workload", args.workload, "--steps", str(min(args.steps, 100)), "--warmup", "5", "--repeats", "3",
+                   "--no-roofline", "--no-accuracy", "--no-cpu-baseline", "--no-also", "--seed", str(args.seed)]
+            r = subprocess.run(cmd, env=dict(os.environ, OCL_DEBUG_SKIP_WGRAD="1"), capture_output=True, text=True, timeout=300)
+            d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+            step_ms = res["elapsed"] / args.steps * 1e3
+            exposed = dict(chain_only_ms_per_step=d["ms_per_step"], exposed_ms_per_step=step_ms - d["ms_per_step"],
+                           source="second process with OCL_DEBUG_SKIP_WGRAD=1 (the engine skips conv_wgrad_kernel + its reductions; timing only), same "
+                                  "two-stream schedule, %d steps x 3 repeats" % min(args.steps, 100))
+        except Exception as e:      # (a reported extra: its failure must not take the line with it)
+            exposed = dict(error="%s: %s" % (type(e).__name__, str(e)[:160]))
+        res["roofline"]["wgrad"]["exposed"] = exposed
     cpu_line, oracle_handle = None, None
     if rank == 0 and world == 1:
         with contextlib.redirect_stdout(sys.stderr):

@@ -98,6 +98,7 @@ struct ocl_net {
     bool descs_uploaded = false;
     const float* pack_src = nullptr;   // parameter array the weight-pack arena was last written from (by a forward)
     int pack_have = 0;                 // PACK_* bits of the packs that hold `pack_src`'s weights
+    hipStream_t pack_stream = nullptr; // stream the packs were last written on: a forward elsewhere has no dependency on them
     bool bsums_clean = false;          // the backward's statistics arena was cleared by the last forward's pack launch and not used since
     int pack_need_fwd = 0, pack_need_bwd = 0;   // packs the plans made so far read (forward pack; data-gradient pack once a backward is planned)
 
@@ -948,7 +949,7 @@ int ocl_net_forward_segments(ocl_net* n, const float* const* xs, const int32_t* 
     const int pack_mask = n->pack_need_fwd | ((flags & (OCL_FWD_SAVE_TAPE | OCL_FWD_PACK_ALL | OCL_FWD_SAME_WEIGHTS)) ? n->pack_need_bwd : 0);
     // OCL_FWD_SAME_WEIGHTS: the packs of the previous forward are still those of this array -- no pack launch; a train-mode pass
     // clears its statistics arenas (the pack launch's other job) with one memset over both, an eval-mode pass needs nothing
-    const bool same_weights = (flags & OCL_FWD_SAME_WEIGHTS) && n->pack_src == P && (n->pack_have & pack_mask) == pack_mask;
+    const bool same_weights = (flags & OCL_FWD_SAME_WEIGHTS) && n->pack_src == P && (n->pack_have & pack_mask) == pack_mask && n->pack_stream == s;
 
     float* S = n->slotf(slot);
     float* x4 = S + n->x4_off;
@@ -1036,6 +1037,7 @@ int ocl_net_forward_segments(ocl_net* n, const float* const* xs, const int32_t* 
     // be trusted by the next taped forward -- the bug tests/test_gpu_net.py::test_same_weights_... now pins)
     if (!same_weights) {
         n->pack_have = pack_mask;
+        n->pack_stream = s;
         n->pack_src = P;
     }
     if (rc != OCL_OK) return rc;
@@ -1523,6 +1525,7 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
     if (repack) {
         n->pack_src = P;
         n->pack_have = repack_mask;
+        n->pack_stream = s;
     }
     n->bsums_clean = false;
     return rc;

@@ -213,8 +213,9 @@ def knn_sv(eval_f, eval_y, cand_f, cand_y, k, want_order=False):
     eval_y, cand_y = _i64(eval_y), _i64(cand_y)
     ne, d = eval_f.shape
     nc = cand_f.shape[0]
-    # (every entry of a row is written: the kernel scatters a permutation of the candidates)
-    sv = (torch.empty if ne and nc else torch.zeros)((ne, nc), dtype=torch.float32, device=eval_f.device)
+    # (zeros, not empty: with a NaN distance -- a diverged feature -- the sort may move a padding entry into a row and leave a cell unwritten;
+    # a Shapley value of 0 there, not whatever the allocator held)
+    sv = torch.zeros((ne, nc), dtype=torch.float32, device=eval_f.device)
     order = torch.empty((ne, nc), dtype=torch.int64, device=eval_f.device) if want_order else None
     if ne and nc:
         ffi.check(ffi.lib().ocl_knn_sv(ffi.ptr(eval_f), ffi.ptr(eval_y), ne, ffi.ptr(cand_f), ffi.ptr(cand_y), nc, d, int(k),
