@@ -1,5 +1,5 @@
 """CPU: the hot kernels must not use scratch (a private segment is paid at wave launch: profiles/r3_conv_s_ab.md -- a conv_s_kernel build
-with 10 spilled VGPRs was 1 - 4 us per launch slower than the build before it, with a faster loop).  Compiles conv.hip and wgrad.hip for
+with 10 spilled VGPRs was 1 - 4 us per launch slower than the build before it, with a faster loop).  Compiles conv.hip, wgrad.hip and convw.hip for
 gfx950 with the compiler's resource remarks (no GPU needed; the two files side by side) and reads ScratchSize per kernel."""
 import re
 import shutil
@@ -10,7 +10,7 @@ import pytest
 from conftest import ROOT
 
 HIPCC = "/opt/rocm/bin/hipcc"
-SRCS = [ROOT + "/online-continual-learning_amd/csrc/" + f for f in ("conv.hip", "wgrad.hip")]
+SRCS = [ROOT + "/online-continual-learning_amd/csrc/" + f for f in ("conv.hip", "wgrad.hip", "convw.hip")]
 
 # the kernels a training / eval step launches (templates: the instantiations the planner picks at the BASELINE sizes)
 HOT = [
@@ -24,6 +24,10 @@ HOT = [
     r"conv_wgrad_kernel<1, 2, 8, 0, 0>", r"conv_wgrad_kernel<1, 2, 4, 0, 0>",
     r"conv_wgrad_kernel<1, 5, [48], 0, 0>",       # (80-channel blocks: layers 3 - 4 of passes of 48 images and more)
     r"conv_wgrad_kernel<1, 1, [48], [123], 0>",   # (the 4x4x1 form: layer 1 of the large passes)
+    r"conv_wgrad_multi_kernel<[01]>",             # (every layer of a replay-sized pass in one launch)
+    # the one-wave-per-SIMD forms the planner takes by default (layers 2 - 3, 3x3 stride 1, forward without input transform / data gradient)
+    r"conv_wx_kernel<3, 1, 23, 10, (true|false), false, false>", r"conv_wx_kernel<1, 1, 45, 14, (true|false), false, false>",
+    r"conv_wx_kernel<1, 1, 23, 7, (true|false), false, false>",
     r"bn_fwd_kernel", r"bn_bwd_fused_kernel<\d+, \d>", r"bn_bwd_apply_e_kernel", r"wgrad_reduce_kernel", r"wgrad_reduce_multi_kernel",
 ]
 
