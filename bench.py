@@ -86,7 +86,7 @@ def flops_per_step(workload, hw, n_classes_in_buffer=100):
     return gemm, wgrad
 
 
-PMC_TRAFFIC_FILES = ("r5_scr_pmc_traffic.json", "r4_scr_pmc_traffic.json", "r3_scr_pmc_traffic.json", "r2_scr_pmc_traffic.json")   # newest first: r5 = this tree (scripts/gpu_r5g.sh)
+PMC_TRAFFIC_FILES = ("r6_scr_pmc_traffic.json", "r5_scr_pmc_traffic.json", "r4_scr_pmc_traffic.json", "r3_scr_pmc_traffic.json", "r2_scr_pmc_traffic.json")   # newest first: r5 = this tree (scripts/gpu_r5g.sh)
 
 
 def pmc_traffic(kernel):

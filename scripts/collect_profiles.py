@@ -25,7 +25,15 @@ def main(tag, version, rnd="r3"):
         db = _db(os.path.join(g, "%s_%s" % (tag, sub)), name)
         if db:
             rocpd_stats.main(db, os.path.join(p, "%s_%s_kernel_stats_%s%s.csv" % (rnd, name, version, suffix)))
-    for w in ("scr", "aser", "er", "mir"):
+    # (round 6, scripts/gpu_r6_final.sh: the kernel statistics are written by the call itself; copy them under the round's names)
+    for name in ("scr", "scr_single_stream", "aser_single_stream", "er_single_stream"):
+        src = os.path.join(g, "%s_%s_kernel_stats.csv" % (tag, name))
+        if os.path.isfile(src):
+            w_, _, suffix = name.partition("_")
+            open(os.path.join(p, "%s_%s_kernel_stats_%s%s.csv" % (rnd, w_, version, "_" + suffix if suffix else "")), "w").write(open(src).read())
+    if os.path.isfile(os.path.join(g, "%s_pmc_mfma.txt" % tag)):
+        open(os.path.join(p, "%s_scr_pmc_mfma_%s.txt" % (rnd, version)), "w").write(open(os.path.join(g, "%s_pmc_mfma.txt" % tag)).read())
+    for w in ("scr", "aser", "er", "mir", "default"):
         src = os.path.join(g, "%s_bench_%s.log" % (tag, w))
         if os.path.isfile(src):
             line = [l for l in open(src) if l.startswith("{")][-1]
@@ -46,7 +54,8 @@ def main(tag, version, rnd="r3"):
            "units": "FETCH_SIZE / WRITE_SIZE are KiB; gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts 64 B per 128-B "
                     "request for 16 B/lane streaming reads -> doubled; WRITE_SIZE uncalibrated, taken as is",
            "kernels": {}}
-    for prefix, label in (("conv_t_kernel", "conv_t_kernel"), ("conv_q_kernel", "conv_q_kernel"), ("conv_s_kernel", "conv_s_kernel"), ("conv_wgrad_kernel", "conv_wgrad_kernel"), ("bn_fwd_kernel", "bn_fwd_kernel"), ("bn_bwd_fused", "bn_bwd_fused_kernel"), ("wgrad_reduce", "wgrad_reduce_kernel"),
+    for prefix, label in (("conv_t_kernel", "conv_t_kernel"), ("conv_q_kernel", "conv_q_kernel"), ("conv_s_kernel", "conv_s_kernel"), ("conv_wx_kernel", "conv_wx_kernel"),
+                          ("conv_wgrad_kernel", "conv_wgrad_kernel"), ("conv_wgrad_multi_kernel", "conv_wgrad_multi_kernel"), ("bn_fwd_kernel", "bn_fwd_kernel"), ("bn_bwd_fused", "bn_bwd_fused_kernel"), ("wgrad_reduce", "wgrad_reduce_kernel"),
                           ("bn_bwd_reduce", "bn_bwd_reduce_kernel"), ("bn_bwd_apply_kernel", "bn_bwd_apply_kernel"), ("bn_bwd_apply_e", "bn_bwd_apply_e_kernel"),
                           ("rows_copy16<false>", "rows_copy16_gather")):
         fs, fn = agg("FETCH_SIZE", prefix)
@@ -55,7 +64,7 @@ def main(tag, version, rnd="r3"):
             out["kernels"][label] = dict(launches_profiled=fn, fetch_kib_per_launch=fs / fn, write_kib_per_launch=ws / wn,
                                          hbm_bytes_per_launch=(2 * fs / fn + ws / wn) * 1024)
     # the convolution forward / data-gradient class of the bench's roofline (conv_t_kernel + conv_q_kernel + conv_s_kernel launches together)
-    ks = [out["kernels"][k] for k in ("conv_t_kernel", "conv_q_kernel", "conv_s_kernel") if k in out["kernels"]]
+    ks = [out["kernels"][k] for k in ("conv_t_kernel", "conv_q_kernel", "conv_s_kernel", "conv_wx_kernel") if k in out["kernels"]]
     if ks:
         nl = sum(k["launches_profiled"] for k in ks)
         out["kernels"]["conv_fwd_dgrad"] = dict(launches_profiled=nl, hbm_bytes_per_launch=sum(k["hbm_bytes_per_launch"] * k["launches_profiled"] for k in ks) / nl)
