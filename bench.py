@@ -499,7 +499,6 @@ def accuracy_oracle_start(seeds, threads):
     """The same streams through the CPU oracle (identity augmentation), rank 0 at N = 1 only: one process per (stream kind, seed),
     all at once on the host cores (test infrastructure: the checker, not the thing measured).  Started AFTER every timed GPU leg and
     the cpu_baseline sample, so that the HIP accuracy runs (not timing-critical) overlap the oracle's ~5 minutes."""
-    import subprocess
     t0 = time.perf_counter()
     # every seed of the texture stream (the spread over the seeds is the yardstick for the augmentation comparison on the stream where the
     # augmentation must not hurt), the first seed of the white-noise and smooth streams (the like-for-like check of the identity-
@@ -616,7 +615,6 @@ def main():
         # plain `python bench.py --gpus N`: launch the N ranks ourselves (one process per GPU, the same command the driver uses);
         # rank 0 of the child job prints the JSON line
         import socket
-        import subprocess
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
@@ -631,7 +629,6 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     # every rank (also the single one) goes to the CPUs of its GPU's NUMA node before the first model is built (dist.pin_to_gpu_numa)
     pinned = odist.pin_to_gpu_numa(local, int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
-    import contextlib
     also, acc_res, acc_seeds = {}, None, None
     with contextlib.redirect_stdout(sys.stderr):   # the agents print like the reference ("buffer has N slots"): stdout carries the JSON only
         res = gpu_leg(args, rank, world, local)

@@ -31,8 +31,8 @@ def main(tag, version, rnd="r3"):
         if os.path.isfile(src):
             w_, _, suffix = name.partition("_")
             open(os.path.join(p, "%s_%s_kernel_stats_%s%s.csv" % (rnd, w_, version, "_" + suffix if suffix else "")), "w").write(open(src).read())
-    if os.path.isfile(os.path.join(g, "%s_pmc_mfma.txt" % tag)):
-        open(os.path.join(p, "%s_scr_pmc_mfma_%s.txt" % (rnd, version)), "w").write(open(os.path.join(g, "%s_pmc_mfma.txt" % tag)).read())
+    # (the MFMA-pipe counters: scripts/pmc_mfma.py's table, re-expressed per SIMD / per XCD as in profiles/r5_scr_pmc_mfma.txt, by hand into
+    #  profiles/<round>_scr_pmc_mfma.txt)
     for w in ("scr", "aser", "er", "mir", "default"):
         src = os.path.join(g, "%s_bench_%s.log" % (tag, w))
         if os.path.isfile(src):
