@@ -379,11 +379,6 @@ int launch_avgpool_bwd(const float* dfeat, float* dz, int N, int H, int W, int C
 // F.normalize(dim=1) forward/backward
 int launch_l2norm_fwd(const float* v, float* out, float* norms, int n, int d, hipStream_t s, float* out2 = nullptr);
 int launch_l2norm_bwd(const float* out, const float* norms, const float* dout, float* dv, int n, int d, hipStream_t s);
-// SupConResNet's 'mlp' head in one launch each way (conv.hip: mlp_head_fwd_kernel / mlp_head_bwd_kernel)
-int launch_mlp_head_fwd(const float* x, const float* W0, const float* b0, const float* W2, const float* b2, float* h1, float* h2, float* out,
-                        float* norms, float* out2, int N, int FD, int OD, hipStream_t s);
-int launch_mlp_head_bwd(const float* o, const float* norms, const float* dout, const float* h1, const float* W0, const float* W2, float* dh2,
-                        float* dh1, float* dx, int N, int FD, int OD, hipStream_t s);
 // dx = dy * (a > 0)
 int launch_relu_bwd(const float* dy, const float* a, float* dx, int64_t n, hipStream_t s);
 // out[c] (+)= sum_r m[r][c]

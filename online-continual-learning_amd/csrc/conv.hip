@@ -2925,164 +2925,6 @@ int launch_l2norm_bwd(const float* out, const float* norms, const float* dout, f
     return OCL_OK;
 }
 
-// ---- the projection head of SupConResNet (head = 'mlp': Linear - ReLU - Linear - F.normalize, models/resnet.py:140-168) in one launch each way -------
-// Replaces gemm + gemm + l2norm (forward) and l2norm backward + gemm + ReLU mask + gemm (backward: the dx chain; the two dW / db products keep
-// their kernels, on the weight-gradient stream): 220 rows of 160 features are 11 MFLOP -- five dependent launches of 5 - 9 us each and two
-// cross-stream hand-overs between them were ~60 us of an SCR step's chain.  kHeadRows rows per workgroup; the weights come from L2.
-constexpr int kHeadRows = 2;
-constexpr int kHeadTile = 32;   // weight rows per LDS tile (forward)
-// h1 = relu(x W0^T + b0), h2 = h1 W2^T + b2, out = h2 / max(||h2||, 1e-12); W0 [FD, FD], W2 [OD, FD] row-major (nn.Linear)
-__global__ void __launch_bounds__(256) mlp_head_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W0, const float* __restrict__ b0,
-                                                           const float* __restrict__ W2, const float* __restrict__ b2, float* __restrict__ h1,
-                                                           float* __restrict__ h2, float* __restrict__ out, float* __restrict__ norms,
-                                                           float* __restrict__ out2, int N, int FD, int OD) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    float* xs = (float*)lds_raw;                      // [kHeadRows][FD]
-    float* hs = xs + kHeadRows * FD;                  // [kHeadRows][FD]
-    float* os = hs + kHeadRows * FD;                  // [kHeadRows][OD]
-    float* wt = os + kHeadRows * OD;                  // [kHeadTile][FD + 1]
-    const int tid = threadIdx.x, r0 = blockIdx.x * kHeadRows;
-    const int nr = min(kHeadRows, N - r0);
-    for (int i = tid; i < kHeadRows * FD; i += 256) {
-        const int r = i / FD;
-        xs[i] = r < nr ? x[(int64_t)(r0 + r) * FD + (i - r * FD)] : 0.f;
-    }
-    const int jj = tid >> 3, part = tid & 7;
-    auto layer = [&](const float* __restrict__ W, const float* __restrict__ b, int rows, const float* in, float* outs, float* gout, bool relu) {
-        for (int j0 = 0; j0 < rows; j0 += kHeadTile) {
-            __syncthreads();   // the tile's previous readers (and, the first time, the writers of `in`) are done
-            const int tr = min(kHeadTile, rows - j0);
-            for (int i = tid; i < tr * FD; i += 256) {
-                const int rr = i / FD;
-                wt[rr * (FD + 1) + (i - rr * FD)] = W[(int64_t)j0 * FD + i];
-            }
-            __syncthreads();
-            float acc[kHeadRows];
-#pragma unroll
-            for (int r = 0; r < kHeadRows; ++r) acc[r] = 0.f;
-            if (jj < tr) {
-                const float* wr = wt + jj * (FD + 1);
-                for (int c = part; c < FD; c += 8) {
-                    const float w = wr[c];
-#pragma unroll
-                    for (int r = 0; r < kHeadRows; ++r) acc[r] = fmaf(w, in[r * FD + c], acc[r]);
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < kHeadRows; ++r) {   // the eight partial sums of a row, in a fixed order
-                acc[r] += __shfl_xor(acc[r], 1);
-                acc[r] += __shfl_xor(acc[r], 2);
-                acc[r] += __shfl_xor(acc[r], 4);
-            }
-            if (jj < tr && part == 0) {
-                const int j = j0 + jj;
-#pragma unroll
-                for (int r = 0; r < kHeadRows; ++r) {
-                    float v = acc[r] + b[j];
-                    if (relu) v = fmaxf(v, 0.f);
-                    outs[r * rows + j] = v;
-                    if (r < nr) gout[(int64_t)(r0 + r) * rows + j] = v;
-                }
-            }
-        }
-    };
-    layer(W0, b0, FD, xs, hs, h1, true);
-    layer(W2, b2, OD, hs, os, h2, false);
-    __syncthreads();
-    const int wave = tid >> 6, lane = tid & 63;
-    if (wave < nr) {   // (the arithmetic of l2norm_fwd_kernel)
-        const float* p = os + wave * OD;
-        float ss = 0.f;
-        for (int j = lane; j < OD; j += 64) ss = fmaf(p[j], p[j], ss);
-        ss = wave_sum(ss);
-        const float nrm = fmaxf(sqrtf(ss), 1e-12f);
-        if (lane == 0) norms[r0 + wave] = nrm;
-        for (int j = lane; j < OD; j += 64) {
-            const float q = p[j] / nrm;
-            out[(int64_t)(r0 + wave) * OD + j] = q;
-            if (out2) out2[(int64_t)(r0 + wave) * OD + j] = q;
-        }
-    }
-}
-// dh2 = (dout - out <out, dout>) / norm, dh1 = (h1 > 0) * (dh2 W2), dx = dh1 W0; dh2 and dh1 are written for the dW / db products
-__global__ void __launch_bounds__(256) mlp_head_bwd_kernel(const float* __restrict__ o, const float* __restrict__ norms, const float* __restrict__ dout,
-                                                           const float* __restrict__ h1, const float* __restrict__ W0, const float* __restrict__ W2,
-                                                           float* __restrict__ dh2, float* __restrict__ dh1, float* __restrict__ dx, int N, int FD, int OD) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
-    float* g2 = (float*)lds_raw;            // [kHeadRows][OD]
-    float* g1 = g2 + kHeadRows * OD;        // [kHeadRows][FD]
-    const int tid = threadIdx.x, r0 = blockIdx.x * kHeadRows;
-    const int nr = min(kHeadRows, N - r0);
-    const int wave = tid >> 6, lane = tid & 63;
-    if (wave < kHeadRows) {   // (the arithmetic of l2norm_bwd_kernel)
-        if (wave < nr) {
-            const float* oo = o + (int64_t)(r0 + wave) * OD;
-            const float* g = dout + (int64_t)(r0 + wave) * OD;
-            float dot = 0.f;
-            for (int j = lane; j < OD; j += 64) dot = fmaf(oo[j], g[j], dot);
-            dot = wave_sum(dot);
-            const float inv = 1.0f / norms[r0 + wave];
-            for (int j = lane; j < OD; j += 64) {
-                const float v = (g[j] - oo[j] * dot) * inv;
-                g2[wave * OD + j] = v;
-                dh2[(int64_t)(r0 + wave) * OD + j] = v;
-            }
-        } else {
-            for (int j = lane; j < OD; j += 64) g2[wave * OD + j] = 0.f;
-        }
-    }
-    __syncthreads();
-    for (int j = tid; j < FD; j += 256) {
-        float acc[kHeadRows];
-#pragma unroll
-        for (int r = 0; r < kHeadRows; ++r) acc[r] = 0.f;
-#pragma unroll 8
-        for (int k = 0; k < OD; ++k) {
-            const float w = W2[(int64_t)k * FD + j];
-#pragma unroll
-            for (int r = 0; r < kHeadRows; ++r) acc[r] = fmaf(g2[r * OD + k], w, acc[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < kHeadRows; ++r) {
-            const float v = (r < nr && h1[(int64_t)(r0 + r) * FD + j] > 0.f) ? acc[r] : 0.f;
-            g1[r * FD + j] = v;
-            if (r < nr) dh1[(int64_t)(r0 + r) * FD + j] = v;
-        }
-    }
-    __syncthreads();
-    for (int c = tid; c < FD; c += 256) {
-        float acc[kHeadRows];
-#pragma unroll
-        for (int r = 0; r < kHeadRows; ++r) acc[r] = 0.f;
-#pragma unroll 8
-        for (int j = 0; j < FD; ++j) {
-            const float w = W0[(int64_t)j * FD + c];
-#pragma unroll
-            for (int r = 0; r < kHeadRows; ++r) acc[r] = fmaf(g1[r * FD + j], w, acc[r]);
-        }
-#pragma unroll
-        for (int r = 0; r < kHeadRows; ++r)
-            if (r < nr) dx[(int64_t)(r0 + r) * FD + c] = acc[r];
-    }
-}
-int launch_mlp_head_fwd(const float* x, const float* W0, const float* b0, const float* W2, const float* b2, float* h1, float* h2, float* out,
-                        float* norms, float* out2, int N, int FD, int OD, hipStream_t s) {
-    const size_t lds = ((size_t)2 * kHeadRows * FD + (size_t)kHeadRows * OD + (size_t)kHeadTile * (FD + 1)) * 4;
-    OCL_REQUIRE(lds <= kLdsLimit, "mlp_head_fwd: feature width %d does not fit the LDS", FD);
-    ProfScope ps(PROF_HEAD, s);
-    hipLaunchKernelGGL(mlp_head_fwd_kernel, dim3(cdiv(N, kHeadRows)), dim3(256), lds, s, x, W0, b0, W2, b2, h1, h2, out, norms, out2, N, FD, OD);
-    OCL_LAUNCH_CHECK();
-    return OCL_OK;
-}
-int launch_mlp_head_bwd(const float* o, const float* norms, const float* dout, const float* h1, const float* W0, const float* W2, float* dh2,
-                        float* dh1, float* dx, int N, int FD, int OD, hipStream_t s) {
-    ProfScope ps(PROF_HEAD, s);
-    hipLaunchKernelGGL(mlp_head_bwd_kernel, dim3(cdiv(N, kHeadRows)), dim3(256), (size_t)kHeadRows * (FD + OD) * 4, s, o, norms, dout, h1, W0, W2, dh2, dh1,
-                       dx, N, FD, OD);
-    OCL_LAUNCH_CHECK();
-    return OCL_OK;
-}
-
 __global__ void __launch_bounds__(256) relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ a, float* __restrict__ dx,
                                                        int64_t n) {
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
@@ -3131,7 +2973,6 @@ int launch_fill(float* p, int64_t n, float v, hipStream_t s) {
 
 // Allow every instantiation to use the full 160 KiB of dynamic LDS.
 int conv_kernels_init() {
-    OCL_HIP(hipFuncSetAttribute((const void*)mlp_head_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit));
     static bool done_dev[kMaxDevices] = {false};   // function attributes and the mode symbol are per device
     int dev = 0;
     OCL_HIP(hipGetDevice(&dev));

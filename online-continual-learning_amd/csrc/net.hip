@@ -565,11 +565,6 @@ static int run_conv(ocl_net* n, ConvPlan& cached, const float* in, const float* 
     return launch_conv(p, s);
 }
 
-// OCL_HEAD_FUSED=0: the 'mlp' head as separate gemm / l2norm / ReLU-mask launches (A/B reference, tests/test_gpu_netcheck.py)
-static bool head_fused() {
-    static const bool on = [] { const char* e = getenv("OCL_HEAD_FUSED"); return !e || e[0] != '0'; }();
-    return on;
-}
 static int head_forward(ocl_net* n, const float* P, float* feat, float* h1, float* h2, float* norms, float* out, int N,
                         hipStream_t s, float* out2, bool* wrote_out2) {
     const int FD = n->feat_dim;
@@ -580,11 +575,6 @@ static int head_forward(ocl_net* n, const float* P, float* feat, float* h1, floa
             rc = ocl_gemm_small(feat, FD, 1, T(n->t_linear_w), 1, FD, out, n->out_dim, N, n->out_dim, FD, T(n->t_linear_b), 0, 0, s);
             break;
         case 1:
-            if (head_fused()) {   // Linear - ReLU - Linear - normalise in one launch
-                rc = launch_mlp_head_fwd(feat, T(n->t_h0_w), T(n->t_h0_b), T(n->t_h2_w), T(n->t_h2_b), h1, h2, out, norms, out2, N, FD, n->out_dim, s);
-                *wrote_out2 = true;
-                break;
-            }
             rc = ocl_gemm_small(feat, FD, 1, T(n->t_h0_w), 1, FD, h1, FD, N, FD, FD, T(n->t_h0_b), 1, 0, s);
             if (rc) return rc;
             rc = ocl_gemm_small(h1, FD, 1, T(n->t_h2_w), 1, FD, h2, n->out_dim, N, n->out_dim, FD, T(n->t_h2_b), 0, 0, s);
@@ -1482,12 +1472,12 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
     // kTwoStreamMinBatch x 32 x 32 input pixels: the smallest pass whose weight gradients leave the caller's stream
     const bool two_streams = n->dbg_stop < 0 && (int64_t)N * n->d.in_h * n->d.in_w >= (int64_t)kTwoStreamMinBatch * 1024 && !prof_on() && !env_single;
     if (two_streams && (rc = ensure_side_stream(n))) return rc;
-    auto lin_bwd = [&](const float* dy, int ncol, const float* xin, int kin, int tw, int tb, float* dx, bool publish = true) -> int {
+    auto lin_bwd = [&](const float* dy, int ncol, const float* xin, int kin, int tw, int tb, float* dx) -> int {
         // y = x W^T + b, W [ncol, kin]
         const bool hs_big = (int64_t)N * n->d.in_h * n->d.in_w >= (int64_t)kSideExtraMinBatch * 1024;
         const bool hs = two_streams && hs_big;
         hipStream_t sw = hs ? n->s2 : s;
-        int r = hs && publish ? side_wait(n, s) : OCL_OK;   // dy is complete (publish = false: the previous hand-over covers it)
+        int r = hs ? side_wait(n, s) : OCL_OK;   // dy is complete
         if (r) return r;
         if ((r = ocl_gemm_small(dy, 1, ncol, xin, kin, 1, GT(tw), kin, ncol, kin, N, nullptr, 0, accumulate, sw))) return r;  // dW = dy^T x
         if ((r = launch_colsum(dy, N, ncol, GT(tb), accumulate, sw))) return r;
@@ -1509,12 +1499,7 @@ int ocl_net_backward(ocl_net* n, int slot, const float* dout, int accumulate, vo
                 // (weight and bias are neighbours in the flat array: one fill)
                 if ((rc = launch_fill(GT(n->t_linear_w), n->tensors[n->t_linear_w].numel + n->tensors[n->t_linear_b].numel, 0.f, s))) return rc;
             }
-            if (n->d.head == 1 && head_fused()) {
-                // the dx chain in one launch; then both dW / db products (beside the trunk's chain on large passes: one hand-over)
-                if ((rc = launch_mlp_head_bwd(o, norms, dout, h1, T(n->t_h0_w), T(n->t_h2_w), dh2, dh1, dfeat, N, FD, OD, s))) return rc;
-                if ((rc = lin_bwd(dh2, OD, h1, FD, n->t_h2_w, n->t_h2_b, nullptr))) return rc;
-                if ((rc = lin_bwd(dh1, FD, feat, FD, n->t_h0_w, n->t_h0_b, nullptr, false))) return rc;
-            } else if (n->d.head == 1) {
+            if (n->d.head == 1) {
                 if ((rc = launch_l2norm_bwd(o, norms, dout, dh2, N, OD, s))) return rc;
                 if ((rc = lin_bwd(dh2, OD, h1, FD, n->t_h2_w, n->t_h2_b, dh1))) return rc;
                 if ((rc = launch_relu_bwd(dh1, h1, dh1, (int64_t)N * FD, s))) return rc;
