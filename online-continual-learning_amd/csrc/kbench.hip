@@ -962,10 +962,11 @@ int main(int argc, char** argv) {
                 }
             }
             WgradPlan wp;
-            OK(plan_wgrad(N, c.Hin, c.Win, c.CinT, c.Ho, c.Wo, c.Cout, c.k, c.stride, &wp));
-            printf("%-20s wgrad  M=%4d N=%3d K=%7d  MTW=%d NTW=%d grid=%4dx%3d lds=%6zu KC=%3d CP=%3d S=%4d tiles=%d KP=%d q4=%d xcd=%d partial=%6.2f MB\n", l.name.c_str(),
+            const char* wt = getenv("KBENCH_WG_TARGET");   // (the layer's split inside the merged launch of a replay-sized pass: net.hip passes 96)
+            OK(plan_wgrad(N, c.Hin, c.Win, c.CinT, c.Ho, c.Wo, c.Cout, c.k, c.stride, &wp, 0, wt ? atoi(wt) : 0));
+            printf("%-20s wgrad  M=%4d N=%3d K=%7d  MTW=%d NTW=%d grid=%4dx%3d lds=%6zu KC=%3d CP=%3d S=%4d tiles=%d KP=%d q4=%d xcd=%d multi=%d partial=%6.2f MB\n", l.name.c_str(),
                    c.k * c.k * c.CinT, c.Cout, N * c.Ho * c.Wo, wp.MTW, wp.NTW, wp.grid_x, wp.grid_y, wp.lds_bytes, wp.a.KC, wp.a.CP, wp.a.S,
-                   wp.a.total_tiles, wp.a.KP, wp.q_rgw, wp.a.xcd_by, wp.partial_floats * 4e-6);
+                   wp.a.total_tiles, wp.a.KP, wp.q_rgw, wp.a.xcd_by, wgrad_multi_variant(wp), wp.partial_floats * 4e-6);
         }
         return 0;
     }
@@ -1097,7 +1098,9 @@ int main(int argc, char** argv) {
         for (auto& l : layers) {
             const ConvShape& c = l.s;
             WgradPlan wp;
-            OK(plan_wgrad(N, c.Hin, c.Win, c.CinT, c.Ho, c.Wo, c.Cout, c.k, c.stride, &wp));
+            // (KBENCH_WG_TARGET: the pixel split of a layer inside the merged launch of a replay-sized pass, net.hip: 96)
+            static const int env_wt = [] { const char* e = getenv("KBENCH_WG_TARGET"); return e ? atoi(e) : 0; }();
+            OK(plan_wgrad(N, c.Hin, c.Win, c.CinT, c.Ho, c.Wo, c.Cout, c.k, c.stride, &wp, 0, env_wt));
             wp.a.x = bufA; wp.a.dy = bufB; wp.a.partial = partial;
             const int nwg = wp.grid_x * wp.grid_y;
             unsigned long long* tr;

@@ -469,6 +469,7 @@ static wgrad_fn_t wgrad_trace_fn(int M, int N, int PF, int rgw) {
     if (M == 2 && N == 3) return conv_wgrad_kernel<2, 3, 8, 0, 1>;
     if (M == 3 && N == 2) return conv_wgrad_kernel<3, 2, 8, 0, 1>;
     if (M == 1 && N == 3) return conv_wgrad_kernel<1, 3, 8, 0, 1>;
+    if (M == 1 && N == 2) return conv_wgrad_kernel<1, 2, 8, 0, 1>;
     return nullptr;
 }
 static int wgrad_pf_for(int units) { return units <= 1024 ? 4 : 8; }
@@ -616,7 +617,11 @@ int plan_wgrad(int N, int Hin, int Win, int Cin, int Ho, int Wo, int Cout, int k
     // (wg_target > 0: the layer shares its launch with the other layers of the pass -- conv_wgrad_multi_kernel -- and need not fill the
     // machine alone: fewer pixel splits, i.e. fewer slabs to write and to reduce)
     constexpr int env_kp = 128;
-    const int env_target = wg_target > 0 ? wg_target : 512, env_enough = wg_target > 0 ? std::max(1, wg_target * 3 / 4) : 384;
+    // (OCL_WGRAD_TARGET / OCL_WGRAD_ENOUGH: measurement overrides, profiles/r6_wgrad_mtw_ab.txt)
+    static const int ov_target = [] { const char* e = getenv("OCL_WGRAD_TARGET"); return e ? atoi(e) : 0; }();
+    static const int ov_enough = [] { const char* e = getenv("OCL_WGRAD_ENOUGH"); return e ? atoi(e) : 0; }();
+    const int env_target = wg_target > 0 ? wg_target : (ov_target > 0 ? ov_target : 512);
+    const int env_enough = wg_target > 0 ? std::max(1, wg_target * 3 / 4) : (ov_enough > 0 ? ov_enough : 384);
     for (int pass = 0; pass < 2 && !found; ++pass) {
         for (int KPmax = env_kp; KPmax >= 32 && !found; KPmax /= 2) {
             if (LP >= KPmax) {

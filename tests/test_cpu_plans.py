@@ -163,3 +163,22 @@ def test_eighty_channel_weight_gradient_blocks_are_planned_by_pass_size():
             else:
                 assert f["NTW"] <= 3, l
             assert float(re.search(r"partial= *([\d.]+) MB", l).group(1)) <= 12.6, l
+
+
+def test_merged_weight_gradient_launch_gets_a_form_for_every_layer_of_a_replay_sized_pass():
+    """conv_wgrad_multi_kernel<0> (every layer of a replay-sized pass in one launch) holds the 64-row forms: split as net.hip asks for the merged
+    launch (96 workgroups per layer) every layer of a 10 / 13 / 20 / 47-image pass must plan one of them (`multi` = its index, 0 .. 3), with at
+    most ~96 workgroups where the output blocks alone do not exceed that, and slabs that fit side by side in the 64 MB workspace."""
+    for n, groups in [(10, 1), (13, 1), (20, 2), (47, 1)]:
+        lines = [l for l in _plan_lines(n, groups, 32, {"KBENCH_WG_TARGET": "96"}) if " wgrad " in l]
+        assert len(lines) == 20
+        total_mb = 0.0
+        for l in lines:
+            f = _fields(l)
+            gx, gy = (int(v) for v in re.search(r"grid= *(\d+)x *(\d+)", l).groups())
+            assert f["MTW"] == 1 and 0 <= f["multi"] <= 3, l
+            assert gx * gy <= max(gy, 96 + gy), l
+            total_mb += float(re.search(r"partial= *([\d.]+) MB", l).group(1))
+        assert total_mb < 64.0
+    # as a launch of its own the 220-view pass keeps forms the merged kernels do not all have: it is never merged (two streams)
+    assert any(_fields(l)["multi"] < 0 for l in _plan_lines(220, 2, 32) if " wgrad " in l)
