@@ -4,16 +4,23 @@ Until the stream has seen more samples than the memory holds, retrieval is unifo
 the candidates; each is scored by its kNN Shapley value w.r.t. the incoming batch (adversarial: high value = close to current
 samples of its own class) and w.r.t. a second class-balanced memory sample (cooperative), combined per `aser_type`
 ("asv": max coop - min adv, "asvm": mean coop - mean adv, "neg_sv": -sum adv), and the best `eps_mem_batch` are returned.
-The two Shapley matrices share ONE eval-mode feature pass over batch + cooperative samples + candidates (the reference extracts the
-candidates' features twice); scoring, ranking and the final gather stay on the GPU, nothing is copied back to the host."""
+The candidates' features are extracted once (the reference extracts them twice): one eval-mode pass over batch + candidates, issued
+before the host draws the cooperative samples, and one over those; scoring, ranking and the final gather stay on the GPU, nothing is
+copied back to the host."""
 import torch
 
 from .. import debug
 from .. import ops
 from ..setup_elements import n_classes
 from ..utils import maybe_cuda
-from .aser_utils import compute_knn_sv, compute_knn_sv_pair
+import os
+
+from .aser_utils import compute_knn_sv, compute_knn_sv_pair, features_begin
 from .buffer_utils import ClassBalancedRandomSampling, random_retrieve
+
+
+def _split_features():
+    return os.environ.get("OCL_ASER_SPLIT", "1") != "0"
 
 
 class ASER_retrieve(object):
@@ -48,9 +55,14 @@ class ASER_retrieve(object):
         else:
             # the cooperative evaluation set is drawn before any scoring (no RNG draw lies between, so the streams are those of the
             # reference's order :56-76) and both matrices come out of one feature pass
+            # Round 6: the feature pass over batch + candidates is ISSUED before the cooperative draw: that draw excludes the candidates'
+            # slots -- a real set difference per class on the host, ~0.2 ms with the GPU's queue empty (the step's one synchronisation lies
+            # just behind) -- and now runs beside ~0.3 ms of GPU work; the cooperative samples' features follow in a second, smaller pass
+            # (eval-mode features are per sample).  OCL_ASER_SPLIT=0: one pass over all three pieces, after both draws.
+            pending = features_begin(buffer.model, cur_x, cand_x) if _split_features() else None
             coop_x, coop_y, _ = sampler.sample(buffer.buffer_img, buffer.buffer_label, self.n_smp_cls, excl_indices=set(cand_slots.tolist()),
                                                device=self.device)
-            adv, coop = compute_knn_sv_pair(buffer.model, cur_x, cur_y, coop_x, coop_y, cand_x, cand_y, self.k, want_order=trace)
+            adv, coop = compute_knn_sv_pair(buffer.model, cur_x, cur_y, coop_x, coop_y, cand_x, cand_y, self.k, want_order=trace, begun=pending)
             if trace:
                 (adv, order_adv), (coop, order_coop) = adv, coop
         score = ops.aser_score(adv, coop, self.aser_type)

@@ -37,14 +37,24 @@ def compute_knn_sv(model, eval_x, eval_y, cand_x, cand_y, k, device="cpu", want_
     return ops.knn_sv(eval_df.contiguous(), eval_y, cand_df.contiguous(), cand_y, k, want_order=want_order)
 
 
-def compute_knn_sv_pair(model, eval_a_x, eval_a_y, eval_b_x, eval_b_y, cand_x, cand_y, k, want_order=False):
+def features_begin(model, eval_a_x, cand_x):
+    """The eval-mode feature pass over eval_a + candidates, issued now (compute_knn_sv_pair(begun=...) takes it from here)."""
+    na, nc = eval_a_x.size(0), cand_x.size(0)
+    return mini_batch_deep_features(model, [maybe_cuda(eval_a_x), maybe_cuda(cand_x)], na + nc)
+
+
+def compute_knn_sv_pair(model, eval_a_x, eval_a_y, eval_b_x, eval_b_y, cand_x, cand_y, k, want_order=False, begun=None):
     """Two compute_knn_sv calls over the SAME candidates (aser_retrieve.py:56-76: adversarial and cooperative Shapley values)
     with ONE eval-mode feature pass over eval_a + eval_b + candidates: eval-mode features are per-sample, so the candidates'
     features (computed twice by the reference) are the same in both calls."""
     na, nb, nc = eval_a_x.size(0), eval_b_x.size(0), cand_x.size(0)
-    f = mini_batch_deep_features(model, [maybe_cuda(eval_a_x), maybe_cuda(eval_b_x), maybe_cuda(cand_x)], na + nb + nc)
+    if begun is not None:   # features of eval_a + candidates are on their way (features_begin): eval_b's in a pass of their own
+        fb = mini_batch_deep_features(model, [maybe_cuda(eval_b_x)], nb)
+        fab, fc = torch.cat((begun[0:na], fb)), begun[na:].contiguous()
+    else:
+        f = mini_batch_deep_features(model, [maybe_cuda(eval_a_x), maybe_cuda(eval_b_x), maybe_cuda(cand_x)], na + nb + nc)
+        fab, fc = f[0:na + nb].contiguous(), f[na + nb:].contiguous()
     # one workgroup per evaluation row, rows independent: both evaluation sets are ONE launch over the stacked rows
-    fab, fc = f[0:na + nb].contiguous(), f[na + nb:].contiguous()
     sv = ops.knn_sv(fab, torch.cat((eval_a_y, eval_b_y)), fc, cand_y, k, want_order=want_order)
     if want_order:
         sv, order = sv
