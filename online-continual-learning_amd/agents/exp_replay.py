@@ -139,9 +139,20 @@ class ExperienceReplay(ContinualLearner):
             if getattr(mem_y, 'host', None) is not None:
                 combined_labels.host = np.concatenate((np.asarray(mem_y.host), np.asarray(batch_y_host)))
             # (torch.cat((mem_x, batch_x)) is not materialised: the engine reads the two pieces where they are)
-            loss_combined = self.criterion(self.model.forward((mem_x, batch_x)), combined_labels)
-            self._emit("er_loss_combined", loss_combined)
-            loss_combined.backward(unit_gradient(loss_combined))
+            trick = self.params.trick
+            if (hasattr(self.model, "forward_views_taped") and not trick['labels_trick'] and not trick['separated_softmax']
+                    and not getattr(self, "_force_autograd", False) and os.environ.get("OCL_ASER_AUTOGRAD", "0") != "1"):   # (both: the A/B's autograd side)
+                # plain cross-entropy (agents/base.py:113), as in _merged_step: the loss kernel's dL/dlogits goes straight into the engine's
+                # backward -- the same numbers, without autograd's engine between the loss and the backward (a hand-over to its worker
+                # thread with the GPU's queue already empty: ~0.1 ms of an ASER step, profiles/r6_aser_step_timeline.txt)
+                out, tape = self.model.forward_views_taped([(mem_x, batch_x)])
+                loss_combined, dl = ops.cross_entropy(out, combined_labels, "mean")
+                self._emit("er_loss_combined", loss_combined)
+                self.model.backward_taped(tape, dl)
+            else:
+                loss_combined = self.criterion(self.model.forward((mem_x, batch_x)), combined_labels)
+                self._emit("er_loss_combined", loss_combined)
+                loss_combined.backward(unit_gradient(loss_combined))
         self.opt.step()
 
     # ---- the loop ------------------------------------------------------------------------------------------------------

@@ -527,6 +527,62 @@ def test_er_merged_step_direct_backward_is_schedule_only(cuda):
         assert np.array_equal(r1[k], r0[k]), k
 
 
+def test_aser_combined_pass_direct_backward_is_schedule_only(cuda):
+    """The ASER iteration's combined pass (exp_replay.py:76-84) hands the loss kernel's dL/dlogits straight to the engine's backward instead of
+    going through autograd's engine: same numbers into the same backward.  With order-independent batch sums 40 free-running ER + ASER steps
+    (memory filling up, then Shapley-ranked retrieval and replacement) end in bit-identical weights, running statistics, replay memory and
+    class table on both paths (`_force_autograd` = the autograd path)."""
+    from ocl_amd import ops
+    from ocl_amd.plugins.buffer_utils import ClassBalancedRandomSampling as CBRS
+    cfg = dict(STEP_CASES["aser_c100"])
+    rng = np.random.default_rng(79)
+    x = rng.integers(0, 256, (400, 32, 32, 3), dtype=np.uint8)
+    y = rng.integers(0, 8, 400).astype(np.int64)
+    finals = []
+    ops.set_deterministic(True)
+    try:
+        for force in (False, True):
+            params, model, agent = build_agent(cfg)
+            agent._force_autograd = force
+            agent.train_learner(torch.from_numpy(x).to(cuda), y)
+            torch.cuda.synchronize()
+            finals.append((model.flat_params().cpu().numpy().copy(), agent.buffer.buffer_img.cpu().numpy().copy(),
+                           agent.buffer.buffer_label.cpu().numpy().copy(), agent.buffer.n_seen_so_far,
+                           {k: v.cpu().numpy().copy() for k, v in model.state_dict().items() if "running" in k},
+                           {int(k): sorted(v) for k, v in CBRS.class_index_cache.items()}))
+    finally:
+        ops.set_deterministic(False)
+    (w1, b1, l1, n1, r1, c1), (w0, b0, l0, n0, r0, c0) = finals
+    assert n1 == n0 == 400 and np.array_equal(l1, l0) and np.array_equal(b1, b0) and c1 == c0
+    assert np.array_equal(w1, w0)
+    for k in r0:
+        assert np.array_equal(r1[k], r0[k]), k
+
+
+def test_aser_retrieval_feature_pass_split_keeps_the_retrieval(cuda, monkeypatch):
+    """plugins/aser_retrieve.py issues the eval-mode feature pass over batch + candidates BEFORE the host draws the cooperative samples
+    (OCL_ASER_SPLIT=0: one pass over all three pieces after both draws).  Eval-mode features are per sample and the host draws are the same
+    draws in the same order, so the replay memory, the class table and the counters of 40 free-running ER + ASER steps are exactly those of
+    the one-pass schedule; the weights agree to rounding (the two schedules run their passes at other batch sizes, i.e. under other plans)."""
+    from ocl_amd.plugins.buffer_utils import ClassBalancedRandomSampling as CBRS
+    cfg = dict(STEP_CASES["aser_c100"])
+    rng = np.random.default_rng(80)
+    x = rng.integers(0, 256, (400, 32, 32, 3), dtype=np.uint8)
+    y = rng.integers(0, 8, 400).astype(np.int64)
+    finals = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("OCL_ASER_SPLIT", flag)
+        params, model, agent = build_agent(cfg)
+        agent.train_learner(torch.from_numpy(x).to(cuda), y)
+        torch.cuda.synchronize()
+        finals.append((model.flat_params().cpu().numpy().copy(), agent.buffer.buffer_img.cpu().numpy().copy(),
+                       agent.buffer.buffer_label.cpu().numpy().copy(), agent.buffer.n_seen_so_far,
+                       {int(k): sorted(v) for k, v in CBRS.class_index_cache.items()}))
+    (w1, b1, l1, n1, c1), (w0, b0, l0, n0, c0) = finals
+    assert n1 == n0 == 400 and np.array_equal(l1, l0) and np.array_equal(b1, b0) and c1 == c0
+    assert np.abs(w1 - w0).max() <= 1e-3 * max(1.0, np.abs(w0).max())
+
+
 def test_aser_pipelined_loop_is_schedule_only(cuda, monkeypatch):
     """agents/exp_replay.py issues the batch-pass forward of iteration i+1 before the host half of iteration i's ASER update (wait
     for the ranking, class table, row moves).  Same kernels on the same data, same RNG draws: 40 free-running ER + ASER steps
