@@ -85,8 +85,9 @@ class ContinualLearner(torch.nn.Module, metaclass=abc.ABCMeta):
 
         @contextlib.contextmanager
         def ctx():
-            prio = os.environ.get("OCL_LOOP_PRIO")   # (experiment: the loop on a stream of its own with this priority, -1 = high; profiles/r6_loop_prio_ab.txt)
-            if not (self.cuda and (os.environ.get("OCL_GRAPH") == "1" or prio)) or debug.on():
+            # (the loop on a HIGH-priority stream of its own against the lowest-priority weight-gradient stream: no gain on SCR, ER + 0.02 ms --
+            # profiles/r6_loop_prio_ab.txt; the switch is gone)
+            if not (self.cuda and os.environ.get("OCL_GRAPH") == "1") or debug.on():
                 yield
                 return
             cur = torch.cuda.current_stream()
@@ -95,7 +96,7 @@ class ContinualLearner(torch.nn.Module, metaclass=abc.ABCMeta):
                 return
             own = self.__dict__.get("_ocl_stream")
             if own is None:
-                own = self.__dict__["_ocl_stream"] = torch.cuda.Stream(priority=int(prio)) if prio else torch.cuda.Stream()
+                own = self.__dict__["_ocl_stream"] = torch.cuda.Stream()
             own.wait_stream(cur)
             with torch.cuda.stream(own):
                 yield
