@@ -49,7 +49,7 @@ def compute_knn_sv_pair(model, eval_a_x, eval_a_y, eval_b_x, eval_b_y, cand_x, c
     features (computed twice by the reference) are the same in both calls."""
     na, nb, nc = eval_a_x.size(0), eval_b_x.size(0), cand_x.size(0)
     if begun is not None:   # features of eval_a + candidates are on their way (features_begin): eval_b's in a pass of their own
-        fb = mini_batch_deep_features(model, [maybe_cuda(eval_b_x)], nb)
+        fb = mini_batch_deep_features(model, [maybe_cuda(eval_b_x)], nb) if nb > 0 else begun.new_zeros((0, begun.shape[1]))   # (no class has a second sample)
         fab, fc = torch.cat((begun[0:na], fb)), begun[na:].contiguous()
     else:
         f = mini_batch_deep_features(model, [maybe_cuda(eval_a_x), maybe_cuda(eval_b_x), maybe_cuda(cand_x)], na + nb + nc)
