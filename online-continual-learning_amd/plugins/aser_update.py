@@ -87,7 +87,9 @@ class ASER_update(object):
     def _replace(self, buffer, cur_x, cur_y, cur_labels, mem_slots, eval_slots, minor_x, total, ranking_dev, knn_order, n_mem, n_cur):
         trace = debug.on()
         ranking_host, arrived, _keep = ranking_dev
-        arrived.synchronize()                            # the update's one synchronisation: the ranking has reached the host
+        # the update's one synchronisation: the ranking has reached the host (polling the event instead of blocking on it: not faster,
+        # profiles/r6_aser_spin_ab.txt)
+        arrived.synchronize()
         ranking = ranking_host.clone()
 
         # the n_mem best-valued candidates hold a slot afterwards: batch items among them move in, memory items outside move out
