@@ -60,6 +60,7 @@ class ContinualLearner(torch.nn.Module, metaclass=abc.ABCMeta):
         if os.environ.get("OCL_GC_FREEZE", "1") != "0":
             gc.collect()
             gc.freeze()
+        # (the young generations' collections do not show in the step: collector off / threshold 100000 change nothing, profiles/r6_gc_threshold_ab.txt)
 
     def before_train(self, x_train, y_train):
         """agents/base.py:43-50."""
