@@ -132,14 +132,19 @@ static uint64_t set_checksum(PyObject* set) {
     return acc;
 }
 
-/* cbrs_sample(class_index_cache: dict[label -> set[int]], excluded: set | None, n_smp_cls: int, state, out[, versions, token])
- * -> number of picks.  out: writable buffer of int64; raises if it is too small.  versions: int64 buffer indexed by label. */
+/* cbrs_sample(class_index_cache: dict[label -> set[int]], excluded: set | None, n_smp_cls: int, state, out[, versions, token[, verify]])
+ * -> number of picks.  out: writable buffer of int64; raises if it is too small.  versions: int64 buffer indexed by label.
+ * verify (default 1): compare the live set's checksum before a memoised order is used.  The comparison walks the set's whole hash table --
+ * 256 - 512 entries for ~50 members once update_cache has churned the sets for a few hundred steps -- and was most of the call by then
+ * (profiles/r6_cbrs_drift_cpu.txt: 163 -> 279 us per draw over 1600 steps with it, 68 -> 85 us without); a caller whose every mutation goes
+ * through update_cache (the ASER plugins) passes 0 and verifies now and then. */
 static PyObject* py_cbrs_sample(PyObject* self, PyObject* args) {
     PyObject *cache, *excluded;
     long long n_smp, token = 0;
+    int verify = 1;
     Py_buffer sb, ob, vb;
     vb.buf = NULL; vb.obj = NULL; vb.len = 0;
-    if (!PyArg_ParseTuple(args, "O!OLw*w*|y*L", &PyDict_Type, &cache, &excluded, &n_smp, &sb, &ob, &vb, &token)) return NULL;
+    if (!PyArg_ParseTuple(args, "O!OLw*w*|y*Li", &PyDict_Type, &cache, &excluded, &n_smp, &sb, &ob, &vb, &token, &verify)) return NULL;
     MtState* s;
     PyObject* result = NULL;
     PyObject* empty = NULL;
@@ -177,7 +182,7 @@ static PyObject* py_cbrs_sample(PyObject* self, PyObject* args) {
                 if (label >= 0 && label < MEMO_LABELS && label < n_versions) {
                     memo = &g_memo[label];
                     if (memo->members && memo->token == token && memo->version == versions[label] && memo->n == PySet_GET_SIZE(slots) &&
-                        memo->content == set_checksum(slots)) {
+                        (!verify || memo->content == set_checksum(slots))) {
                         const Py_ssize_t n = memo->n;
                         if (n > cap) {
                             cap = n * 2 + 64;

@@ -34,6 +34,8 @@ class ASER_retrieve(object):
         self.out_dim = n_classes[params.data]
         self.is_aser_upt = params.update == "ASER"
         ClassBalancedRandomSampling.class_index_cache = None     # class-level state, reset per plugin instance (:19)
+        # (every mutation of the class sets goes through update_cache: the C helper's memo is verified one draw in 64, buffer_utils.py)
+        ClassBalancedRandomSampling.verify_every = int(__import__("os").environ.get("OCL_CBRS_VERIFY_EVERY", "64"))
 
     def retrieve(self, buffer, **kwargs):
         if buffer.n_seen_so_far <= self.mem_size:                 # memory not yet cycled once: uniform retrieval (:24-26)

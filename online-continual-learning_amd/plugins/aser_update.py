@@ -29,6 +29,8 @@ class ASER_update(object):
         self.reservoir_update = Reservoir_update(params)
         self._pinned = None
         ClassBalancedRandomSampling.class_index_cache = None     # class-level state, reset per plugin instance (:20)
+        # (every mutation of the class sets goes through update_cache: the C helper's memo is verified one draw in 64, buffer_utils.py)
+        ClassBalancedRandomSampling.verify_every = int(__import__("os").environ.get("OCL_CBRS_VERIFY_EVERY", "64"))
 
     # ---- entry point ---------------------------------------------------------------------------------------------------------
     def update(self, buffer, x, y, **kwargs):

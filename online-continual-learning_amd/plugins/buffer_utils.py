@@ -123,6 +123,12 @@ class ClassBalancedRandomSampling:
     _versions = None
     _tracked = None
     _token = 0
+    # The C helper can compare a checksum of every live set with the one it memoised (it catches in-place mutations behind update_cache's
+    # back, at the price of a walk over the set's whole hash table: most of a draw once the sets have been churned, and growing with the
+    # step count -- profiles/r6_aser_drift_probe.txt).  Default: every draw.  The ASER plugins, whose every mutation goes through
+    # update_cache, set verify_every = 64: one verified draw in 64.
+    verify_every = 1
+    _draws = 0
 
     @classmethod
     def draw(cls, n_smp_cls, excl_indices=None):
@@ -159,7 +165,9 @@ class ClassBalancedRandomSampling:
             cls._scratch = np.empty(room, dtype=np.int64)
         entry_state = state.clone()       # (the C call advances `state` in place)
         try:
-            n = _hostc.cbrs_sample(cache, excl_indices, int(n_smp_cls), state.numpy(), cls._scratch, cls._versions, cls._token)
+            ClassBalancedRandomSampling._draws += 1
+            verify = 1 if cls.verify_every <= 1 or ClassBalancedRandomSampling._draws % cls.verify_every == 0 else 0
+            n = _hostc.cbrs_sample(cache, excl_indices, int(n_smp_cls), state.numpy(), cls._scratch, cls._versions, cls._token, verify)
         except Exception:
             # the C helper gave up midway (a class set holding a non-integer, out of memory): the generator has not been touched yet
             # -- it is set only below -- so the Python loop replays the draw from the state this call started with

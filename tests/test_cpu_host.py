@@ -312,6 +312,8 @@ def test_class_balanced_draw_memo_survives_mutations_outside_update_cache():
     assert B._hostc_usable()
     C = B.ClassBalancedRandomSampling
     saved = (C.class_index_cache, C.class_num_cache)
+    saved_verify = C.verify_every
+    C.verify_every = 1                                   # (the class default; the ASER plugins lower the rate: every mutation of theirs goes through update_cache)
     try:
         labels = np.random.default_rng(5).integers(0, 12, 400).astype(np.int64)
         C.class_index_cache = None
@@ -339,6 +341,37 @@ def test_class_balanced_draw_memo_survives_mutations_outside_update_cache():
         assert torch.equal(torch.get_rng_state(), s_py)  # ... from the same generator state
     finally:
         C.class_index_cache, C.class_num_cache = saved
+        C.verify_every = saved_verify
+
+
+def test_class_balanced_draw_with_rare_verification_follows_update_cache():
+    """verify_every = 64 (what the ASER plugins set): the memoised iteration orders are trusted on the version counters that update_cache
+    bumps; through 300 steps of slot moves (the ASER update's bookkeeping) and three draws per step the C helper's picks and generator state
+    equal the Python loop's."""
+    from ocl_amd.plugins import buffer_utils as B
+    assert B._hostc_usable()
+    C = B.ClassBalancedRandomSampling
+    saved = (C.class_index_cache, C.class_num_cache, C.verify_every)
+    try:
+        rng = np.random.default_rng(11)
+        labels = rng.integers(0, 20, 1000).astype(np.int64)
+        C.class_index_cache = None
+        C.update_cache(labels, 20)
+        C.verify_every = 64
+        torch.manual_seed(9)
+        for step in range(300):
+            for excl in (None, set(rng.choice(1000, 20, replace=False).tolist()), None):
+                state = torch.get_rng_state()
+                a, sa = C.draw(1, excl), torch.get_rng_state()
+                torch.set_rng_state(state)
+                b, sb = C.draw_fast(1, excl), torch.get_rng_state()
+                assert torch.equal(a, b) and torch.equal(sa, sb), step
+            slots = rng.choice(1000, 6, replace=False)
+            new = rng.integers(0, 20, 6).astype(np.int64)
+            C.update_cache(labels, 20, new_y=new, ind=slots.tolist())
+            labels[slots] = new
+    finally:
+        C.class_index_cache, C.class_num_cache, C.verify_every = saved
 
 
 def test_texture_accuracy_stream_is_flip_invariant_and_class_separable():
