@@ -132,19 +132,109 @@ static uint64_t set_checksum(PyObject* set) {
     return acc;
 }
 
+/* Iteration order of the NEW set `slots - excluded` without building it (round 6: the draw with exclusions was 220 - 320 us of host time on
+ * the ASER step's critical path, most of it allocating and filling one Python set per class, and grew with the step count as the class sets'
+ * tables did: profiles/r6_aser_drift_probe.txt).  CPython's set_difference, in the branch it takes when len(slots) / 4 <= len(excluded),
+ * walks `slots` in table order and adds every element that is not in `excluded` to a fresh set; the fresh set's iteration order is the order
+ * of its hash table.  That table is simulated here for non-negative ints below 2^61 (hash == value): first slot hash & mask, nine linear
+ * probes, then i = 5 i + 1 + (perturb >>= 5); growth when 5 fill >= 3 mask to the power of two above 4 used, re-inserting the old table in
+ * order (Objects/setobject.c: set_add_entry, set_table_resize, set_insert_clean; no dummies and no equal keys can occur in the fresh set).
+ * Anything else -- other element types, other size ratios, subclasses -- returns -1 and the caller performs the real Python operation.
+ * `setdiff_check` hands the simulated order to the Python side, which compares it with list(a - b) on churned sets before trusting it
+ * (plugins/buffer_utils.py), as it does for randperm. */
+#define EMU_LINEAR_PROBES 9
+#define EMU_PERTURB_SHIFT 5
+#define EMU_MAX_TABLE 16384
+static int64_t g_emu_a[EMU_MAX_TABLE], g_emu_b[EMU_MAX_TABLE];
+static inline void emu_place(int64_t* table, size_t mask, int64_t v) {
+    size_t perturb = (size_t)v, i = (size_t)v & mask;
+    for (;;) {
+        if (table[i] < 0) { table[i] = v; return; }
+        if (i + EMU_LINEAR_PROBES <= mask) {
+            for (size_t j = 1; j <= EMU_LINEAR_PROBES; ++j)
+                if (table[i + j] < 0) { table[i + j] = v; return; }
+        }
+        perturb >>= EMU_PERTURB_SHIFT;
+        i = (i * 5 + 1 + perturb) & mask;
+    }
+}
+/* -> number of members written (in the fresh set's iteration order), or -1: not simulated */
+/* exmap (optional): exmap[v] != 0 <=> v is in `other`, for 0 <= v < exmap_n (every element of `other` lies below exmap_n): membership
+ * without hashing a PyLong per element (5000 PySet_Contains calls were most of the simulated draw) */
+static Py_ssize_t emu_difference(PyObject* so, PyObject* other, int64_t* members, Py_ssize_t cap, const unsigned char* exmap, Py_ssize_t exmap_n) {
+    if (!PySet_CheckExact(so) || !PyAnySet_CheckExact(other)) return -1;
+    if ((PySet_GET_SIZE(so) >> 2) > PySet_GET_SIZE(other)) return -1;   /* CPython copies `so` and discards instead */
+    int64_t *cur = g_emu_a, *nxt = g_emu_b;
+    size_t mask = 7, fill = 0;
+    for (size_t k = 0; k <= mask; ++k) cur[k] = -1;
+    Py_ssize_t pos = 0;
+    PyObject* key;
+    Py_hash_t h;
+    while (_PySet_NextEntry(so, &pos, &key, &h)) {
+        if (!PyLong_CheckExact(key) || h < 0 || h >= ((Py_hash_t)1 << 60)) return -1;   /* hash == value only for these */
+        if (exmap) {
+            if (h < exmap_n && exmap[h]) continue;
+        } else {
+            const int rv = PySet_Contains(other, key);
+            if (rv < 0) { PyErr_Clear(); return -1; }
+            if (rv) continue;
+        }
+        emu_place(cur, mask, (int64_t)h);
+        ++fill;
+        if (fill * 5 >= mask * 3) {
+            const size_t minused = fill > 50000 ? fill * 2 : fill * 4;
+            size_t newsize = 8;
+            while (newsize <= minused) newsize <<= 1;
+            if (newsize > EMU_MAX_TABLE) return -1;
+            for (size_t k = 0; k < newsize; ++k) nxt[k] = -1;
+            for (size_t k = 0; k <= mask; ++k)
+                if (cur[k] >= 0) emu_place(nxt, newsize - 1, cur[k]);
+            int64_t* t = cur; cur = nxt; nxt = t;
+            mask = newsize - 1;
+        }
+    }
+    if ((Py_ssize_t)fill > cap) return -1;
+    Py_ssize_t n = 0;
+    for (size_t k = 0; k <= mask; ++k)
+        if (cur[k] >= 0) members[n++] = cur[k];
+    return n;
+}
+
+/* setdiff_check(a: set, b: set) -> list | None: the simulated iteration order of `a - b` (None: this pair is not simulated) */
+static PyObject* py_setdiff_check(PyObject* self, PyObject* args) {
+    PyObject *a, *b;
+    if (!PyArg_ParseTuple(args, "OO", &a, &b)) return NULL;
+    int64_t* members = (int64_t*)PyMem_Malloc(sizeof(int64_t) * EMU_MAX_TABLE);
+    if (!members) return PyErr_NoMemory();
+    const Py_ssize_t n = emu_difference(a, b, members, EMU_MAX_TABLE, NULL, 0);
+    PyObject* out;
+    if (n < 0) {
+        out = Py_None;
+        Py_INCREF(out);
+    } else {
+        out = PyList_New(n);
+        for (Py_ssize_t i = 0; out && i < n; ++i) PyList_SET_ITEM(out, i, PyLong_FromLongLong(members[i]));
+    }
+    PyMem_Free(members);
+    return out;
+}
+
 /* cbrs_sample(class_index_cache: dict[label -> set[int]], excluded: set | None, n_smp_cls: int, state, out[, versions, token[, verify]])
  * -> number of picks.  out: writable buffer of int64; raises if it is too small.  versions: int64 buffer indexed by label.
  * verify (default 1): compare the live set's checksum before a memoised order is used.  The comparison walks the set's whole hash table --
  * 256 - 512 entries for ~50 members once update_cache has churned the sets for a few hundred steps -- and was most of the call by then
  * (profiles/r6_cbrs_drift_cpu.txt: 163 -> 279 us per draw over 1600 steps with it, 68 -> 85 us without); a caller whose every mutation goes
- * through update_cache (the ASER plugins) passes 0 and verifies now and then. */
+ * through update_cache (the ASER plugins) passes 0 and verifies now and then.
+ * emulate (default 0): a draw with exclusions takes the order of `slots - excluded` from emu_difference where that applies. */
 static PyObject* py_cbrs_sample(PyObject* self, PyObject* args) {
     PyObject *cache, *excluded;
     long long n_smp, token = 0;
-    int verify = 1;
+    int verify = 1, emulate = 0;
+    unsigned char* exmap = NULL;
+    Py_ssize_t exmap_n = 0;
     Py_buffer sb, ob, vb;
     vb.buf = NULL; vb.obj = NULL; vb.len = 0;
-    if (!PyArg_ParseTuple(args, "O!OLw*w*|y*Li", &PyDict_Type, &cache, &excluded, &n_smp, &sb, &ob, &vb, &token, &verify)) return NULL;
+    if (!PyArg_ParseTuple(args, "O!OLw*w*|y*Lii", &PyDict_Type, &cache, &excluded, &n_smp, &sb, &ob, &vb, &token, &verify, &emulate)) return NULL;
     MtState* s;
     PyObject* result = NULL;
     PyObject* empty = NULL;
@@ -160,6 +250,24 @@ static PyObject* py_cbrs_sample(PyObject* self, PyObject* args) {
         goto done;
     }
     if (n_smp < 0) n_smp = 0;
+    if (emulate && PyAnySet_CheckExact(excluded) && PySet_GET_SIZE(excluded) > 0) {   /* membership map of the excluded slots */
+        Py_ssize_t pos = 0, top = -1;
+        PyObject* item;
+        Py_hash_t h;
+        int plain = 1;
+        while (_PySet_NextEntry(excluded, &pos, &item, &h)) {
+            if (!PyLong_CheckExact(item) || h < 0 || h >= (1 << 24)) { plain = 0; break; }
+            if (h > top) top = h;
+        }
+        if (plain && top >= 0) {
+            exmap = (unsigned char*)PyMem_Calloc((size_t)top + 1, 1);
+            if (exmap) {
+                exmap_n = top + 1;
+                pos = 0;
+                while (_PySet_NextEntry(excluded, &pos, &item, &h)) exmap[h] = 1;
+            }
+        }
+    }
     {
         const int64_t* versions = (const int64_t*)vb.buf;
         const Py_ssize_t n_versions = vb.buf ? vb.len / (Py_ssize_t)sizeof(int64_t) : 0;
@@ -202,6 +310,28 @@ static PyObject* py_cbrs_sample(PyObject* self, PyObject* args) {
                         continue;
                     }
                     memo_version = versions[label];
+                }
+            }
+            if (emulate && !memo) {   /* a draw with exclusions: the fresh set's order without the fresh set */
+                const Py_ssize_t need = PySet_GET_SIZE(slots);
+                if (need > cap) {
+                    cap = need * 2 + 64;
+                    int64_t* m2 = (int64_t*)PyMem_Realloc(members, sizeof(int64_t) * (size_t)cap);
+                    int64_t* p2 = m2 ? (int64_t*)PyMem_Realloc(perm, sizeof(int64_t) * (size_t)cap) : NULL;
+                    if (m2) members = m2;
+                    if (p2) perm = p2;
+                    if (!m2 || !p2) { PyErr_NoMemory(); goto done; }
+                }
+                const Py_ssize_t ne = emu_difference(slots, excluded, members, cap, exmap, exmap_n);
+                if (ne >= 0) {
+                    randperm(s, (int64_t)ne, perm);
+                    const Py_ssize_t take = ne < (Py_ssize_t)n_smp ? ne : (Py_ssize_t)n_smp;
+                    if (n_out + take > out_cap) {
+                        PyErr_SetString(PyExc_ValueError, "output buffer too small");
+                        goto done;
+                    }
+                    for (Py_ssize_t j = 0; j < take; ++j) out[n_out++] = members[perm[j]];
+                    continue;
                 }
             }
             PyObject* eligible = PyNumber_Subtract(slots, excluded);   /* a new set, exactly as `slots - excluded` */
@@ -249,6 +379,7 @@ static PyObject* py_cbrs_sample(PyObject* self, PyObject* args) {
         result = PyLong_FromSsize_t(n_out);
     }
 done:
+    PyMem_Free(exmap);
     PyMem_Free(members);
     PyMem_Free(perm);
     Py_XDECREF(empty);
@@ -261,6 +392,7 @@ done:
 static PyMethodDef methods[] = {
     {"cbrs_sample", py_cbrs_sample, METH_VARARGS, "class-balanced draw (see file header)"},
     {"randperm_check", py_randperm_check, METH_VARARGS, "the permutation the restated generator draws"},
+    {"setdiff_check", py_setdiff_check, METH_VARARGS, "the simulated iteration order of a - b (None: not simulated)"},
     {NULL, NULL, 0, NULL}};
 
 static struct PyModuleDef moddef = {PyModuleDef_HEAD_INIT, "_hostc", "host-side helpers (ASER class-balanced sampling)", -1, methods};

@@ -42,6 +42,48 @@ def _hostc_usable():
     return _hostc_ok
 
 
+_setdiff_ok = None
+_EMULATE = __import__("os").environ.get("OCL_CBRS_EMULATE", "1") != "0"   # (0: the draw with exclusions builds its sets, A/B)
+
+
+def _setdiff_emulation_ok():
+    """The C helper can produce the iteration order of `slots - excluded` without building that set (a simulation of CPython's set table,
+    csrc/hostc.c: emu_difference).  It is trusted only after it has reproduced list(a - b) on a few hundred sets of this interpreter --
+    fresh and churned, across the resize thresholds -- once per process; otherwise the real set operation is used (as before round 6)."""
+    global _setdiff_ok
+    if _setdiff_ok is None:
+        ok = _hostc is not None and hasattr(_hostc, "setdiff_check")
+        if ok:
+            import random
+            rnd = random.Random(20251)
+            seen = 0
+            for trial in range(400):
+                n = rnd.choice([0, 1, 4, 5, 18, 19, 20, 49, 50, 76, 77, 90, 200, 306, 307, 330])
+                a = set(rnd.sample(range(5000), n))
+                for _ in range(rnd.choice([0, 10, 120])):     # remove / add: dummies, tables larger than a fresh set's
+                    if a and rnd.random() < 0.5:
+                        a.discard(rnd.choice(tuple(a)))
+                    else:
+                        a.add(rnd.randrange(5000))
+                b = set(rnd.sample(range(5000), rnd.choice([1, 30, 100, 150])))
+                if a:
+                    b |= set(rnd.sample(tuple(a), min(len(a), rnd.randrange(0, 4))))
+                got = _hostc.setdiff_check(a, b)
+                if got is None:
+                    continue
+                seen += 1
+                if got != list(a - b):
+                    ok = False
+                    break
+            ok = ok and seen >= 100
+            if not ok:
+                import warnings
+                warnings.warn("ocl_amd: _hostc's simulation of CPython's set difference disagrees with this interpreter; the class-balanced "
+                              "draw with exclusions builds the sets")
+        _setdiff_ok = ok
+    return _setdiff_ok
+
+
 def _host_labels(y, y_host=None):
     if y_host is not None:
         return np.asarray(y_host).astype(np.int64)
@@ -167,7 +209,8 @@ class ClassBalancedRandomSampling:
         try:
             ClassBalancedRandomSampling._draws += 1
             verify = 1 if cls.verify_every <= 1 or ClassBalancedRandomSampling._draws % cls.verify_every == 0 else 0
-            n = _hostc.cbrs_sample(cache, excl_indices, int(n_smp_cls), state.numpy(), cls._scratch, cls._versions, cls._token, verify)
+            emulate = 1 if (excl_indices and _EMULATE and _setdiff_emulation_ok()) else 0
+            n = _hostc.cbrs_sample(cache, excl_indices, int(n_smp_cls), state.numpy(), cls._scratch, cls._versions, cls._token, verify, emulate)
         except Exception:
             # the C helper gave up midway (a class set holding a non-integer, out of memory): the generator has not been touched yet
             # -- it is set only below -- so the Python loop replays the draw from the state this call started with

