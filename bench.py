@@ -299,6 +299,10 @@ def gpu_leg(args, rank, world, local, workload=None, steps=None, warmup=None):
 # ---- accuracy leg ("final avg accuracy" half of BASELINE.json's metric) -----------------------------------------------------
 ACC_CFG = dict(n_tasks=10, classes_per_task=10, n_train=50, n_test=10, blend=0.3, seeds=3)
 ACC_STREAMS = ("noise_prototype", "smooth_prototype", "texture_prototype")
+# accuracy.aser: BASELINE configs[2] (ER + ASER retrieve / update) with a memory the stream FILLS early -- 500 slots on 2000 images (10 tasks x 10
+# classes x 20) -- so that 150 of the 200 steps run the Shapley-valued retrieval and replacement (with configs[2]'s 5000 slots the 5000-image
+# accuracy stream would never leave the uniform fill phase: aser_retrieve.py:24-26, aser_update.py:27-36)
+ACC_ASER = dict(mem_size=500, n_train=20)
 
 
 def _upsample(grid, hw):
@@ -451,8 +455,8 @@ def accuracy_leg(args, rank, world, local):
     # the oracle's runs
     runs, ev_ms, wall = [], [], 0.0
     for seed in seeds:
-        tasks, tests = accuracy_stream(seed, c["n_tasks"], c["classes_per_task"], c["n_train"], c["n_test"], c["blend"], kind="texture_prototype")
-        params = make_params(dict(WORKLOADS["aser"], num_tasks=c["n_tasks"]))
+        tasks, tests = accuracy_stream(seed, c["n_tasks"], c["classes_per_task"], ACC_ASER["n_train"], c["n_test"], c["blend"], kind="texture_prototype")
+        params = make_params(dict(WORKLOADS["aser"], num_tasks=c["n_tasks"], mem_size=ACC_ASER["mem_size"]))
         t0 = time.perf_counter()
         acc, tt, n_img, ag = single_run(params, tasks, tests, seed)
         wall += time.perf_counter() - t0
@@ -463,7 +467,9 @@ def accuracy_leg(args, rank, world, local):
         accs, _ = odist.gather_runs(runs[0], device=device)
     out["aser"] = dict(hip=dict(summarise_accuracy(accs), runs=int(accs.shape[0]), wall_s=wall, end_acc_per_run=[float(a[-1].mean()) for a in accs],
                                 evaluate_ms=dict(mean=float(np.mean(ev_ms)), last_task=float(np.mean(ev_ms[c["n_tasks"] - 1::c["n_tasks"]])))),
-                       stream="texture_prototype", config="BASELINE.json configs[2]: ER, retrieve ASER, update ASER, mem_size 5000, k 3, n_smp_cls 1.5, softmax classifier")
+                       stream="texture_prototype, %d images per class" % ACC_ASER["n_train"],
+                       config="BASELINE.json configs[2] (ER, retrieve ASER, update ASER, k 3, n_smp_cls 1.5, softmax classifier) with mem_size %d: the memory is full "
+                              "after 50 of the 200 steps, the other 150 run the Shapley-valued retrieval and replacement" % ACC_ASER["mem_size"])
     out["stream"] = ("%d tasks x %d classes, %d train / %d test images per class; SCR random/random, mem_size 5000, eps_mem_batch 100, temp 0.07, "
                      "NCM classifier; %d runs, seeds = --seed + rank + 100 * run; noise_prototype: class prototype (white noise) blended %.0f%% "
                      "with white noise; smooth_prototype: smooth 4x4-grid prototype, 30%% + 70%% smooth per-image field + pixel noise; "
@@ -478,8 +484,11 @@ def accuracy_oracle_worker(seed, kind, threads, workload="scr"):
     from oracle import ocl_oracle as O
     import random
     c = ACC_CFG
-    tasks, tests = accuracy_stream(seed, c["n_tasks"], c["classes_per_task"], c["n_train"], c["n_test"], c["blend"], kind=kind)
+    aser = workload == "aser"
+    tasks, tests = accuracy_stream(seed, c["n_tasks"], c["classes_per_task"], ACC_ASER["n_train"] if aser else c["n_train"], c["n_test"], c["blend"], kind=kind)
     cfg = dict(WORKLOADS[workload], seed=seed, tasks=[[0]] * c["n_tasks"], n_train=0, n_test=0)
+    if aser:
+        cfg["mem_size"] = ACC_ASER["mem_size"]
     np.random.seed(seed)
     random.seed(seed)
     torch.manual_seed(seed)
