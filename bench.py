@@ -302,7 +302,13 @@ ACC_STREAMS = ("noise_prototype", "smooth_prototype", "texture_prototype")
 # accuracy.aser: BASELINE configs[2] (ER + ASER retrieve / update) with a memory the stream FILLS early -- 500 slots on 2000 images (10 tasks x 10
 # classes x 20) -- so that 150 of the 200 steps run the Shapley-valued retrieval and replacement (with configs[2]'s 5000 slots the 5000-image
 # accuracy stream would never leave the uniform fill phase: aser_retrieve.py:24-26, aser_update.py:27-36)
-ACC_ASER = dict(mem_size=500, n_train=20)
+ACC_ASER = dict(mem_size=500, n_train=20, extra_seeds=2)
+
+
+def aser_seeds(seeds):
+    """The accuracy leg's seeds + two more (short runs: five of them narrow the comparison of two free-running distributions)."""
+    seeds = list(seeds)
+    return seeds + [seeds[-1] + 100 * (i + 1) for i in range(ACC_ASER["extra_seeds"])]
 
 
 def _upsample(grid, hw):
@@ -454,7 +460,7 @@ def accuracy_leg(args, rank, world, local):
     # BASELINE configs[2] (ER + ASER retrieve / update, softmax classifier, no augmentation on either side): the texture stream, same seeds as
     # the oracle's runs
     runs, ev_ms, wall = [], [], 0.0
-    for seed in seeds:
+    for seed in aser_seeds(seeds):
         tasks, tests = accuracy_stream(seed, c["n_tasks"], c["classes_per_task"], ACC_ASER["n_train"], c["n_test"], c["blend"], kind="texture_prototype")
         params = make_params(dict(WORKLOADS["aser"], num_tasks=c["n_tasks"], mem_size=ACC_ASER["mem_size"]))
         t0 = time.perf_counter()
@@ -517,8 +523,8 @@ def accuracy_oracle_start(seeds, threads):
                                       stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=dict(os.environ, OMP_NUM_THREADS=str(threads)))
              for k in ACC_STREAMS for s in todo[k]}
     # ER + ASER (configs[2]) on the texture stream, every seed: three more concurrent runs
-    todo["aser"] = list(seeds)
-    for s in seeds:
+    todo["aser"] = aser_seeds(seeds)
+    for s in todo["aser"]:
         procs[("aser", s)] = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--oracle-accuracy-worker", str(s), "texture_prototype", str(threads), "aser"],
                                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=dict(os.environ, OMP_NUM_THREADS=str(threads)))
     return procs, todo, t0, threads
@@ -752,7 +758,10 @@ def main():
                 h, o = acc_res["aser"]["hip"], orc["aser"]
                 acc_res["aser"]["cpu_oracle"] = dict(avg_end_acc=o["avg_end_acc"], runs=o["runs"], seeds=o["seeds"])
                 acc_res["aser"]["summary"] = dict(abs_diff_avg_end_acc_vs_oracle=abs(h["avg_end_acc"]["mean"] - o["avg_end_acc"]["mean"]),
-                                                  oracle_spread_over_seeds=(max(o["end_acc_per_run"]) - min(o["end_acc_per_run"])) if o["runs"] > 1 else None)
+                                                  oracle_spread_over_seeds=(max(o["end_acc_per_run"]) - min(o["end_acc_per_run"])) if o["runs"] > 1 else None,
+                                                  # (free-running runs diverge step by step -- fp32 rounding, then other retrievals -- so the two columns agree
+                                                  # as distributions, not run by run; the per-step agreement is the co-simulation tests')
+                                                  end_acc_per_seed=dict(hip=[round(v, 4) for v in h["end_acc_per_run"]], cpu_oracle=[round(v, 4) for v in o["end_acc_per_run"]]))
                 orc.pop("aser", None)
         if "aser" in acc_res:
             acc_res["aser"]["hip"].pop("end_acc_per_run", None)
