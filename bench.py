@@ -302,11 +302,11 @@ ACC_STREAMS = ("noise_prototype", "smooth_prototype", "texture_prototype")
 # accuracy.aser: BASELINE configs[2] (ER + ASER retrieve / update) with a memory the stream FILLS early -- 500 slots on 2000 images (10 tasks x 10
 # classes x 20) -- so that 150 of the 200 steps run the Shapley-valued retrieval and replacement (with configs[2]'s 5000 slots the 5000-image
 # accuracy stream would never leave the uniform fill phase: aser_retrieve.py:24-26, aser_update.py:27-36)
-ACC_ASER = dict(mem_size=500, n_train=20, extra_seeds=2)
+ACC_ASER = dict(mem_size=500, n_train=20, extra_seeds=0, oracle_threads=4)   # (five seeds both sides lengthened the default run by 1.5 minutes: scripts/aser_accuracy_probe.py has them)
 
 
 def aser_seeds(seeds):
-    """The accuracy leg's seeds + two more (short runs: five of them narrow the comparison of two free-running distributions)."""
+    """The accuracy leg's seeds (+ ACC_ASER["extra_seeds"] more)."""
     seeds = list(seeds)
     return seeds + [seeds[-1] + 100 * (i + 1) for i in range(ACC_ASER["extra_seeds"])]
 
@@ -525,8 +525,9 @@ def accuracy_oracle_start(seeds, threads):
     # ER + ASER (configs[2]) on the texture stream, every seed: three more concurrent runs
     todo["aser"] = aser_seeds(seeds)
     for s in todo["aser"]:
-        procs[("aser", s)] = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--oracle-accuracy-worker", str(s), "texture_prototype", str(threads), "aser"],
-                                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=dict(os.environ, OMP_NUM_THREADS=str(threads)))
+        ta = ACC_ASER["oracle_threads"]   # (short runs, half of them Python loops: fewer threads, less contention with the SCR oracles)
+        procs[("aser", s)] = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--oracle-accuracy-worker", str(s), "texture_prototype", str(ta), "aser"],
+                                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=dict(os.environ, OMP_NUM_THREADS=str(ta)))
     return procs, todo, t0, threads
 
 
