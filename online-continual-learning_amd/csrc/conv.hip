@@ -1144,10 +1144,15 @@ __global__ void __launch_bounds__(256, NT == 1 ? 5 : 4) conv_s_kernel(const Conv
         const int C = a.Cin;
         const double M = (double)a.xf_m_per_group;
         const bool lead = blockIdx.x == 0 && blockIdx.y == 0;
-        for (int j = tid; j < a.groups * C; j += 256) {
+        // A tile lies inside one BatchNorm group (d1.y) and stage_store reads that group's rows only: the ~2000 workgroups of a layer-4
+        // launch each build ONE group's table, two replica loads in flight per thread (every group's with one load in flight was 16
+        // dependent L2 round trips per entry and two entries per thread: 6.4 us of a 32 us launch, profiles/r6_convs_xf_prologue_ab.txt);
+        // the lead workgroup builds every group's (it saves mean / invstd for the backward).
+        const int j_end = lead ? a.groups * C : (d1.y + 1) * C;
+        for (int j = (lead ? 0 : d1.y * C) + tid; j < j_end; j += 256) {
             const int gq = j / C, c = j - gq * C;
             double mean, var;
-            bn_batch_moments<1, FXM>(a.xf_stats, a.xf_rep_stride, gq, c, C, M, a.xf_eps, mean, var);
+            bn_batch_moments<2, FXM>(a.xf_stats, a.xf_rep_stride, gq, c, C, M, a.xf_eps, mean, var);
             const double xv = var + (double)a.xf_eps;
             double invstd = (double)rsqrtf((float)xv);
             invstd = invstd * (1.5 - 0.5 * xv * invstd * invstd);
