@@ -788,6 +788,20 @@ int ocl_net_bind(ocl_net* net, float* params, float* grads, float* running, int6
 // inside the BatchNorm kernels (once per group, in group order = the reference's separate forward calls).  side: the projection
 // shortcuts run on the engine's second stream.  frozen: BatchNorm normalises with the running statistics (eval-mode tape).
 // -----------------------------------------------------------------------------------------------------
+// Measurement only, like OCL_DEBUG_SKIP_WGRAD (results are WRONG with either set; scripts/gpu_r6bb.sh): upper bounds of what two launch
+// folds the reviews asked for could return -- OCL_DEBUG_SKIP_BN2FWD=1: no bn_fwd_kernel launch behind conv2 of the seven non-final blocks
+// (the fold of bn2 + residual + ReLU into the next conv1's staging would still have to read y2 and the residual and write z there);
+// OCL_DEBUG_SKIP_SHORTCUT=1: no projection-shortcut convolution, data gradient or weight gradient (the fold into the block's 3x3
+// stride-2 convolution keeps their arithmetic).
+static bool dbg_skip_bn2fwd() {
+    static const bool v = [] { const char* e = getenv("OCL_DEBUG_SKIP_BN2FWD"); return e && e[0] == '1'; }();
+    return v;
+}
+static bool dbg_skip_shortcut() {
+    static const bool v = [] { const char* e = getenv("OCL_DEBUG_SKIP_SHORTCUT"); return e && e[0] == '1'; }();
+    return v;
+}
+
 static int trunk_forward_train(ocl_net* n, PlanSet* ps, const float* P, float* S, int Nc, int G, bool upd, float* feat, hipStream_t st,
                                bool side = false, bool frozen = false, bool fuse = false) {
     const int img0 = 0, g0 = 0;
@@ -860,7 +874,7 @@ static int trunk_forward_train(ocl_net* n, PlanSet* ps, const float* P, float* S
             hipStream_t ss = side ? n->s2 : st;
             if (side && (rc = side_wait(n, st))) return rc;       // `cur` (and the zeroed statistics) are ready
             // (its BatchNorm is applied by the block's last BatchNorm launch below: z = relu(bn2(y2) + bn_s(ys)), one launch for both)
-            if ((rc = conv_stats(b.convs, cur, ss))) return rc;
+            if (!dbg_skip_shortcut() && (rc = conv_stats(b.convs, cur, ss))) return rc;
             res = nullptr;
         }
         if ((rc = conv_stats(b.conv1, cur, st))) return rc;
@@ -886,7 +900,7 @@ static int trunk_forward_train(ocl_net* n, PlanSet* ps, const float* P, float* S
             if ((rc = conv_stats(b.conv2, a1, st))) return rc;
         }
         if (b.convs >= 0 && side && (rc = side_join(n, st))) return rc;
-        if ((rc = bn_fwd(b.conv2, at(c2.y_off, c2), z, res, 1, st, b.convs))) return rc;
+        if (!(dbg_skip_bn2fwd() && &b != &n->blocks.back()) && (rc = bn_fwd(b.conv2, at(c2.y_off, c2), z, res, 1, st, b.convs))) return rc;
         cur = z;
     }
     if (!feat) return OCL_OK;   // (a pass run for its running-statistic updates alone)
@@ -1317,7 +1331,7 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
         if (stop_here(bi, 1)) return OCL_OK;                                 // gB = dL/dy2, gC = dL/dys
         if ((rc = publish())) return rc;
         if (b.convs >= 0) {
-            if ((rc = wgrad(b.convs, xin, gC))) return rc;
+            if (!dbg_skip_shortcut() && (rc = wgrad(b.convs, xin, gC))) return rc;
             if ((rc = release(rC))) return rc;                               // (the shortcut's dgrad below reads gC on `s`)
         }
         if ((rc = fused ? wgrad(b.conv2, at(c1.y_off, c1), gB, b.conv1) : wgrad(b.conv2, a1, gB))) return rc;
@@ -1342,7 +1356,7 @@ static int trunk_backward(ocl_net* n, PlanSet* ps, const float* P, float* Gr, fl
         if (b.convs >= 0) {
             if ((rc = dgrad(b.conv1, gB1, gE, nullptr, nullptr, 0))) return rc;
             if (stop_here(bi, 4)) return OCL_OK;
-            if ((rc = dgrad(b.convs, gC, gE, nullptr, nullptr, EPI_ACCUM))) return rc;
+            if (!dbg_skip_shortcut() && (rc = dgrad(b.convs, gC, gE, nullptr, nullptr, EPI_ACCUM))) return rc;
         } else {
             // + identity shortcut: dz * (z>0).  Stage 2 (small passes, get_plans): this launch completes dL/dz of the block in front (of the stem for
             // block 0), so its epilogue also masks that gradient with (xin > 0) and sums it for the BatchNorm behind xin

@@ -318,10 +318,23 @@ __global__ void __launch_bounds__(256) supcon_rows(const float* __restrict__ fea
     for (int d = threadIdx.x; d < dim; d += blockDim.x) fi[d] = feat[(int64_t)i * dim + d];
     __syncthreads();
     float m = -INFINITY;
+    const bool vec = (dim & 3) == 0 && (((uintptr_t)feat) & 15) == 0;
     for (int j = threadIdx.x; j < A; j += blockDim.x) {
         const float* fj = feat + (int64_t)j * dim;
         float dot = 0.f;
-        for (int d = 0; d < dim; ++d) dot = fmaf(fi[d], fj[d], dot);
+        if (vec) {   // 16-byte loads, four independent chains (one chain of `dim` FMAs behind 4-byte loads was most of this kernel's 10 us)
+            const float4* fj4 = (const float4*)fj;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 8
+            for (int d4 = 0; d4 < (dim >> 2); ++d4) {
+                const float4 v = fj4[d4];
+                const float4 e = *(const float4*)(fi + 4 * d4);
+                a0 = fmaf(e.x, v.x, a0); a1 = fmaf(e.y, v.y, a1); a2 = fmaf(e.z, v.z, a2); a3 = fmaf(e.w, v.w, a3);
+            }
+            dot = (a0 + a1) + (a2 + a3);
+        } else {
+            for (int d = 0; d < dim; ++d) dot = fmaf(fi[d], fj[d], dot);
+        }
         const float l = dot / T;
         lg[j] = l;
         m = fmaxf(m, l);  // reference takes the max over the full row, diagonal included (loss.py:71)
@@ -368,23 +381,38 @@ __global__ void __launch_bounds__(128) supcon_grad(const float* __restrict__ fea
         for (int j = threadIdx.x; j < A; j += blockDim.x) cf[j] = G[(int64_t)i * A + j] + G[(int64_t)j * A + i];
         __syncthreads();
         for (int d = threadIdx.x; d < dim; d += blockDim.x) {
-            // four independent chains (a single chain of A = 220 dependent FMAs behind their loads was 18 us of the SCR step's chain)
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            // sixteen independent chains, sixteen loads in flight (a single chain of A = 220 dependent FMAs behind their loads was 18 us of
+            // the SCR step's chain; four chains = 55 dependent L2 round trips: 17 us)
+            float acc[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) acc[k] = 0.f;
             int j = 0;
-            for (; j + 4 <= A; j += 4) {
-                a0 = fmaf(cf[j], feat[(int64_t)j * dim + d], a0);
-                a1 = fmaf(cf[j + 1], feat[(int64_t)(j + 1) * dim + d], a1);
-                a2 = fmaf(cf[j + 2], feat[(int64_t)(j + 2) * dim + d], a2);
-                a3 = fmaf(cf[j + 3], feat[(int64_t)(j + 3) * dim + d], a3);
+            for (; j + 16 <= A; j += 16) {
+                float v[16];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) v[k] = feat[(int64_t)(j + k) * dim + d];
+#pragma unroll
+                for (int k = 0; k < 16; ++k) acc[k] = fmaf(cf[j + k], v[k], acc[k]);
             }
-            for (; j < A; ++j) a0 = fmaf(cf[j], feat[(int64_t)j * dim + d], a0);
-            dfeat[(int64_t)i * dim + d] = ((a0 + a1) + (a2 + a3)) / T;
+            for (; j < A; ++j) acc[j & 15] = fmaf(cf[j], feat[(int64_t)j * dim + d], acc[j & 15]);
+#pragma unroll
+            for (int st = 8; st > 0; st >>= 1)
+#pragma unroll
+                for (int k = 0; k < st; ++k) acc[k] += acc[k + st];
+            dfeat[(int64_t)i * dim + d] = acc[0] / T;
         }
     }
-    if (i == 0 && threadIdx.x == 0) {
-        float s = 0.f;
-        for (int j = 0; j < A; ++j) s += rowloss[j];
-        loss_out[0] = s / (float)A;
+    if (i == 0) {   // mean of the row losses: every thread a strided share, then a tree over the workgroup (was one thread, A dependent steps)
+        __syncthreads();   // (cf is free again)
+        float t = 0.f;
+        for (int j = threadIdx.x; j < A; j += blockDim.x) t += rowloss[j];
+        cf[threadIdx.x] = t;
+        __syncthreads();
+        for (int st = blockDim.x >> 1; st > 0; st >>= 1) {
+            if ((int)threadIdx.x < st) cf[threadIdx.x] += cf[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) loss_out[0] = cf[0] / (float)A;
     }
 }
 
@@ -1030,7 +1058,7 @@ int ocl_supcon_fwd_bwd(const float* feat, const int64_t* y, int bsz, int n_views
     const size_t sm = (size_t)(dim + A + 16) * sizeof(float);
     hipLaunchKernelGGL(supcon_rows, dim3(A), dim3(256), sm, s, feat, y, bsz, A, dim, temperature, G, rowloss);
     OCL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(supcon_grad, dim3(dfeat ? A : 1), dim3(128), (size_t)A * sizeof(float), s, feat, A, dim, temperature, G, rowloss,
+    hipLaunchKernelGGL(supcon_grad, dim3(dfeat ? A : 1), dim3(128), (size_t)std::max(A, 128) * sizeof(float), s, feat, A, dim, temperature, G, rowloss,
                        loss_out, dfeat);
     OCL_LAUNCH_CHECK();
     return OCL_OK;
