@@ -2150,17 +2150,31 @@ __global__ void __launch_bounds__(256) pack_weights_kernel(const float* __restri
         return;
     }
     PackDesc d = descs[blockIdx.y];
-    // the scattered stores are the cost of this kernel: a pass writes only the packs it reads (PACK_* bits)
+    // a pass writes only the packs it reads (PACK_* bits).  The threads walk the PACKS in storage order -- rows of Cout x 4 (forward) /
+    // Cin x 4 (data gradient) consecutive floats, coalesced stores -- and gather from the OIHW tensor (read-only, 36-byte strides: served by
+    // L2); walking the tensor and scattering 4-byte stores into both packs was 13 us at the head of every step's chain.  Padding rows /
+    // columns of a pack are never written (zero since the arena was created).
     if (!(mask & PACK_TF)) d.tf_off = -1;
     if (!(mask & PACK_TD)) d.td_off = -1;
-    const int total = d.Cout * d.Cin * d.ntaps;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-        const int co = e / (d.Cin * d.ntaps);
-        const int rem = e - co * d.Cin * d.ntaps;
-        const int ci = rem / d.ntaps, t = rem - ci * d.ntaps;
-        const float v = params[d.w_off + e];
-        if (d.tf_off >= 0) arena[d.tf_off + ((((int64_t)t * (d.CinP >> 2) + (ci >> 2)) * d.CoutP + co) << 2) + (ci & 3)] = v;
-        if (d.td_off >= 0) arena[d.td_off + ((((int64_t)t * (d.Cout >> 2) + (co >> 2)) * d.CiP + ci) << 2) + (co & 3)] = v;
+    const int ci4n = (d.Cin + 3) >> 2;
+    const int nF = d.tf_off >= 0 ? d.ntaps * ci4n * d.Cout * 4 : 0;
+    const int nD = d.td_off >= 0 ? d.ntaps * d.Cout * d.Cin : 0;   // (Cout is a multiple of 4)
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nF + nD; e += gridDim.x * blockDim.x) {
+        if (e < nF) {   // [t][ci >> 2][co][ci & 3]
+            const int k = e & 3, r = e >> 2;
+            const int co = r % d.Cout, r2 = r / d.Cout;
+            const int c4 = r2 % ci4n, t = r2 / ci4n;
+            const int ci = c4 * 4 + k;
+            if (ci < d.Cin)
+                arena[d.tf_off + ((((int64_t)t * (d.CinP >> 2) + c4) * d.CoutP + co) << 2) + k] = params[d.w_off + ((int64_t)co * d.Cin + ci) * d.ntaps + t];
+        } else {        // [t][co >> 2][ci][co & 3]
+            const int f = e - nF;
+            const int k = f & 3, r = f >> 2;
+            const int ci = r % d.Cin, r2 = r / d.Cin;
+            const int o4 = r2 % (d.Cout >> 2), t = r2 / (d.Cout >> 2);
+            const int co = o4 * 4 + k;
+            arena[d.td_off + ((((int64_t)t * (d.Cout >> 2) + o4) * d.CiP + ci) << 2) + k] = params[d.w_off + ((int64_t)co * d.Cin + ci) * d.ntaps + t];
+        }
     }
 }
 
@@ -2169,7 +2183,7 @@ int launch_pack_weights(const float* params, float* arena, const PackDesc* descs
     ProfScope ps(PROF_BN, s);
     const int extra = (zero_a_n + zero_b_n) > 0 ? 1 : 0;
     // (up to 256 workgroups per layer: layer 4's 230 k weights in 4 passes per thread instead of 14)
-    hipLaunchKernelGGL(pack_weights_kernel, dim3(std::min(256, cdiv(max_elems, 256)), n_layers + extra), dim3(256), 0, s, params, arena,
+    hipLaunchKernelGGL(pack_weights_kernel, dim3(std::min(512, cdiv(2 * max_elems, 256)), n_layers + extra), dim3(256), 0, s, params, arena,
                        descs_dev, mask, n_layers, zero_a, zero_a_n, zero_b, zero_b_n);
     OCL_LAUNCH_CHECK();
     return OCL_OK;
