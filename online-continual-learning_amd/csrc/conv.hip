@@ -2548,6 +2548,10 @@ __global__ void __launch_bounds__(256) bn_bwd_apply_kernel(const BnBwdArgs a) {
 constexpr int kBnFusedThreads = 512;
 // accumulator replicas (same-address returning atomics serialise at the coherence point: 256 workgroups on one address cost ~20 us)
 constexpr int kBnFusedReps = 8;
+#ifndef OCL_BN_FLAT
+#define OCL_BN_FLAT 40
+#endif
+constexpr int kBnFusedFlat = OCL_BN_FLAT;   // grids up to this size arrive at one counter
 // NS = 2: the two BatchNorms of a projection block (main path + shortcut) share the masked gradient dz; their outputs differ only
 // in xhat.  One launch reads dz, z, y_a, y_b and writes dy_a, dy_b (6 tensor passes, one grid arrival) instead of reduce + apply
 // (10 passes, 2 launches).  The sum of the masked gradient is the same for both; each BatchNorm's arena receives it with its own
@@ -2651,8 +2655,11 @@ __global__ void __launch_bounds__(kBnFusedThreads) bn_bwd_fused_kernel(const BnB
         // arrival of each sub-counter reports to the master counter a.barrier[0]
         const unsigned sub = blockIdx.x % kBnFusedReps;
         const unsigned members = (gridDim.x - sub + kBnFusedReps - 1) / kBnFusedReps;
-        const unsigned groups_total = gridDim.x < (unsigned)kBnFusedReps ? gridDim.x : (unsigned)kBnFusedReps;
-        if (__hip_atomic_fetch_add(a.barrier + 1 + sub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1)
+        // (replay-sized passes run 8 - 33 workgroups: they arrive at the master counter directly -- one device-scope round trip less in a
+        // kernel that is nothing but such round trips there, profiles/r6_bn_flat_arrival_ab.txt)
+        const bool flat = gridDim.x <= (unsigned)kBnFusedFlat;
+        const unsigned groups_total = flat ? gridDim.x : (unsigned)kBnFusedReps;
+        if (flat || __hip_atomic_fetch_add(a.barrier + 1 + sub, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == members - 1)
             __hip_atomic_fetch_add(a.barrier, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         int spins = 0;
         while (__hip_atomic_load(a.barrier, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < groups_total && ++spins < (1 << 22))
