@@ -2717,6 +2717,135 @@ __global__ void __launch_bounds__(kBnFusedThreads) bn_bwd_fused_kernel(const BnB
     }
 }
 
+// BatchNorm backward of a SMALL map (layer 4 of a replay-sized pass), partitioned by CHANNEL: one workgroup
+// owns one channel quad for every pixel of every group, so its batch sums need nobody else -- no atomics, no grid-wide arrival, no replicas
+// to read back.  bn_bwd_fused_kernel on such a map is five dependent device-scope round trips (10.8 - 12.5 us for a few hundred KB); here:
+// one strided read of dz, z, y (16 bytes per lane at a stride of C floats), a wave butterfly + the wave totals in fp64 in a fixed order
+// (deterministic), the apply from registers: 6.7 - 8.4 us at one unit per thread (profiles/r6_bn_chan_ab.txt; at four units per thread --
+// layer 3 of a 20-image pass on 20 workgroups -- it LOSES to the one-pass kernel, hence the size gate in launch_bn_bwd).  Two groups split
+// the workgroup's threads (the two-group replay pass of ER: 10 + 10 images).  NS as bn_bwd_fused_kernel.
+constexpr int kBnChanThreads = 512;
+template <int E, int NS>
+__global__ void __launch_bounds__(kBnChanThreads) bn_bwd_chan_kernel(const BnBwdArgs a) {
+    constexpr int NW = kBnChanThreads / 64;
+    __shared__ double wred[1 + NS][4][NW];
+    __shared__ double tot[2][1 + NS][4];
+    __shared__ float kk[2][1 + NS][4];
+    const int c4 = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C4 = a.C >> 2;
+    const int T = kBnChanThreads / a.G;           // threads per group (G = 1 or 2)
+    const int g = tid / T, pt = tid - g * T;
+    const int64_t M = a.m_per_group;
+    const float4 f4z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int64_t base = (int64_t)g * M * C4 + c4;
+    float4 d[E], xh[NS][E], zz[E];
+    float4 sd = f4z, sx[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) sx[k] = f4z;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        const int64_t pix = pt + (int64_t)e * T;
+        const bool in = pix < M;
+        const int64_t u = base + (in ? pix : 0) * C4;
+        d[e] = ((const float4*)a.dz)[u];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) xh[k][e] = ((const float4*)a.y[k])[u];
+        zz[e] = a.z ? ((const float4*)a.z)[u] : make_float4(1.f, 1.f, 1.f, 1.f);
+        if (!in) d[e] = f4z;
+    }
+    if (a.mask_from_y) {   // (the arithmetic of the staging kernels, as in bn_bwd_fused_kernel)
+        const float4 gm = *(const float4*)(a.gamma[0] + c4 * 4), bt = *(const float4*)(a.beta[0] + c4 * 4);
+        const float4 mn = *(const float4*)(a.mean[0] + (int64_t)g * a.C + c4 * 4), is = *(const float4*)(a.invstd[0] + (int64_t)g * a.C + c4 * 4);
+        float4 sc, sh;
+        bn_scale_shift(gm.x, bt.x, mn.x, is.x, sc.x, sh.x); bn_scale_shift(gm.y, bt.y, mn.y, is.y, sc.y, sh.y);
+        bn_scale_shift(gm.z, bt.z, mn.z, is.z, sc.z, sh.z); bn_scale_shift(gm.w, bt.w, mn.w, is.w, sc.w, sh.w);
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+            zz[e] = make_float4(__fmaf_rn(xh[0][e].x, sc.x, sh.x), __fmaf_rn(xh[0][e].y, sc.y, sh.y), __fmaf_rn(xh[0][e].z, sc.z, sh.z),
+                                __fmaf_rn(xh[0][e].w, sc.w, sh.w));
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+        d[e].x = zz[e].x > 0.f ? d[e].x : 0.f; d[e].y = zz[e].y > 0.f ? d[e].y : 0.f;
+        d[e].z = zz[e].z > 0.f ? d[e].z : 0.f; d[e].w = zz[e].w > 0.f ? d[e].w : 0.f;
+        sd.x += d[e].x; sd.y += d[e].y; sd.z += d[e].z; sd.w += d[e].w;
+    }
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const float4 mean = *(const float4*)(a.mean[k] + (int64_t)g * a.C + c4 * 4);
+        const float4 istd = *(const float4*)(a.invstd[k] + (int64_t)g * a.C + c4 * 4);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            xh[k][e].x = (xh[k][e].x - mean.x) * istd.x; xh[k][e].y = (xh[k][e].y - mean.y) * istd.y;
+            xh[k][e].z = (xh[k][e].z - mean.z) * istd.z; xh[k][e].w = (xh[k][e].w - mean.w) * istd.w;
+            sx[k].x = fmaf(d[e].x, xh[k][e].x, sx[k].x); sx[k].y = fmaf(d[e].y, xh[k][e].y, sx[k].y);
+            sx[k].z = fmaf(d[e].z, xh[k][e].z, sx[k].z); sx[k].w = fmaf(d[e].w, xh[k][e].w, sx[k].w);
+        }
+    }
+    // wave butterfly in fp64 (a lane's partial covers <= E values; a wave lies inside one group), wave totals to LDS
+    auto wsum = [&](float v) __attribute__((always_inline)) -> double {
+        double t = (double)v;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        return t;
+    };
+    {
+        const double t0 = wsum(sd.x), t1 = wsum(sd.y), t2 = wsum(sd.z), t3 = wsum(sd.w);
+        if (lane == 0) { wred[0][0][wave] = t0; wred[0][1][wave] = t1; wred[0][2][wave] = t2; wred[0][3][wave] = t3; }
+    }
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const double t0 = wsum(sx[k].x), t1 = wsum(sx[k].y), t2 = wsum(sx[k].z), t3 = wsum(sx[k].w);
+        if (lane == 0) { wred[1 + k][0][wave] = t0; wred[1 + k][1][wave] = t1; wred[1 + k][2][wave] = t2; wred[1 + k][3][wave] = t3; }
+    }
+    __syncthreads();
+    if (tid < (1 + NS) * 4 * a.G) {
+        const int gg = tid / ((1 + NS) * 4), r = tid - gg * (1 + NS) * 4;
+        const int which = r >> 2, c = r & 3;
+        const int wpg = NW / a.G;
+        double t = 0.0;
+        for (int w = gg * wpg; w < (gg + 1) * wpg; ++w) t += wred[which][c][w];
+        tot[gg][which][c] = t;
+        kk[gg][which][c] = (float)(t / (double)M);
+    }
+    __syncthreads();
+    if (tid < (1 + NS) * 4) {   // dbeta = sum(d), dgamma_k = sum(d * xhat_k), over the groups in order
+        const int which = tid >> 2, c = tid & 3, ch = c4 * 4 + c;
+        double t = tot[0][which][c];
+        if (a.G == 2) t += tot[1][which][c];
+        if (which == 0) {
+#pragma unroll
+            for (int k = 0; k < NS; ++k) {
+                if (a.accumulate) a.dbeta[k][ch] += (float)t;
+                else a.dbeta[k][ch] = (float)t;
+            }
+        } else {
+            if (a.accumulate) a.dgamma[which - 1][ch] += (float)t;
+            else a.dgamma[which - 1][ch] = (float)t;
+        }
+    }
+    const float4 k1 = *(const float4*)&kk[g][0][0];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+        const float4 k2 = *(const float4*)&kk[g][1 + k][0];
+        const float4 gm = *(const float4*)(a.gamma[k] + c4 * 4);
+        const float4 istd = *(const float4*)(a.invstd[k] + (int64_t)g * a.C + c4 * 4);
+        const float4 sc = make_float4(gm.x * istd.x, gm.y * istd.y, gm.z * istd.z, gm.w * istd.w);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+            const int64_t pix = pt + (int64_t)e * T;
+            if (pix < M) {
+                float4 o;
+                o.x = sc.x * (d[e].x - k1.x - xh[k][e].x * k2.x);
+                o.y = sc.y * (d[e].y - k1.y - xh[k][e].y * k2.y);
+                o.z = sc.z * (d[e].z - k1.z - xh[k][e].z * k2.z);
+                o.w = sc.w * (d[e].w - k1.w - xh[k][e].w * k2.w);
+                ((float4*)a.dy[k])[base + pix * C4] = o;
+            }
+        }
+    }
+}
+
 static int g_bn_bwd_cap = 0, g_bn_bwd_unroll = 0, g_bn_bwd_phase = 0;   // micro-benchmark overrides (kbench)
 void bn_bwd_tune(int cap, int unroll, int phase) { g_bn_bwd_cap = cap; g_bn_bwd_unroll = unroll; g_bn_bwd_phase = phase; }
 
@@ -2731,6 +2860,17 @@ int launch_bn_bwd(const BnBwdArgs& a, hipStream_t s) {
     if (g_bn_fused < 0) {
         const char* e = getenv("OCL_BN_FUSED");
         g_bn_fused = e ? atoi(e) : 1;
+    }
+    // small maps: one workgroup per channel quad, no cross-workgroup reduction (bn_bwd_chan_kernel; OCL_BN_CHAN=0: off).  Gate: ONE unit per
+    // thread (all groups' pixels <= 512: layer 4 up to 32 images) and >= 16 channel quads; at two units per thread it is neutral (6 x 84x84) or
+    // loses (64 images in two groups: +7.5 us per pass), at four (layer 3 of a 20-image pass) it loses -- profiles/r6_bn_chan_ab.txt
+    static const bool bn_chan = [] { const char* e = getenv("OCL_BN_CHAN"); return !(e && e[0] == '0'); }();
+    if (bn_chan && g_bn_fused && !a.frozen && g_bn_bwd_phase == 0 && a.G <= 2 && C4 >= 16 && a.m_per_group * a.G <= kBnChanThreads) {
+        ProfScope ps(PROF_BN, s);
+        if (a.nsets == 2) hipLaunchKernelGGL((bn_bwd_chan_kernel<1, 2>), dim3(C4), dim3(kBnChanThreads), 0, s, a);
+        else hipLaunchKernelGGL((bn_bwd_chan_kernel<1, 1>), dim3(C4), dim3(kBnChanThreads), 0, s, a);
+        OCL_LAUNCH_CHECK();
+        return OCL_OK;
     }
     if (g_bn_fused && a.barrier && a.fsums && (a.nsets == 1 || a.fsums_b) && a.G <= 2 && a.C <= 160 && g_bn_bwd_phase == 0 && !a.frozen) {
         if (!g_num_cus) {

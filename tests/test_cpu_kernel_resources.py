@@ -28,7 +28,7 @@ HOT = [
     # the one-wave-per-SIMD forms the planner takes by default (layers 2 - 3, 3x3 stride 1, forward without input transform / data gradient)
     r"conv_wx_kernel<3, 1, 23, 10, (true|false), false, false>", r"conv_wx_kernel<1, 1, 45, 14, (true|false), false, false>",
     r"conv_wx_kernel<1, 1, 23, 7, (true|false), false, false>",
-    r"bn_fwd_kernel", r"bn_bwd_fused_kernel<\d+, \d>", r"bn_bwd_apply_e_kernel", r"wgrad_reduce_kernel", r"wgrad_reduce_multi_kernel",
+    r"bn_fwd_kernel", r"bn_bwd_fused_kernel<\d+, \d>", r"bn_bwd_chan_kernel<1, [12]>", r"bn_bwd_apply_e_kernel", r"wgrad_reduce_kernel", r"wgrad_reduce_multi_kernel",
 ]
 
 
