@@ -83,10 +83,33 @@ SIGNATURES = {
 FWD_TRAIN, FWD_SAVE_TAPE, FWD_UPDATE_RUNNING, FWD_FROZEN_BN, FWD_SAME_WEIGHTS, FWD_PACK_ALL = 1, 2, 4, 8, 16, 32
 
 
+# Every OCL_* variable the package or the library reads (tests/test_cpu_host.py keeps this list equal to the sources).  A variable that is
+# not here does nothing -- an A/B script written for a knob that has since been hard-wired would compare the tree with itself -- so
+# loading the library warns about it.  (OCL_NONE: the scripts' "no switch" placeholder; the rest of the second line: test / script harness.)
+KNOWN_ENV = frozenset("""
+OCL_ASER_AUTOGRAD OCL_ASER_PIPELINE OCL_ASER_SPLIT OCL_BNB_EPI OCL_BN_CHAN OCL_BN_FUSED OCL_CBRS_EMULATE OCL_CBRS_VERIFY_EVERY
+OCL_CONV_PIPE OCL_CONV_Q4 OCL_CONV_S OCL_CONV_S_NT OCL_CONV_W OCL_CONV_WX OCL_DATA_STREAM OCL_DEBUG_SKIP_BN2FWD OCL_DEBUG_SKIP_SHORTCUT
+OCL_DEBUG_SKIP_WGRAD OCL_DETERMINISTIC OCL_DIST_BACKEND OCL_DY_KEEP OCL_GC_FREEZE OCL_GRAPH OCL_GRAPH_VERBOSE OCL_LIB OCL_LOG_PLANS
+OCL_PIN OCL_SIDE_EXTRA_MIN OCL_SINGLE_STREAM OCL_WGRAD_ENOUGH OCL_WGRAD_FLUSH OCL_WGRAD_MULTI OCL_WGRAD_MULTI_TARGET OCL_WGRAD_Q
+OCL_WGRAD_TARGET""".split())
+HARNESS_ENV = frozenset("OCL_NONE OCL_TEST_CASES OCL_TEST_PORT OCL_SHARD_BACKEND OCL_PROBE_STREAM OCL_EAGER_DEVICE".split())
+
+
+def unknown_env(environ=None):
+    """The OCL_* variables of the environment that nothing reads (sorted)."""
+    environ = os.environ if environ is None else environ
+    return sorted(k for k in environ if k.startswith("OCL_") and k not in KNOWN_ENV and k not in HARNESS_ENV)
+
+
 def lib():
     """Loads the shared library (once). Raises if it has not been built: no CPU fallback exists."""
     global _lib
     if _lib is None:
+        dead = unknown_env()
+        if dead:
+            import warnings
+            warnings.warn("environment variables %s are not read by ocl_amd / libocl_hip.so (removed or misspelt switch?): "
+                          "they change nothing" % ", ".join(dead), RuntimeWarning, stacklevel=2)
         if not os.path.isfile(LIB_PATH):
             raise RuntimeError(
                 "libocl_hip.so not found at %s — build it with `python -c 'import __graft_entry__ as g; "

@@ -33,6 +33,27 @@ def test_library_exports_every_header_symbol():
     assert L.ocl_version() >= 100
 
 
+def test_known_env_list_equals_the_switches_the_sources_read():
+    """ffi.KNOWN_ENV (the list behind the 'this variable changes nothing' warning) == every quoted OCL_* name in the package's sources and
+    bench.py; everything tests / scripts set beyond that is either in the list or a harness name."""
+    pkg = os.path.join(ROOT, "online-continual-learning_amd")
+    quoted = set()
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".c", ".h")) and f != "ffi.py":
+                quoted |= set(re.findall(r'"(OCL_[A-Z0-9_]+)"', open(os.path.join(d, f)).read()))
+    quoted |= set(re.findall(r'os\.environ\.get\("(OCL_[A-Z0-9_]+)"', open(os.path.join(pkg, "ffi.py")).read()))
+    assert quoted == set(ffi.KNOWN_ENV), (sorted(quoted - set(ffi.KNOWN_ENV)), sorted(set(ffi.KNOWN_ENV) - quoted))
+    # bench.py and the tests only ever set variables something reads
+    used = set()
+    for f in [os.path.join(ROOT, "bench.py")] + [os.path.join(ROOT, "tests", n) for n in os.listdir(os.path.join(ROOT, "tests")) if n.endswith(".py")]:
+        used |= set(re.findall(r'\b(OCL_[A-Z0-9_]+)\b', open(f).read()))
+    used -= {"OCL_LAUNCH_CHECK", "OCL_BN_FLAT", "OCL_WGRAD_XCD"} | {n for n in used if n.startswith(("OCL_FWD_", "OCL_ERR_", "OCL_OK"))}   # C-side names quoted in comments, this test's own dead knob
+    stray = sorted(n for n in used if n not in ffi.KNOWN_ENV and n not in ffi.HARNESS_ENV)
+    assert not stray, stray
+    assert ffi.unknown_env({"OCL_WGRAD_XCD": "1", "OCL_CONV_W": "0", "OCL_NONE": "1", "HOME": "/"}) == ["OCL_WGRAD_XCD"]
+
+
 def _layout(desc):
     L = ffi.lib()
     h = ffi.vp(0)
